@@ -1,0 +1,76 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
+
+
+def load_golden(name):
+    """Load a fixture as {key: ndarray}; npz only, pickles refused."""
+    with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def group(rec, prefix):
+    p = prefix + "/"
+    return {k[len(p):]: v for k, v in rec.items() if k.startswith(p)}
+
+
+def to_torch(d, device="cpu"):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in d.items()}
+
+
+MODEL_FIXTURES = [
+    "VanillaMF_d16", "VanillaMF_d64", "BiasMF_d16", "SideFeaturesMF_d16", "TemporalMF_d16",
+    "FactorizationMachine_d16", "FactorizationMachine_d64", "GMF_d16", "MLP_d16", "NeuMF_d16",
+    "NeuMF_d64", "WidenDeep_d16", "DeepFactorizationMachine_d16",
+]
+
+
+def model_kwargs(rec):
+    n_users, n_items, n_occ, max_ts, dim, b, n = (int(x) for x in rec["dims"])
+    return dict(n_users=n_users, n_items=n_items, n_occupations=n_occ,
+                max_timestamp_rank=max_ts, embedding_dim=dim)
+
+
+def assert_close(actual, expected, rtol=1e-5, what="", atol=0.0):
+    """|a - e| <= rtol * max(|e|, scale) elementwise, scale = max|expected| of the tensor:
+    relative accuracy measured against the tensor's magnitude, so that sums with
+    cancellation are not held to a relative bound on a near-zero entry.  ``atol`` is for
+    quantities that are zero in exact arithmetic (e.g. the gradient of a Linear bias that
+    feeds BatchNorm), where both sides hold rounding noise only."""
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
+    scale = float(np.abs(e).max()) if e.size else 0.0
+    tol = rtol * np.maximum(np.abs(e), scale) + atol + 1e-12
+    bad = np.abs(a - e) > tol
+    if bad.any():
+        i = np.argmax(np.abs(a - e) - tol)
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{a.size} off; worst |d|={np.abs(a - e).flat[i]:.3e} "
+            f"at {i} (a={a.flat[i]:.8e}, e={e.flat[i]:.8e}, scale={scale:.3e}, rtol={rtol})"
+        )
+
+
+def adagrad_well_conditioned(actual, expected, grad, gmax=None, floor=1e-4):
+    """Adagrad's and Adam's first steps move a weight by about lr * g / |g|: where g is
+    rounding noise around zero the step is decided by that noise (on either side of the
+    comparison), so elements with |g| below ``floor`` times the largest gradient entry of the
+    model are left out.  Rows of a 2-D table whose gradient row is exactly zero (rows the
+    batch never touched) are kept: they must come back unchanged.  Returns the kept elements."""
+    g = np.abs(np.asarray(grad, dtype=np.float64))
+    keep = g > floor * (g.max() if gmax is None else gmax)
+    if g.ndim == 2:
+        keep |= (g.max(axis=1, keepdims=True) == 0)
+    return np.asarray(actual)[keep], np.asarray(expected)[keep]
