@@ -1,0 +1,328 @@
+/*
+ * recsys_hip.h — C ABI of librecsys_hip.so (MI355X / gfx950).
+ *
+ * The reference (huyqd/recsys) exposes its embedding + interaction hot path only as
+ * PyTorch nn.Modules that issue stock torch ops; it has no FFI seam.  This header is the
+ * seam the drop-in modules in recsys_amd/ call instead of those torch ops.  Each entry
+ * point cites the reference op sequence it replaces (paths relative to the reference
+ * checkout).
+ *
+ * Conventions
+ *  - Every function returns 0 on success, nonzero on failure; rx_last_error() then
+ *    returns a thread-local message.  Arguments are validated on the host before any
+ *    launch (null pointers, sizes, supported widths).
+ *  - All pointers named d_* / tables / outputs are DEVICE pointers owned by the caller
+ *    (the host side passes tensor.data_ptr()).  The library never allocates, frees or
+ *    keeps them.  Scratch memory is passed in as `ws` with `ws_bytes`; its size comes
+ *    from the matching *_workspace_bytes() query.
+ *  - `device` is the HIP device ordinal, `stream` a hipStream_t (as void*).  Calls are
+ *    asynchronous on that stream, never synchronise it, and are re-entrant.
+ *  - Embedding tables are row-major fp32 [rows, dim]; indices are int64 (the dtype the
+ *    reference's batches carry, recsys/dataset.py:255-262).
+ *  - `err_flag` (device int32*, may be NULL): kernels never dereference an out-of-range
+ *    row; they skip it and OR a bit into *err_flag (RX_ERR_INDEX).  The host side checks
+ *    the word and raises IndexError, as torch does for nn.Embedding.
+ */
+#ifndef RECSYS_HIP_H
+#define RECSYS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RX_ABI_VERSION 1
+#define RX_ERR_INDEX 1 /* bit set in *err_flag when an index was out of range */
+
+#define RX_MAX_SEGS 8   /* segments per rx_gather_concat call */
+#define RX_MAX_DIM 1024 /* widest embedding row the fused kernels take */
+
+int rx_abi_version(void);
+const char* rx_last_error(void);
+
+/* ------------------------------------------------------------------ gather / assemble
+ * Replaces nn.Embedding lookups followed by unsqueeze/repeat/cat/view when a tower input
+ * is built: recsys/models/neuralcf/mlp.py:67-76, neumf.py:92-101, widendeep.py:79-89,
+ * deep_factorization_machine.py:94-102.  Rows are copied bit-exactly.
+ *
+ * out is [out_rows, out_ld] fp32.  For segment s and output row i:
+ *   j   = (i / s.div) * s.stride + s.k          element of s.idx that row i uses
+ *   row = s.idx[j] + s.base                     row of s.table (base = field offset)
+ *   out[i, s.col : s.col + s.dim] = s.table[row, :]
+ * div = N broadcasts one gathered row over N consecutive output rows (user rows over the
+ * N items of a sample); stride/k pick field k out of a [B, stride] index matrix.
+ */
+typedef struct {
+  const float* table;   /* [rows, dim] */
+  const int64_t* idx;   /* int64 indices */
+  int64_t rows;         /* rows in table (bounds check) */
+  int64_t base;         /* added to every index */
+  int32_t dim;          /* row width */
+  int32_t col;          /* first output column */
+  int32_t div;          /* >= 1 */
+  int32_t stride;       /* >= 1 */
+  int32_t k;            /* 0 <= k < stride */
+  int32_t pad_;
+} rx_gather_seg;
+
+int rx_gather_concat(const rx_gather_seg* segs, int n_segs, float* d_out, int64_t out_rows,
+                     int64_t out_ld, int32_t* err_flag, int device, void* stream);
+
+/* Backward companion for one segment: the gradient of the q-th gathered row
+ * (q = 0 .. out_rows/div - 1, the row that used index element q*stride + k) is
+ *   occ[q, :] = sum_{r < div} d_out[q*div + r, col : col+dim]
+ * occ is [out_rows/div, dim] fp32. */
+int rx_gather_concat_bwd(const float* d_dout, int64_t out_rows, int64_t out_ld, int32_t col,
+                         int32_t dim, int32_t div, float* d_occ, int device, void* stream);
+
+/* ------------------------------------------------------------------ MF-family score
+ * Replaces, fused, without the [B,N,D] temporaries:
+ *   VanillaMF      recsys/models/matrix_factorization/vanilla_mf.py:29-31
+ *   BiasMF         bias_mf.py:16-18,28-35
+ *   SideFeaturesMF side_features_mf.py:24-40
+ *   TemporalMF     temporal_mf.py:34-54
+ *   GMF            recsys/models/neuralcf/gmf.py:49-57 (lin_w != NULL: Linear(D,1) folded in)
+ *
+ * logits[b,n] = sum_d (U[u_b,d] + O[o_b,d]) * V[i_bn,d] * lin_w[d]  + lin_b
+ *             + bias + user_bias[u_b] + item_bias[i_bn]
+ *             + sum_d UT[u_b,d] * T[t_b,d]
+ * Any of O, lin_w/lin_b, the three biases and UT/T may be NULL (term absent).
+ */
+typedef struct {
+  const float* user_table;  int64_t n_users;      /* U  [n_users, dim] */
+  const float* item_table;  int64_t n_items;      /* V  [n_items, dim] */
+  const float* occ_table;   int64_t n_occ;        /* O  [n_occ, dim] or NULL */
+  const float* utemp_table;                       /* UT [n_users, dim] or NULL */
+  const float* temp_table;  int64_t n_temp;       /* T  [n_temp, dim] or NULL */
+  const float* user_bias;                         /* [n_users] or NULL */
+  const float* item_bias;                         /* [n_items] or NULL */
+  const float* bias;                              /* [1] or NULL */
+  const float* lin_w;                             /* [dim] or NULL */
+  const float* lin_b;                             /* [1] or NULL */
+  const int64_t* users;                           /* [B] */
+  const int64_t* items;                           /* [B, N] */
+  const int64_t* occs;                            /* [B] or NULL */
+  const int64_t* temps;                           /* [B] or NULL */
+  int64_t B; int32_t N; int32_t dim;
+} rx_mf_args;
+
+int rx_mf_score_fwd(const rx_mf_args* a, float* d_logits, int32_t* err_flag, int device,
+                    void* stream);
+
+/* Backward of the above given g = dL/dlogits [B,N].  Writes per-occurrence gradients:
+ *   d_user_occ [B, dim]   = sum_n g_bn * V[i_bn] * lin_w        (also the gradient of O rows)
+ *   d_item_occ [B*N, dim] = g_bn * (U+O) * lin_w
+ *   d_utemp_occ[B, dim]   = (sum_n g_bn) * T[t_b]      d_temp_occ [B, dim] = (sum_n g_bn) * UT[u_b]
+ *   d_gsum     [B]        = sum_n g_bn                 (gradient of user_bias[u_b])
+ *   d_linw_part[grid, dim]  per-block partial sums of g_bn*(U+O)*V  (reduced in block order
+ *                           by rx_colsum_partials; NULL when lin_w is NULL)
+ * rx_mf_bwd_grid() returns the number of blocks = rows of d_linw_part.  */
+int64_t rx_mf_bwd_grid(int64_t B, int32_t dim);
+int rx_mf_score_bwd(const rx_mf_args* a, const float* d_g, float* d_user_occ, float* d_item_occ,
+                    float* d_utemp_occ, float* d_temp_occ, float* d_gsum, float* d_linw_part,
+                    int device, void* stream);
+
+/* out[c] = sum over r in block order of part[r, c]; fixed order, bitwise reproducible. */
+int rx_colsum_partials(const float* d_part, int64_t rows, int32_t cols, float* d_out, int device,
+                       void* stream);
+
+/* ------------------------------------------------------------------ GMF product (NeuMF)
+ * prod[b*N+n, col:col+dim] = U[u_b] * V[i_bn]   — recsys/models/neuralcf/neumf.py:84-89 ahead
+ * of linear_gmf.  Backward: d_user_occ[b] = sum_n dprod[b,n]*V[i_bn]; d_item_occ[b,n] = dprod*U. */
+int rx_gmf_mul_fwd(const float* user_table, int64_t n_users, const float* item_table,
+                   int64_t n_items, const int64_t* users, const int64_t* items, int64_t B,
+                   int32_t N, int32_t dim, float* d_out, int64_t out_ld, int32_t col,
+                   int32_t* err_flag, int device, void* stream);
+int rx_gmf_mul_bwd(const float* user_table, int64_t n_users, const float* item_table,
+                   int64_t n_items, const int64_t* users, const int64_t* items, int64_t B,
+                   int32_t N, int32_t dim, const float* d_dout, int64_t out_ld, int32_t col,
+                   float* d_user_occ, float* d_item_occ, int device, void* stream);
+
+/* ------------------------------------------------------------------ FM second order
+ * Replaces recsys/models/matrix_factorization/factorization_machine.py:33-64 and the same
+ * block of recsys/models/neuralcf/deep_factorization_machine.py:62-92 (one shared table,
+ * field offsets, D=1 bias table gathered with the same indices, sum-square minus
+ * square-sum).  ex_idx is [B, F] with per-field offsets ex_base[f] added on the fly;
+ * item_idx is [B, N] with item_base added.
+ *
+ * logits[b,n] = sum_f bias[ex_f] + bias[item_n]
+ *             + 0.5 * sum_d [ (sum_f e_f + v_n)^2 - (sum_f e_f^2 + v_n^2) ]_d
+ * deep_out (may be NULL) receives the gathered rows as the DeepFM tower input
+ * [B*N, (1+F)*dim]: item row first, then the F rows (deep_factorization_machine.py:94-102).
+ * With N == 1 and F = 25 this is the 26-field Criteo-shaped FM.
+ */
+typedef struct {
+  const float* feat;        /* [n_feat, dim] */
+  const float* bias;        /* [n_feat] (the [n_feat,1] table) or NULL */
+  int64_t n_feat;
+  const int64_t* ex_idx;    /* [B, F] */
+  const int64_t* ex_base;   /* device [F] offsets */
+  const int64_t* item_idx;  /* [B, N] */
+  int64_t item_base;
+  int64_t B; int32_t F; int32_t N; int32_t dim;
+  int32_t flags;            /* RX_FM_NO_SECOND_ORDER: bias sums only (the wide part of
+                               recsys/models/neuralcf/widendeep.py:69-77); rows still feed deep_out */
+} rx_fm_args;
+#define RX_FM_NO_SECOND_ORDER 1
+
+int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, int32_t* err_flag,
+               int device, void* stream);
+
+/* Backward given g [B,N] (and optionally d_deep [B*N,(1+F)*dim]):
+ *   d_occ [(B*F + B*N), dim]: rows 0..B*F-1 = gradient of e_(b,f); then B*N item rows
+ *   d_bias_occ [(B*F + B*N)]: gradient of the bias entries in the same order (NULL ok)
+ * d e_f = G (S - e_f) + sum_n g_n v_n ; d v_n = g_n S ; G = sum_n g_n ; S = sum_f e_f. */
+int rx_fm2_bwd(const rx_fm_args* a, const float* d_g, const float* d_deep, float* d_occ,
+               float* d_bias_occ, int device, void* stream);
+
+/* Flat index list in the order of d_occ above (row ids with offsets applied), int64. */
+int rx_fm2_flat_indices(const rx_fm_args* a, int64_t* d_flat, int device, void* stream);
+
+/* ------------------------------------------------------------------ BCE with logits
+ * F.binary_cross_entropy_with_logits(logits f32, labels f64|f32), mean reduction — call
+ * sites vanilla_mf.py:35-39, factorization_machine.py:68-72, gmf.py:41-45, mlp.py:59-63,
+ * neumf.py:75-79, widendeep.py:96-100, deep_factorization_machine.py:109-113.  The loss is
+ * accumulated and returned in fp64 (labels are fp64 in the reference, dataset.py:184).
+ * d_dlogits (may be NULL) = (sigmoid(x) - y) / M.  ws: rx_bce_workspace_bytes(M). */
+size_t rx_bce_workspace_bytes(int64_t M);
+int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int64_t M,
+               double* d_loss, float* d_dlogits, void* ws, size_t ws_bytes, int device,
+               void* stream);
+
+/* ------------------------------------------------------------------ index sort / dedup
+ * First stage of the deterministic backward that replaces aten embedding_dense_backward /
+ * index_put_(accumulate=True) (what autograd runs for every nn.Embedding and 1-D bias
+ * parameter of the reference models).  Stable LSD radix sort of (row, position) pairs,
+ * then run-length compaction:
+ *   sorted_pos [n] int32   positions 0..n-1 ordered by (row, position)
+ *   uniq_rows  [n] int64   distinct rows ascending (first *n_uniq entries valid)
+ *   seg_off    [n+1] int32 start of each row's run in sorted_pos; seg_off[*n_uniq] = n
+ *   n_uniq     [1] int32   (device)
+ *   inverse    [n] int32   slot of each occurrence's row in uniq_rows (may be NULL)
+ * Rows must lie in [0, n_rows); n_rows <= 2^32.  Out-of-range rows set err_flag and are
+ * clamped.  Equal to torch.sort(stable=True) / torch.unique(sorted=True, return_inverse). */
+size_t rx_sort_dedup_workspace_bytes(int64_t n);
+int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
+                  int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
+                  int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
+                  void* stream);
+
+/* ------------------------------------------------------------------ segmented reduce + update
+ * Second stage.  For each distinct row u (fixed order: positions ascending) the gradient
+ *   G_u = sum_{p in run u} occ[sorted_pos[p], :]
+ * is formed by one lane group without atomics, then consumed according to `mode`:
+ *   RX_SEG_DENSE   grad[row, :]  = G_u                   (grad pre-zeroed by the caller)
+ *   RX_SEG_COMPACT grad[u, :]    = G_u
+ *   RX_SEG_SGD     w[row] -= lr * scale * G_u                              (torch.optim.SGD)
+ *   RX_SEG_ADAGRAD state[row] += (scale G_u)^2 ; w[row] -= lr * scale G_u / (sqrt(state)+eps)
+ *                                                                      (torch.optim.Adagrad)
+ *   RX_SEG_ROWWISE_ADAGRAD  state[row] (one float per row) += mean_d (scale G_u)^2
+ * scale = *d_scale if d_scale != NULL else 1 (global-norm clip factor, recsys/utils.py:101).
+ * d_sq_part (may be NULL) [rx_segreduce_grid(n, dim)] receives per-block sum of G_u^2. */
+enum { RX_SEG_DENSE = 0, RX_SEG_COMPACT = 1, RX_SEG_SGD = 2, RX_SEG_ADAGRAD = 3,
+       RX_SEG_ROWWISE_ADAGRAD = 4 };
+int64_t rx_segreduce_grid(int64_t n, int32_t dim);
+int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
+                 const int32_t* d_sorted_pos, const int64_t* d_uniq_rows,
+                 const int32_t* d_seg_off, const int32_t* d_n_uniq, int mode, float* d_target,
+                 float* d_state, int64_t n_rows, float lr, float eps, const float* d_scale,
+                 float* d_sq_part, int device, void* stream);
+
+/* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
+ * step when a global clip factor must be known before any row moves). mode as above
+ * (SGD / ADAGRAD / ROWWISE_ADAGRAD). */
+int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
+                  const int32_t* d_n_uniq, int64_t n_max, int mode, float* d_w, float* d_state,
+                  int64_t n_rows, float lr, float eps, const float* d_scale, int device,
+                  void* stream);
+
+/* Dense full-table optimizers for MovieLens-sized tables and tower weights, one launch per
+ * tensor: torch.optim.Adam(lr, betas, eps) exactly as recsys/pipelines/ build it
+ * (e.g. recsys/pipelines/neuralcf/neumf.py:10), and SGD / Adagrad.  scale as above. */
+int rx_dense_adam(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, const float* d_scale,
+                  int device, void* stream);
+int rx_dense_sgd(float* d_w, const float* d_g, int64_t n, float lr, const float* d_scale,
+                 int device, void* stream);
+int rx_dense_adagrad(float* d_w, const float* d_g, float* d_state, int64_t n, float lr, float eps,
+                     const float* d_scale, int device, void* stream);
+
+/* Sum of squares of a tensor (fp64 accumulate, fixed order) added into *d_acc (device
+ * double); and scale = min(1, max_norm / (sqrt(*d_acc) + 1e-6)) as clip_grad_norm_ does
+ * (recsys/utils.py:101). ws: rx_sumsq_workspace_bytes(n). */
+size_t rx_sumsq_workspace_bytes(int64_t n);
+int rx_sumsq_accumulate(const float* d_x, int64_t n, double* d_acc, void* ws, size_t ws_bytes,
+                        int device, void* stream);
+/* *d_acc += sum(x): adds the per-block partials that rx_segreduce wrote to d_sq_part. */
+int rx_sum_accumulate(const float* d_x, int64_t n, double* d_acc, void* ws, size_t ws_bytes,
+                      int device, void* stream);
+int rx_clip_scale(const double* d_acc, float max_norm, float* d_scale, float* d_total_norm,
+                  int device, void* stream);
+/* out[0] = sum(x) (fp64 accumulate, fixed order): gradient of a scalar bias that is added to
+ * every logit (bias_mf.py:12,17; the Linear(D,1) bias of gmf.py:20). Same workspace size. */
+int rx_reduce_sum(const float* d_x, int64_t n, float* d_out, void* ws, size_t ws_bytes, int device,
+                  void* stream);
+
+/* ------------------------------------------------------------------ dense layers (MFMA)
+ * nn.Linear (+ReLU) of the towers: recsys/models/neuralcf/mlp.py:27-36, neumf.py:21,36-47,
+ * widendeep.py:10-21, deep_factorization_machine.py:10-21.  fp32 in/out; `bf16` != 0 rounds
+ * the operands to bf16 for v_mfma_f32_32x32x16_bf16 with fp32 accumulation, otherwise the
+ * exact-fp32 v_mfma_f32_32x32x2_f32 is used.
+ *   rx_linear_fwd : Y[M,N] = act(X[M,K] W[N,K]^T + b)           act: 0 none, 1 ReLU
+ *   rx_linear_bwd_x: dX[M,K] = dY[M,N] W[N,K]                    (accumulate != 0: dX += )
+ *   rx_linear_bwd_w: dW[N,K] = dY^T X, db[N] = colsum(dY)        ws from the query below
+ * ldx/ldy/ldd are row strides in elements (sub-blocks of wider matrices are allowed).
+ * rx_relu_bwd: dZ = dY * (Y > 0) elementwise. */
+int rx_linear_fwd(const float* X, int64_t ldx, const float* W, const float* b, float* Y,
+                  int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int bf16, int device,
+                  void* stream);
+int rx_linear_bwd_x(const float* dY, int64_t ldd, const float* W, float* dX, int64_t ldx,
+                    int64_t M, int32_t N, int32_t K, int accumulate, int bf16, int device,
+                    void* stream);
+size_t rx_linear_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, float* dW,
+                    float* db, int64_t M, int32_t N, int32_t K, int bf16, void* ws,
+                    size_t ws_bytes, int device, void* stream);
+int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int device, void* stream);
+
+/* ------------------------------------------------------------------ DCN-v2 cross layer
+ * No counterpart in the reference.  x_{l+1} = x0 * (x_l W^T + b) + x_l, W [d,d].
+ * fwd: XW = rx_linear_fwd(x_l, W, b) then rx_cross_combine; bwd elementwise part:
+ *   given dXn: dU = dXn * x0 ; dX0 += dXn * U ; dXl (+)= dXn          (U = x_l W^T + b) */
+int rx_cross_combine_fwd(const float* x0, const float* u, const float* xl, float* xn, int64_t n,
+                         int device, void* stream);
+int rx_cross_combine_bwd(const float* dxn, const float* x0, const float* u, float* du,
+                         float* dx0_acc, float* dxl, int64_t n, int device, void* stream);
+
+/* ------------------------------------------------------------------ row-sharded exchange helpers
+ * No counterpart in the reference (single device).  Row r of a table lives on rank r % G at
+ * local row r / G.  Bucketise a rank's index list by owner so one all-to-all (issued by the
+ * host through torch.distributed / RCCL) can ship it:
+ *   counts [G] int64        number of indices owned by each rank
+ *   send_local [n] int64    local row ids (r / G) grouped by owner, original order kept
+ *   perm [n] int32          perm[j] = position in the input of the j-th sent index
+ * rx_unpermute_rows scatters received rows back: out[perm[j], :] = rows[j, :];
+ * rx_permute_rows gathers gradient rows into send order: out[j, :] = rows[perm[j], :]. */
+size_t rx_bucketize_workspace_bytes(int64_t n, int32_t G);
+int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G, int64_t n_rows_global,
+                          int64_t* d_counts, int64_t* d_send_local, int32_t* d_perm, void* ws,
+                          size_t ws_bytes, int32_t* err_flag, int device, void* stream);
+int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
+                      float* d_out, int device, void* stream);
+int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
+                    float* d_out, int device, void* stream);
+
+/* ------------------------------------------------------------------ evaluation
+ * Top-k item codes per user from list-wise scores, replacing the host numpy
+ * argsort[:, ::-1][:, :k] + take_along_axis of recsys/utils.py:40-58.  Ties resolve like a
+ * stable ascending argsort read backwards: among equal scores the LARGER column comes first.
+ * scores [rows, n] fp32, codes [rows, n] int64 or NULL (then column ids are returned). */
+int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, int32_t n,
+                  int32_t k, int64_t* d_out, int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECSYS_HIP_H */

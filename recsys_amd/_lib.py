@@ -1,0 +1,113 @@
+"""ctypes binding of librecsys_hip.so (the C ABI declared in include/recsys_hip.h).
+
+The library is built in-tree by ``recsys_amd/csrc/Makefile`` (or ``__graft_entry__.build()``)
+into ``recsys_amd/librecsys_hip.so``.  There is no fallback: if it is missing, importing this
+module raises, and every op in ``recsys_amd`` is unusable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecsys_hip.so")
+
+i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
+vp, sz = C.c_void_p, C.c_size_t
+
+
+class GatherSeg(C.Structure):
+    _fields_ = [("table", vp), ("idx", vp), ("rows", i64), ("base", i64), ("dim", i32),
+                ("col", i32), ("div", i32), ("stride", i32), ("k", i32), ("pad_", i32)]
+
+
+class MFArgs(C.Structure):
+    _fields_ = [("user_table", vp), ("n_users", i64), ("item_table", vp), ("n_items", i64),
+                ("occ_table", vp), ("n_occ", i64), ("utemp_table", vp), ("temp_table", vp),
+                ("n_temp", i64), ("user_bias", vp), ("item_bias", vp), ("bias", vp),
+                ("lin_w", vp), ("lin_b", vp), ("users", vp), ("items", vp), ("occs", vp),
+                ("temps", vp), ("B", i64), ("N", i32), ("dim", i32)]
+
+
+class FMArgs(C.Structure):
+    _fields_ = [("feat", vp), ("bias", vp), ("n_feat", i64), ("ex_idx", vp), ("ex_base", vp),
+                ("item_idx", vp), ("item_base", i64), ("B", i64), ("F", i32), ("N", i32),
+                ("dim", i32), ("flags", i32)]
+
+
+RX_FM_NO_SECOND_ORDER = 1
+
+# name -> (restype, argtypes); must list every symbol of include/recsys_hip.h
+PROTOTYPES = {
+    "rx_abi_version": (C.c_int, []),
+    "rx_last_error": (C.c_char_p, []),
+    "rx_gather_concat": (C.c_int, [C.POINTER(GatherSeg), C.c_int, vp, i64, i64, vp, C.c_int, vp]),
+    "rx_gather_concat_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, C.c_int, vp]),
+    "rx_mf_score_fwd": (C.c_int, [C.POINTER(MFArgs), vp, vp, C.c_int, vp]),
+    "rx_mf_bwd_grid": (i64, [i64, i32]),
+    "rx_mf_score_bwd": (C.c_int, [C.POINTER(MFArgs), vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
+    "rx_colsum_partials": (C.c_int, [vp, i64, i32, vp, C.c_int, vp]),
+    "rx_gmf_mul_fwd": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, i64, i32, vp, C.c_int, vp]),
+    "rx_gmf_mul_bwd": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, i64, i32, vp, vp, C.c_int, vp]),
+    "rx_fm2_fwd": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, C.c_int, vp]),
+    "rx_fm2_bwd": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, C.c_int, vp]),
+    "rx_fm2_flat_indices": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp]),
+    "rx_bce_workspace_bytes": (sz, [i64]),
+    "rx_bce_fwd": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, sz, C.c_int, vp]),
+    "rx_sort_dedup_workspace_bytes": (sz, [i64]),
+    "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
+    "rx_segreduce_grid": (i64, [i64, i32]),
+    "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, vp, i64, f32, f32, vp, vp, C.c_int, vp]),
+    "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
+    "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),
+    "rx_dense_adagrad": (C.c_int, [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_sumsq_workspace_bytes": (sz, [i64]),
+    "rx_sumsq_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
+    "rx_sum_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
+    "rx_clip_scale": (C.c_int, [vp, f32, vp, vp, C.c_int, vp]),
+    "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
+    "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
+    "rx_linear_bwd_x": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
+    "rx_linear_bwd_w_workspace_bytes": (sz, [i64, i32, i32]),
+    "rx_linear_bwd_w": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, C.c_int, vp, sz, C.c_int, vp]),
+    "rx_relu_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "rx_cross_combine_fwd": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, vp]),
+    "rx_cross_combine_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, C.c_int, vp]),
+    "rx_bucketize_workspace_bytes": (sz, [i64, i32]),
+    "rx_bucketize_by_owner": (C.c_int, [vp, i64, i32, i64, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
+    "rx_unpermute_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),
+    "rx_permute_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),
+    "rx_topk_codes": (C.c_int, [vp, vp, i64, i32, i32, vp, C.c_int, vp]),
+}
+
+RX_SEG_DENSE, RX_SEG_COMPACT, RX_SEG_SGD, RX_SEG_ADAGRAD, RX_SEG_ROWWISE_ADAGRAD = range(5)
+RX_ERR_INDEX = 1
+RX_ABI_VERSION = 1
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). recsys_amd has no "
+            "fallback path; its ops run only through this HIP library."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.rx_abi_version()
+    if got != RX_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {RX_ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.rx_last_error()
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,232 @@
+"""torch.autograd glue: each Function's forward and backward is one or a few C-ABI launches.
+
+Embedding-table gradients never go through aten's embedding_dense_backward.  Each lookup site
+yields per-occurrence gradient rows; ``table_backward`` sorts/dedups the indices
+(rx_sort_dedup) and runs the segmented reduction (rx_segreduce) which either
+
+* writes a dense ``[rows, dim]`` gradient (drop-in mode: any torch optimizer, clip_grad_norm_
+  and the reference train loop keep working unchanged), or
+* applies the sparse row update in the same pass when the parameter carries a sparse rule
+  (see ``optim.FusedOptimizer``); the parameter's ``.grad`` then stays ``None``.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import _lib, ops
+from .ops import Segment, SortedIndex
+
+Tensor = torch.Tensor
+
+
+def table_backward(param: Optional[Tensor], si: SortedIndex, occ: Tensor, dim: Optional[int] = None,
+                   occ_ld: Optional[int] = None) -> Optional[Tensor]:
+    """Reduce per-occurrence gradients ``occ`` (rows ordered like the index list behind ``si``)
+    into ``param``'s gradient, or apply the parameter's fused sparse rule."""
+    if param is None:
+        return None
+    rule = getattr(param, "_rx_sparse", None)
+    if rule is not None:
+        rule.apply(param, occ, si, dim=dim, occ_ld=occ_ld)
+        return None
+    grad = torch.zeros_like(param)
+    ops.segreduce(occ, si, _lib.RX_SEG_DENSE, grad, dim=dim, occ_ld=occ_ld)
+    return grad
+
+
+# ------------------------------------------------------------------ MF-family score
+class MFScore(Function):
+    """logits[B,N] of the matrix-factorization family / GMF (rx_mf_score_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, users, items, occs, temps, U, V, O, UT, T, user_bias, item_bias, bias, lin_w, lin_b):
+        kw = dict(O=O, occs=occs, UT=UT, T=T, temps=temps, user_bias=user_bias, item_bias=item_bias,
+                  bias=bias, lin_w=None if lin_w is None else lin_w.reshape(-1), lin_b=lin_b)
+        ctx.kw = kw
+        ctx.args = (U, V, users, items)
+        ctx.lin_w = lin_w
+        return ops.mf_score_fwd(U, V, users, items, **kw)
+
+    @staticmethod
+    def backward(ctx, g):
+        U, V, users, items = ctx.args
+        kw = ctx.kw
+        g = g.contiguous()
+        user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, **kw)
+        su = ops.sort_dedup(users, U.shape[0])
+        si = ops.sort_dedup(items, V.shape[0])
+        gU = table_backward(U, su, user_occ)
+        gV = table_backward(V, si, item_occ)
+        gO = gUT = gT = gub = gib = gb = glw = glb = None
+        if kw["O"] is not None:
+            gO = table_backward(kw["O"], ops.sort_dedup(kw["occs"], kw["O"].shape[0]), user_occ)
+        if kw["UT"] is not None:
+            gUT = table_backward(kw["UT"], su, utemp_occ)
+            gT = table_backward(kw["T"], ops.sort_dedup(kw["temps"], kw["T"].shape[0]), temp_occ)
+        if kw["user_bias"] is not None:
+            gub = table_backward(kw["user_bias"], su, gsum, dim=1)
+        if kw["item_bias"] is not None:
+            gib = table_backward(kw["item_bias"], si, g.reshape(-1), dim=1)
+        if kw["bias"] is not None:
+            gb = ops.reduce_sum(g.reshape(-1)).reshape(kw["bias"].shape)
+        if ctx.lin_w is not None:
+            glw = linw_grad.reshape(ctx.lin_w.shape)
+        if kw["lin_b"] is not None:
+            glb = ops.reduce_sum(g.reshape(-1)).reshape(kw["lin_b"].shape)
+        return (None, None, None, None, gU, gV, gO, gUT, gT, gub, gib, gb, glw, glb)
+
+
+# ------------------------------------------------------------------ FM second order (+ DeepFM tower input)
+class FM2(Function):
+    """FM bias + second-order term over one shared table (rx_fm2_fwd / _bwd).  Returns
+    ``(logits[B,N], deep[B*N,(1+F)*D] or None)``."""
+
+    @staticmethod
+    def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True):
+        bias_flat = None if bias_table is None else bias_table.reshape(-1)
+        logits, deep = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep, second_order)
+        ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
+        ctx.second_order = second_order
+        return logits, deep
+
+    @staticmethod
+    def backward(ctx, g, g_deep):
+        ex_idx, ex_base, item_idx, item_base, feat, bias_table = ctx.args
+        if g is None:
+            g = torch.zeros(item_idx.shape[0], item_idx.shape[1] if item_idx.dim() == 2 else 1,
+                            dtype=torch.float32, device=feat.device)
+        g = g.contiguous()
+        if g_deep is not None:
+            g_deep = g_deep.contiguous()
+        bias_flat = None if bias_table is None else bias_table.reshape(-1)
+        occ, bias_occ = ops.fm2_bwd(g, g_deep, feat, bias_flat, ex_idx, ex_base, item_idx, item_base,
+                                    ctx.second_order)
+        flat = ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base)
+        s = ops.sort_dedup(flat, feat.shape[0])
+        gfeat = table_backward(feat, s, occ)
+        gbias = table_backward(bias_table, s, bias_occ, dim=1) if bias_table is not None else None
+        return (None, None, None, None, gfeat, gbias, None, None)
+
+
+# ------------------------------------------------------------------ tower-input assembly
+class GatherConcat(Function):
+    """out[M, W] assembled from gathered rows (rx_gather_concat).  ``spec`` is a list of
+    ``(param_slot, idx, col, div, stride, k, base)``; ``tables`` the distinct table parameters."""
+
+    @staticmethod
+    def forward(ctx, spec, out_rows, out_cols, *tables):
+        segs = [Segment(tables[slot], idx, col, div, stride, k, base) for (slot, idx, col, div, stride, k, base) in spec]
+        ctx.spec, ctx.tables, ctx.out_rows = spec, tables, out_rows
+        return ops.gather_concat(segs, out_rows, out_cols)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        grads = []
+        for slot, table in enumerate(ctx.tables):
+            mine = [s for s in ctx.spec if s[0] == slot]
+            dim = table.shape[1]
+            n_each = [ctx.out_rows // s[3] for s in mine]
+            occ = torch.empty(sum(n_each), dim, dtype=torch.float32, device=dout.device)
+            idx_parts = []
+            o = 0
+            for s, n in zip(mine, n_each):
+                _, idx, col, div, stride, k, base = s
+                ops_occ = ops.gather_concat_bwd(dout, col, dim, div)
+                occ[o:o + n].copy_(ops_occ)
+                o += n
+                used = idx.reshape(-1, stride)[:n, k] if stride > 1 else idx.reshape(-1)[:n]
+                idx_parts.append(used + base if base else used)
+            flat = idx_parts[0] if len(idx_parts) == 1 else torch.cat(idx_parts)
+            si = ops.sort_dedup(flat.contiguous(), table.shape[0])
+            grads.append(table_backward(table, si, occ))
+        return (None, None, None, *grads)
+
+
+# ------------------------------------------------------------------ GMF product feeding a GEMM
+class GMFMul(Function):
+    @staticmethod
+    def forward(ctx, users, items, U, V):
+        ctx.args = (users, items, U, V)
+        return ops.gmf_mul_fwd(U, V, users, items)
+
+    @staticmethod
+    def backward(ctx, dout):
+        users, items, U, V = ctx.args
+        user_occ, item_occ = ops.gmf_mul_bwd(dout.contiguous(), U, V, users, items)
+        gU = table_backward(U, ops.sort_dedup(users, U.shape[0]), user_occ)
+        gV = table_backward(V, ops.sort_dedup(items, V.shape[0]), item_occ)
+        return None, None, gU, gV
+
+
+# ------------------------------------------------------------------ Linear (+ReLU) on the matrix cores
+class LinearAct(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, bf16):
+        y = ops.linear_fwd(x, w, b, act, bf16)
+        ctx.save_for_backward(x, w, y if act else None)
+        ctx.act, ctx.bf16, ctx.has_b = act, bf16, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act:
+            dy = ops.relu_bwd(dy, y)
+        dx = ops.linear_bwd_x(dy, w, ctx.bf16) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dw, db = ops.linear_bwd_w(dy, x, ctx.has_b, ctx.bf16)
+        return dx, dw, db, None, None
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool = False, bf16: bool = False) -> Tensor:
+    return LinearAct.apply(x, w, b, 1 if relu else 0, bf16)
+
+
+# ------------------------------------------------------------------ DCN-v2 cross layer
+class CrossLayer(Function):
+    """x_{l+1} = x0 * (x_l W^T + b) + x_l."""
+
+    @staticmethod
+    def forward(ctx, x0, xl, w, b, bf16):
+        u = ops.linear_fwd(xl, w, b, 0, bf16)
+        xn = ops.cross_combine_fwd(x0, u, xl)
+        ctx.save_for_backward(x0, xl, w, u)
+        ctx.bf16 = bf16
+        return xn
+
+    @staticmethod
+    def backward(ctx, dxn):
+        x0, xl, w, u = ctx.saved_tensors
+        dxn = dxn.contiguous()
+        dx0 = torch.zeros_like(x0)
+        du, dxl = ops.cross_combine_bwd(dxn, x0, u, dx0)
+        ops.linear_bwd_x(du, w, ctx.bf16, out=dxl, accumulate=True)
+        dw, db = ops.linear_bwd_w(du, xl, True, ctx.bf16)
+        return dx0, dxl, dw, db, None
+
+
+# ------------------------------------------------------------------ loss
+class BCEWithLogits(Function):
+    """Mean BCE-with-logits; fp64 loss when the labels are fp64, like the reference."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dl = ops.bce_with_logits(logits.contiguous(), labels.contiguous(), True)
+        ctx.save_for_backward(dl)
+        ctx.shape = logits.shape
+        return loss if labels.dtype == torch.float64 else loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g.to(torch.float32)).reshape(ctx.shape), None
+
+
+def bce_with_logits(logits: Tensor, labels: Tensor) -> Tensor:
+    return BCEWithLogits.apply(logits, labels)

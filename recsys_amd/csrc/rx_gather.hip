@@ -1,0 +1,144 @@
+// Embedding row gather / tower-input assembly and its per-occurrence backward (gfx950).
+//
+// Rows are moved as 16-byte pieces: a group of dim/4 lanes owns one output row segment, so
+// a 64-float row is one 256-byte coalesced read and a 16-float row a single 64-byte read per
+// 4 lanes.  Indices are read once per group leader and broadcast with a wave shuffle.
+#include "rx_common.h"
+
+thread_local char rx_err_buf[512] = "";
+
+extern "C" const char* rx_last_error(void) { return rx_err_buf; }
+extern "C" int rx_abi_version(void) { return RX_ABI_VERSION; }
+
+struct GatherSegs {
+  rx_gather_seg s[RX_MAX_SEGS];
+  int n;
+};
+
+// One launch per segment keeps the lane->row mapping exact for each width.
+template <int VEC>
+__global__ void __launch_bounds__(RX_BLOCK)
+gather_seg_kernel(rx_gather_seg s, float* __restrict__ out, int64_t out_rows, int64_t out_ld,
+                  int group, int chunks, int32_t* err_flag) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = gid / group;  // output row
+  const int lg = (int)(gid % group);
+  if (i >= out_rows) return;
+  const int64_t j = (i / s.div) * s.stride + s.k;
+  // every lane of the group reads the same 8 bytes: one broadcast load from L1
+  const int64_t row = s.idx[j] + s.base;
+  const bool ok = rx_row_ok(row, s.rows, lg == 0 ? err_flag : nullptr);
+  const float* src = s.table + row * (int64_t)s.dim;
+  float* dst = out + i * out_ld + s.col;
+  for (int k = 0; k < chunks; ++k) {
+    const int c = (lg + k * group) * VEC;
+    if (c < s.dim) {
+      RxPack<VEC> v = ok ? rx_load<VEC>(src + c) : rx_zero<VEC>();
+      rx_store<VEC>(dst + c, v);
+    }
+  }
+}
+
+extern "C" int rx_gather_concat(const rx_gather_seg* segs, int n_segs, float* d_out,
+                                int64_t out_rows, int64_t out_ld, int32_t* err_flag, int device,
+                                void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n_segs >= 1 && n_segs <= RX_MAX_SEGS, "rx_gather_concat: n_segs %d not in 1..%d", n_segs, RX_MAX_SEGS);
+  RX_REQUIRE(out_rows >= 0 && out_ld >= 1, "rx_gather_concat: bad output shape");
+  if (out_rows == 0) return 0;
+  RX_REQUIRE(segs && d_out, "rx_gather_concat: null argument");
+  for (int q = 0; q < n_segs; ++q) {
+    const rx_gather_seg& s = segs[q];
+    RX_REQUIRE(s.table && s.idx, "rx_gather_concat: segment %d has a null pointer", q);
+    RX_REQUIRE(s.dim >= 1 && s.dim <= RX_MAX_DIM, "rx_gather_concat: segment %d dim %d unsupported", q, s.dim);
+    RX_REQUIRE(s.div >= 1 && s.stride >= 1 && s.k >= 0 && s.k < s.stride, "rx_gather_concat: segment %d bad div/stride/k", q);
+    RX_REQUIRE(s.col >= 0 && (int64_t)s.col + s.dim <= out_ld, "rx_gather_concat: segment %d exceeds out_ld", q);
+    RxRowShape sh = rx_row_shape(s.dim);
+    const bool vec4 = sh.vec == 4 && (s.col % 4 == 0) && (out_ld % 4 == 0) && rx_aligned16(s.table) && rx_aligned16(d_out);
+    if (!vec4) {
+      sh.vec = 1;
+      int g = 1;
+      while (g < s.dim && g < 64) g <<= 1;
+      sh.group = g;
+      sh.chunks = (s.dim + g - 1) / g;
+    }
+    const int64_t threads = out_rows * sh.group;
+    const unsigned grid = (unsigned)rx_cdiv(threads, RX_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec4)
+      hipLaunchKernelGGL(gather_seg_kernel<4>, dim3(grid), dim3(RX_BLOCK), 0, st, s, d_out, out_rows, out_ld, sh.group, sh.chunks, err_flag);
+    else
+      hipLaunchKernelGGL(gather_seg_kernel<1>, dim3(grid), dim3(RX_BLOCK), 0, st, s, d_out, out_rows, out_ld, sh.group, sh.chunks, err_flag);
+    RX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// occ[q, :] = sum_{r<div} dout[q*div + r, col:col+dim]
+__global__ void __launch_bounds__(RX_BLOCK)
+gather_bwd_kernel(const float* __restrict__ dout, int64_t n_occ, int64_t out_ld, int col, int dim,
+                  int div, float* __restrict__ occ) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = gid / dim;
+  const int c = (int)(gid % dim);
+  if (q >= n_occ) return;
+  const float* p = dout + (q * div) * out_ld + col + c;
+  float acc = 0.f;
+  for (int r = 0; r < div; ++r) acc += p[(int64_t)r * out_ld];
+  occ[q * dim + c] = acc;
+}
+
+extern "C" int rx_gather_concat_bwd(const float* d_dout, int64_t out_rows, int64_t out_ld,
+                                    int32_t col, int32_t dim, int32_t div, float* d_occ,
+                                    int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(d_dout && d_occ, "rx_gather_concat_bwd: null argument");
+  RX_REQUIRE(dim >= 1 && div >= 1 && col >= 0 && (int64_t)col + dim <= out_ld, "rx_gather_concat_bwd: bad shape");
+  RX_REQUIRE(out_rows % div == 0, "rx_gather_concat_bwd: out_rows %lld not a multiple of div %d", (long long)out_rows, div);
+  const int64_t n_occ = out_rows / div;
+  if (n_occ == 0) return 0;
+  const unsigned grid = (unsigned)rx_cdiv(n_occ * dim, RX_BLOCK);
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_dout, n_occ, out_ld, col, dim, div, d_occ);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- permutation of row blocks
+template <bool SCATTER>
+__global__ void __launch_bounds__(RX_BLOCK)
+permute_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ perm, int64_t n,
+                    int dim, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j = gid / dim;
+  const int c = (int)(gid % dim);
+  if (j >= n) return;
+  const int64_t p = perm[j];
+  if (SCATTER)
+    out[p * dim + c] = rows[j * dim + c];
+  else
+    out[j * dim + c] = rows[p * dim + c];
+}
+
+extern "C" int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n,
+                                 int32_t dim, float* d_out, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0 && dim >= 1, "rx_unpermute_rows: bad shape");
+  if (n == 0) return 0;
+  RX_REQUIRE(d_rows && d_perm && d_out, "rx_unpermute_rows: null argument");
+  const unsigned grid = (unsigned)rx_cdiv(n * dim, RX_BLOCK);
+  hipLaunchKernelGGL(permute_rows_kernel<true>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, dim, d_out);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
+                               float* d_out, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0 && dim >= 1, "rx_permute_rows: bad shape");
+  if (n == 0) return 0;
+  RX_REQUIRE(d_rows && d_perm && d_out, "rx_permute_rows: null argument");
+  const unsigned grid = (unsigned)rx_cdiv(n * dim, RX_BLOCK);
+  hipLaunchKernelGGL(permute_rows_kernel<false>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, dim, d_out);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,505 @@
+// Dense layers of the towers on the matrix cores (gfx950): Linear forward with fused
+// bias + ReLU, and both Linear gradients.  Exact-fp32 path on v_mfma_f32_32x32x2_f32 (a
+// k-ordered fmaf chain, so results track an fp32 CPU GEMM to rounding) and a bf16-operand
+// path on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//
+// One kernel template covers the three products through element strides:
+//   forward  Y  = X  W^T   A(i,k)=X[i,k]     B(k,j)=W[j,k]    both K-contiguous
+//   grad X   dX = dY W     A(i,k)=dY[i,k]    B(k,j)=W[k,j]    A K-contiguous, B N-contiguous
+//   grad W   dW = dY^T X   A(i,k)=dY[k,i]    B(k,j)=X[k,j]    both M/N-contiguous, K = batch
+// The batch-long reduction of grad W is cut into slabs (one per blockIdx.z) that a second
+// kernel adds in slab order: fixed order, no float atomics.
+//
+// LDS tiles are k-major ([BK][BM+4]): the MFMA operand read (lane -> row lane&31 of k-slice
+// lane>>5) is then 32 consecutive floats per half-wave, conflict free, and the +4 pad keeps
+// 16-byte alignment for vector stores while spreading transposing stores over the banks.
+#include "rx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define GEMM_BK 16
+#define GEMM_PAD 4
+
+struct GemmArgs {
+  const float* A; int64_t a_rs, a_cs;  // A(i,k) = A[i*a_rs + k*a_cs]
+  const float* B; int64_t b_rs, b_cs;  // B(k,j) = B[k*b_rs + j*b_cs]
+  float* C; int64_t c_rs;              // C(i,j) = C[i*c_rs + j]
+  const float* bias;                   // [N] or null
+  int64_t M; int64_t N; int64_t K;
+  int act;                             // 1 = ReLU
+  int accumulate;                      // C += instead of C =
+  int64_t k_per_slab;                  // K range per blockIdx.z
+  int64_t c_slab_stride;               // C offset per blockIdx.z
+  int a_vec, b_vec;                    // 16-byte global loads are legal for this operand
+  int tiles_n;
+};
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  // round to nearest even; a NaN stays a (quiet) NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// Load 4 consecutive elements (along the contiguous axis) with bounds guards.
+__device__ __forceinline__ void load4(const float* p, int64_t stride_unused, int64_t first, int64_t limit,
+                                      bool row_ok, bool vec, float out[4]) {
+  (void)stride_unused;
+  if (row_ok && vec && first + 3 < limit) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = (row_ok && first + e < limit) ? p[e] : 0.f;
+  }
+}
+
+template <bool A_KC, bool B_KC, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemm_f32_kernel(GemmArgs g) {
+  constexpr int TM = BM / (32 * WAVES_M);
+  constexpr int TN = BN / (32 * WAVES_N);
+  constexpr int LDA = BM + GEMM_PAD;
+  constexpr int LDB = BN + GEMM_PAD;
+  __shared__ __attribute__((aligned(16))) float As[GEMM_BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * LDB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int64_t tile_m = blockIdx.x / g.tiles_n;
+  const int tile_n = blockIdx.x % g.tiles_n;
+  const int64_t m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
+  const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += GEMM_BK) {
+    // ---- stage A tile [BM x BK] -> As[k][i]
+    if (A_KC) {
+      constexpr int TPR = GEMM_BK / 4;          // threads per row
+      constexpr int RPP = RX_BLOCK / TPR;       // rows per pass
+      const int kq = (tid % TPR) * 4;
+#pragma unroll
+      for (int r = tid / TPR; r < BM; r += RPP) {
+        const int64_t row = m0 + r;
+        float v[4];
+        load4(g.A + row * g.a_rs + (k0 + kq), 0, k0 + kq, k_end, row < g.M, g.a_vec, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(kq + e) * LDA + r] = v[e];
+      }
+    } else {
+      constexpr int TPR = BM / 4;               // threads per k-row
+      constexpr int KPP = RX_BLOCK / TPR;       // k-rows per pass
+      const int iq = (tid % TPR) * 4;
+#pragma unroll
+      for (int kk = tid / TPR; kk < GEMM_BK; kk += KPP) {
+        const int64_t k = k0 + kk;
+        float v[4];
+        load4(g.A + k * g.a_cs + (m0 + iq), 0, m0 + iq, g.M, k < k_end, g.a_vec, v);
+        *reinterpret_cast<float4*>(&As[kk * LDA + iq]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    // ---- stage B tile [BK x BN] -> Bs[k][j]
+    if (B_KC) {
+      constexpr int TPR = GEMM_BK / 4;
+      constexpr int RPP = RX_BLOCK / TPR;
+      const int kq = (tid % TPR) * 4;
+#pragma unroll
+      for (int r = tid / TPR; r < BN; r += RPP) {
+        const int64_t col = n0 + r;
+        float v[4];
+        load4(g.B + col * g.b_cs + (k0 + kq), 0, k0 + kq, k_end, col < g.N, g.b_vec, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(kq + e) * LDB + r] = v[e];
+      }
+    } else {
+      constexpr int TPR = BN / 4;
+      constexpr int KPP = RX_BLOCK / TPR;
+      const int jq = (tid % TPR) * 4;
+#pragma unroll
+      for (int kk = tid / TPR; kk < GEMM_BK; kk += KPP) {
+        const int64_t k = k0 + kk;
+        float v[4];
+        load4(g.B + k * g.b_rs + (n0 + jq), 0, n0 + jq, g.N, k < k_end, g.b_vec, v);
+        *reinterpret_cast<float4*>(&Bs[kk * LDB + jq]) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    // ---- 8 k-pairs of 32x32x2 MFMAs
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(kk + h) * LDA + (wave_m * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + h) * LDB + (wave_n * TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cb = g.C + (int64_t)blockIdx.z * g.c_slab_stride;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int64_t col = n0 + (wave_n * TN + j) * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == 1) v = v > 0.f ? v : 0.f;
+          float* dst = Cb + row * g.c_rs + col;
+          *dst = g.accumulate ? (*dst + v) : v;
+        }
+      }
+    }
+  }
+}
+
+// bf16-operand variant: operands are rounded to bf16 while staging; LDS tiles are row-major
+// [BM][BK + 8] bf16 so each lane's 8 consecutive k values are one 16-byte read.
+#define GEMM_BK16 32
+template <bool A_KC, bool B_KC, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemm_bf16_kernel(GemmArgs g) {
+  constexpr int TM = BM / (32 * WAVES_M);
+  constexpr int TN = BN / (32 * WAVES_N);
+  constexpr int LDK = GEMM_BK16 + 8;  // bf16 elements per LDS row (80 bytes: 16-byte aligned, odd multiple of 16)
+  __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int64_t tile_m = blockIdx.x / g.tiles_n;
+  const int tile_n = blockIdx.x % g.tiles_n;
+  const int64_t m0 = tile_m * BM;
+  const int64_t n0 = (int64_t)tile_n * BN;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
+  const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += GEMM_BK16) {
+    if (A_KC) {
+      constexpr int TPR = GEMM_BK16 / 4;
+      constexpr int RPP = RX_BLOCK / TPR;
+      const int kq = (tid % TPR) * 4;
+#pragma unroll
+      for (int r = tid / TPR; r < BM; r += RPP) {
+        const int64_t row = m0 + r;
+        float v[4];
+        load4(g.A + row * g.a_rs + (k0 + kq), 0, k0 + kq, k_end, row < g.M, g.a_vec, v);
+        ushort4 o = make_ushort4(f32_to_bf16_rne(v[0]), f32_to_bf16_rne(v[1]), f32_to_bf16_rne(v[2]), f32_to_bf16_rne(v[3]));
+        *reinterpret_cast<ushort4*>(&As[r * LDK + kq]) = o;
+      }
+    } else {
+      constexpr int TPR = BM / 4;
+      constexpr int KPP = RX_BLOCK / TPR;
+      const int iq = (tid % TPR) * 4;
+#pragma unroll
+      for (int kk = tid / TPR; kk < GEMM_BK16; kk += KPP) {
+        const int64_t k = k0 + kk;
+        float v[4];
+        load4(g.A + k * g.a_cs + (m0 + iq), 0, m0 + iq, g.M, k < k_end, g.a_vec, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(iq + e) * LDK + kk] = f32_to_bf16_rne(v[e]);
+      }
+    }
+    if (B_KC) {
+      constexpr int TPR = GEMM_BK16 / 4;
+      constexpr int RPP = RX_BLOCK / TPR;
+      const int kq = (tid % TPR) * 4;
+#pragma unroll
+      for (int r = tid / TPR; r < BN; r += RPP) {
+        const int64_t col = n0 + r;
+        float v[4];
+        load4(g.B + col * g.b_cs + (k0 + kq), 0, k0 + kq, k_end, col < g.N, g.b_vec, v);
+        ushort4 o = make_ushort4(f32_to_bf16_rne(v[0]), f32_to_bf16_rne(v[1]), f32_to_bf16_rne(v[2]), f32_to_bf16_rne(v[3]));
+        *reinterpret_cast<ushort4*>(&Bs[r * LDK + kq]) = o;
+      }
+    } else {
+      constexpr int TPR = BN / 4;
+      constexpr int KPP = RX_BLOCK / TPR;
+      const int jq = (tid % TPR) * 4;
+#pragma unroll
+      for (int kk = tid / TPR; kk < GEMM_BK16; kk += KPP) {
+        const int64_t k = k0 + kk;
+        float v[4];
+        load4(g.B + k * g.b_rs + (n0 + jq), 0, n0 + jq, g.N, k < k_end, g.b_vec, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(jq + e) * LDK + kk] = f32_to_bf16_rne(v[e]);
+      }
+    }
+    __syncthreads();
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int ks = 0; ks < GEMM_BK16; ks += 16) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(&As[((wave_m * TM + i) * 32 + l31) * LDK + ks + 8 * h]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wave_n * TN + j) * 32 + l31) * LDK + ks + 8 * h]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float* Cb = g.C + (int64_t)blockIdx.z * g.c_slab_stride;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int64_t col = n0 + (wave_n * TN + j) * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == 1) v = v > 0.f ? v : 0.f;
+          float* dst = Cb + row * g.c_rs + col;
+          *dst = g.accumulate ? (*dst + v) : v;
+        }
+      }
+    }
+  }
+}
+
+// out[i] = sum_s slabs[s][i] in slab order
+__global__ void __launch_bounds__(RX_BLOCK)
+slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int q = 0; q < n_slabs; ++q) s += slabs[(int64_t)q * n + i];
+  out[i] = s;
+}
+
+// partial[z][j] = sum over the slab's rows of dY[row, j]
+__global__ void __launch_bounds__(RX_BLOCK)
+colsum_slab_kernel(const float* __restrict__ dY, int64_t ldd, int64_t M, int N, int64_t rows_per_slab,
+                   float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;  // 4 row-lanes
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float s = 0.f;
+  if (j < N)
+    for (int64_t r = lo + q; r < hi; r += 4) s += dY[r * ldd + j];
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && j < N) partial[(int64_t)blockIdx.z * N + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <bool A_KC, bool B_KC>
+static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
+  const int64_t tiles_m = rx_cdiv(g.M, 128);
+#define RX_GEMM_GO(BN_, WM_, WN_)                                                                       \
+  do {                                                                                                  \
+    g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
+    const int64_t blocks = tiles_m * g.tiles_n;                                                         \
+    RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");                                           \
+    dim3 grid((unsigned)blocks, 1, (unsigned)n_slabs);                                                  \
+    if (bf16)                                                                                           \
+      hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, 128, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g); \
+    else                                                                                                \
+      hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 128, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g);  \
+  } while (0)
+  if (g.N <= 32) RX_GEMM_GO(32, 4, 1);
+  else if (g.N <= 64) RX_GEMM_GO(64, 2, 2);
+  else RX_GEMM_GO(128, 2, 2);
+#undef RX_GEMM_GO
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int vec_ok(const float* p, int64_t ld) { return (ld % 4 == 0) && rx_aligned16(p); }
+
+extern "C" int rx_linear_fwd(const float* X, int64_t ldx, const float* W, const float* b, float* Y,
+                             int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int bf16, int device,
+                             void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && N >= 1 && K >= 1 && ldx >= K && ldy >= N, "rx_linear_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  RX_REQUIRE(act == 0 || act == 1, "rx_linear_fwd: unknown activation %d", act);
+  if (M == 0) return 0;
+  RX_REQUIRE(X && W && Y, "rx_linear_fwd: null argument");
+  GemmArgs g{};
+  g.A = X; g.a_rs = ldx; g.a_cs = 1;
+  g.B = W; g.b_rs = 1; g.b_cs = K;
+  g.C = Y; g.c_rs = ldy; g.bias = b;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = 0;
+  g.k_per_slab = K; g.c_slab_stride = 0;
+  g.a_vec = vec_ok(X, ldx); g.b_vec = vec_ok(W, K);
+  return gemm_launch<true, true>(g, 1, bf16, (hipStream_t)stream);
+}
+
+extern "C" int rx_linear_bwd_x(const float* dY, int64_t ldd, const float* W, float* dX, int64_t ldx,
+                               int64_t M, int32_t N, int32_t K, int accumulate, int bf16, int device,
+                               void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && N >= 1 && K >= 1 && ldd >= N && ldx >= K, "rx_linear_bwd_x: bad shape");
+  if (M == 0) return 0;
+  RX_REQUIRE(dY && W && dX, "rx_linear_bwd_x: null argument");
+  GemmArgs g{};
+  g.A = dY; g.a_rs = ldd; g.a_cs = 1;     // A(i,n) = dY[i,n]
+  g.B = W; g.b_rs = K; g.b_cs = 1;        // B(n,k) = W[n,k]
+  g.C = dX; g.c_rs = ldx; g.bias = nullptr;
+  g.M = M; g.N = K; g.K = N; g.act = 0; g.accumulate = accumulate;
+  g.k_per_slab = N; g.c_slab_stride = 0;
+  g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(W, K);
+  return gemm_launch<true, false>(g, 1, bf16, (hipStream_t)stream);
+}
+
+static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
+  // enough slabs to put >= ~512 blocks on the chip, each slab a multiple of the k-step
+  const int64_t tiles = rx_cdiv(N, 128) * rx_cdiv(K, (K <= 32 ? 32 : (K <= 64 ? 64 : 128)));
+  int64_t want = rx_cdiv(512, tiles);
+  int64_t max_by_rows = rx_cdiv(M, 256);
+  if (want > max_by_rows) want = max_by_rows;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+extern "C" size_t rx_linear_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N < 1 || K < 1) return 256;
+  const int s = bwd_w_slabs(M, N, K);
+  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up((size_t)s * N * sizeof(float), 256);
+}
+
+extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, float* dW,
+                               float* db, int64_t M, int32_t N, int32_t K, int bf16, void* ws,
+                               size_t ws_bytes, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldd >= N && ldx >= K, "rx_linear_bwd_w: bad shape");
+  RX_REQUIRE(dY && X && dW && ws, "rx_linear_bwd_w: null argument");
+  RX_REQUIRE(ws_bytes >= rx_linear_bwd_w_workspace_bytes(M, N, K), "rx_linear_bwd_w: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int s = bwd_w_slabs(M, N, K);
+  int64_t rows_per_slab = rx_cdiv(M, s);
+  rows_per_slab = rx_cdiv(rows_per_slab, 32) * 32;
+  const int n_slabs = (int)rx_cdiv(M, rows_per_slab);
+  float* slabs = (float*)ws;
+  float* bpart = (float*)((char*)ws + rx_align_up((size_t)s * N * K * sizeof(float), 256));
+  GemmArgs g{};
+  g.A = dY; g.a_rs = 1; g.a_cs = ldd;     // A(n, m) = dY[m, n]
+  g.B = X; g.b_rs = ldx; g.b_cs = 1;      // B(m, k) = X[m, k]
+  g.C = slabs; g.c_rs = K; g.bias = nullptr;
+  g.M = N; g.N = K; g.K = M; g.act = 0; g.accumulate = 0;
+  g.k_per_slab = rows_per_slab; g.c_slab_stride = (int64_t)N * K;
+  g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(X, ldx);
+  if (gemm_launch<false, false>(g, n_slabs, bf16, st)) return 1;
+  const int64_t nk = (int64_t)N * K;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, RX_BLOCK)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW);
+  RX_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(colsum_slab_kernel, dim3((unsigned)rx_cdiv(N, 64), 1, (unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY, ldd, M, N, rows_per_slab, bpart);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, RX_BLOCK)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, n_slabs, db);
+    RX_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+relu_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dZ, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dZ[i] = Y[i] > 0.f ? dY[i] : 0.f;
+}
+
+extern "C" int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0, "rx_relu_bwd: bad n");
+  if (n == 0) return 0;
+  RX_REQUIRE(dY && Y && dZ, "rx_relu_bwd: null argument");
+  int64_t grid = rx_cdiv(n, RX_BLOCK);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dY, Y, dZ, n);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- DCN-v2 cross combine
+__global__ void __launch_bounds__(RX_BLOCK)
+cross_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ u, const float* __restrict__ xl,
+                 float* __restrict__ xn, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    xn[i] = x0[i] * u[i] + xl[i];
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+cross_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x0, const float* __restrict__ u,
+                 float* __restrict__ du, float* __restrict__ dx0_acc, float* __restrict__ dxl, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = dxn[i];
+    du[i] = d * x0[i];
+    dx0_acc[i] += d * u[i];
+    dxl[i] = d;
+  }
+}
+
+extern "C" int rx_cross_combine_fwd(const float* x0, const float* u, const float* xl, float* xn, int64_t n,
+                                    int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0, "rx_cross_combine_fwd: bad n");
+  if (n == 0) return 0;
+  RX_REQUIRE(x0 && u && xl && xn, "rx_cross_combine_fwd: null argument");
+  int64_t grid = rx_cdiv(n, RX_BLOCK);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cross_fwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, x0, u, xl, xn, n);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_cross_combine_bwd(const float* dxn, const float* x0, const float* u, float* du,
+                                    float* dx0_acc, float* dxl, int64_t n, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0, "rx_cross_combine_bwd: bad n");
+  if (n == 0) return 0;
+  RX_REQUIRE(dxn && x0 && u && du && dx0_acc && dxl, "rx_cross_combine_bwd: null argument");
+  int64_t grid = rx_cdiv(n, RX_BLOCK);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cross_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, x0, u, du, dx0_acc, dxl, n);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,57 @@
+"""Shared pieces of the drop-in modules."""
+from __future__ import annotations
+
+from typing import Iterator, List
+
+import torch
+from torch import nn
+
+from .. import autograd as rxa
+
+Tensor = torch.Tensor
+
+
+class HotPathModule(nn.Module):
+    """nn.Module whose embedding lookups and interaction run on the HIP kernels.
+
+    ``sparse_parameters()`` lists the embedding-table parameters (the ones a fused sparse
+    optimizer updates row-wise); everything else in ``parameters()`` is dense."""
+
+    _sparse_names: List[str] = []
+
+    def sparse_parameters(self) -> Iterator[nn.Parameter]:
+        named = dict(self.named_parameters())
+        for n in self._sparse_names:
+            if n in named:
+                yield named[n]
+
+    def loss(self, inputs, *args, **kwargs):
+        labels = inputs["label"]
+        logits = self(inputs, *args, **kwargs)
+        return rxa.bce_with_logits(logits, labels)
+
+
+def as_index(t: Tensor, name: str) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if t.dtype != torch.int64:
+        raise TypeError(f"{name}: expected int64 indices, got {t.dtype}")
+    return t.contiguous()
+
+
+def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False) -> Tensor:
+    """Evaluate a Linear/(BatchNorm1d)/ReLU/Dropout stack.  Linear (+ a directly following ReLU)
+    goes through the MFMA GEMM with the ReLU fused into its epilogue; BatchNorm1d and Dropout
+    keep torch's own modules (their batch statistics / RNG semantics are torch's)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

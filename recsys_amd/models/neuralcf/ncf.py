@@ -1,0 +1,143 @@
+"""GMF / MLP / NeuMF on the fused kernels (recsys/models/neuralcf/{gmf,mlp,neumf}.py).
+
+Names, init (N(0, 0.01) embeddings, xavier-uniform Linear weights, zero biases) and construction
+order follow the reference, so state_dicts are interchangeable.  The list-wise NeuMF feeds
+``linear_final`` with [gmf, mlp] and the point-wise path with [mlp, gmf], exactly as
+neumf.py:104 and neumf.py:122 do.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ... import autograd as rxa
+from ..base import HotPathModule, as_index, run_tower
+
+
+def _relu_stack(dims, dropout):
+    mods = []
+    for i, o in zip(dims[:-1], dims[1:]):
+        mods.extend([nn.Linear(i, o), nn.ReLU(), nn.Dropout(p=dropout)])
+    return nn.Sequential(*mods[:-2])  # no ReLU / Dropout after the last Linear
+
+
+def _zero_linear_biases(module):
+    for m in module.modules():
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            m.bias.data.zero_()
+
+
+def _tower_input(users, items, U, V):
+    """[B*N, 2D] rows = [user row (broadcast over N), item row] (mlp.py:67-76)."""
+    B = users.shape[0]
+    N = items.shape[1] if items.dim() == 2 else 1
+    D = U.shape[1]
+    spec = [(0, users, 0, N, 1, 0, 0), (1, items, D, 1, 1, 0, 0)]
+    return rxa.GatherConcat.apply(spec, B * N, 2 * D, U, V), B, N
+
+
+class GMF(HotPathModule):
+    _sparse_names = ["user_embedding.weight", "item_embedding.weight"]
+
+    def __init__(self, n_users, n_items, embedding_dim):
+        super().__init__()
+        self.n_users, self.n_items, self.embedding_dim = n_users, n_items, embedding_dim
+        self.user_embedding = nn.Embedding(n_users, embedding_dim)
+        self.item_embedding = nn.Embedding(n_items, embedding_dim)
+        self.linear = nn.Linear(embedding_dim, 1)
+        self.init_weight()
+
+    def init_weight(self):
+        nn.init.normal_(self.user_embedding.weight, std=0.01)
+        nn.init.normal_(self.item_embedding.weight, std=0.01)
+        nn.init.xavier_uniform_(self.linear.weight)
+        _zero_linear_biases(self)
+
+    def forward(self, inputs, pointwise=False):
+        users = as_index(inputs["user_code"], "user_code")
+        items = inputs["item_code"]
+        if items is None:
+            items = torch.arange(self.n_items, device=users.device).expand(users.shape[0], self.n_items)
+        items = as_index(items, "item_code")
+        if pointwise and items.dim() != 1:
+            raise ValueError("pointwise=True takes item_code of shape [B]")
+        # Linear(D, 1) is folded into the score kernel; [B] items give [B, 1] as gmf.py:59-65 does
+        return rxa.MFScore.apply(users, items, None, None, self.user_embedding.weight, self.item_embedding.weight,
+                                 None, None, None, None, None, None, self.linear.weight, self.linear.bias)
+
+
+class MLP(HotPathModule):
+    _sparse_names = ["user_embedding.weight", "item_embedding.weight"]
+
+    def __init__(self, n_users, n_items, embedding_dim, mlp_dims=None, dropout=0.1):
+        super().__init__()
+        self.n_users, self.n_items, self.embedding_dim = n_users, n_items, embedding_dim
+        self.user_embedding = nn.Embedding(n_users, embedding_dim)
+        self.item_embedding = nn.Embedding(n_items, embedding_dim)
+        self.mlp_dims = mlp_dims or (embedding_dim * 2, embedding_dim, embedding_dim // 2, 1)
+        self.mlp = _relu_stack(self.mlp_dims, dropout)
+        self.init_weight()
+
+    def init_weight(self):
+        nn.init.normal_(self.user_embedding.weight, std=0.01)
+        nn.init.normal_(self.item_embedding.weight, std=0.01)
+        for layer in self.mlp:
+            if isinstance(layer, nn.Linear):
+                nn.init.xavier_uniform_(layer.weight)
+        _zero_linear_biases(self)
+
+    def forward(self, inputs, pointwise=False):
+        users = as_index(inputs["user_code"], "user_code")
+        items = inputs["item_code"]
+        if items is None:
+            items = torch.arange(self.n_items, device=users.device).expand(users.shape[0], self.n_items)
+        items = as_index(items, "item_code")
+        if pointwise and items.dim() != 1:
+            raise ValueError("pointwise=True takes item_code of shape [B]")
+        x, B, N = _tower_input(users, items, self.user_embedding.weight, self.item_embedding.weight)
+        out = run_tower(self.mlp, x)
+        return out if pointwise else out.view(B, -1)
+
+
+class NeuMF(HotPathModule):
+    _sparse_names = ["user_embedding_gmf.weight", "item_embedding_gmf.weight",
+                     "user_embedding_mlp.weight", "item_embedding_mlp.weight"]
+
+    def __init__(self, n_users, n_items, embedding_dim, mlp_dims=None, dropout=0.1):
+        super().__init__()
+        self.n_users, self.n_items, self.embedding_dim = n_users, n_items, embedding_dim
+        self.user_embedding_gmf = nn.Embedding(n_users, embedding_dim)
+        self.item_embedding_gmf = nn.Embedding(n_items, embedding_dim)
+        self.linear_gmf = nn.Linear(embedding_dim, embedding_dim // 2)
+        self.user_embedding_mlp = nn.Embedding(n_users, embedding_dim)
+        self.item_embedding_mlp = nn.Embedding(n_items, embedding_dim)
+        self.mlp_dims = mlp_dims or (embedding_dim * 2, embedding_dim, embedding_dim // 2)
+        self.linear_mlp = _relu_stack(self.mlp_dims, dropout)
+        self.linear_final = nn.Linear(embedding_dim, 1)
+        self.init_weight()
+
+    def init_weight(self):
+        for emb in (self.user_embedding_mlp, self.item_embedding_mlp, self.user_embedding_gmf, self.item_embedding_gmf):
+            nn.init.normal_(emb.weight, std=0.01)
+        for layer in self.linear_mlp:
+            if isinstance(layer, nn.Linear):
+                nn.init.xavier_uniform_(layer.weight)
+        nn.init.xavier_uniform_(self.linear_gmf.weight)
+        nn.init.xavier_uniform_(self.linear_final.weight)
+        _zero_linear_biases(self)
+
+    def forward(self, inputs, pointwise=False):
+        users = as_index(inputs["user_code"], "user_code")
+        items = inputs["item_code"]
+        if items is None:
+            items = torch.arange(self.n_items, device=users.device).expand(users.shape[0], self.n_items)
+        items = as_index(items, "item_code")
+        if pointwise and items.dim() != 1:
+            raise ValueError("pointwise=True takes item_code of shape [B]")
+        prod = rxa.GMFMul.apply(users, items, self.user_embedding_gmf.weight, self.item_embedding_gmf.weight)
+        out_gmf = rxa.linear(prod, self.linear_gmf.weight, self.linear_gmf.bias)
+        x, B, N = _tower_input(users, items, self.user_embedding_mlp.weight, self.item_embedding_mlp.weight)
+        out_mlp = run_tower(self.linear_mlp, x)
+        both = torch.cat([out_mlp, out_gmf] if pointwise else [out_gmf, out_mlp], dim=1)
+        out = rxa.linear(both, self.linear_final.weight, self.linear_final.bias)
+        return out if pointwise else out.view(B, -1)

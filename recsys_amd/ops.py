@@ -1,0 +1,574 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see ``autograd.py``).
+
+Each wrapper validates its tensors (device, dtype, contiguity, shapes) on the host, hands raw
+device pointers plus the current HIP stream to ``librecsys_hip.so`` and returns torch tensors.
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import FMArgs, GatherSeg, MFArgs, check, lib
+
+Tensor = torch.Tensor
+
+# ------------------------------------------------------------------ index-error reporting
+_INDEX_CHECK = "sync"  # "sync": raise right after the op; "deferred": raise in raise_if_index_error()
+_err_flags = {}
+
+
+def set_index_check(mode: str) -> None:
+    """``"sync"`` (default): every op that consumes indices synchronises and raises IndexError at
+    once, like nn.Embedding on the CPU.  ``"deferred"``: ops only set a device flag; call
+    :func:`raise_if_index_error` (e.g. once per epoch) to check it without per-step syncs."""
+    global _INDEX_CHECK
+    if mode not in ("sync", "deferred"):
+        raise ValueError(mode)
+    _INDEX_CHECK = mode
+
+
+def _err_flag(device: torch.device) -> Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _err_flags.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _err_flags[key] = t
+    return t
+
+
+def raise_if_index_error(device=None) -> None:
+    for key, t in list(_err_flags.items()):
+        if device is not None and torch.device(device).index not in (None, key):
+            continue
+        if int(t.item()) & _lib.RX_ERR_INDEX:
+            t.zero_()
+            raise IndexError("index out of range in a recsys_amd embedding lookup")
+
+
+def _after_index_op(device) -> None:
+    if _INDEX_CHECK == "sync":
+        raise_if_index_error(device)
+
+
+# ------------------------------------------------------------------ small helpers
+def _stream(t: Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(t: Tensor) -> int:
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _p(t: Optional[Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU, got device {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dimensions, got shape {tuple(t.shape)}")
+    return t
+
+
+def _same_device(ref: Tensor, *ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None and t.device != ref.device:
+            raise ValueError(f"tensors on different devices: {ref.device} vs {t.device}")
+
+
+def _table(t: Tensor, name: str) -> Tensor:
+    return _req(t, torch.float32, name, 2)
+
+
+def _idx(t: Tensor, name: str) -> Tensor:
+    return _req(t, torch.int64, name)
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ gather / assemble
+@dataclass
+class Segment:
+    """One column block of an assembled tower input (see rx_gather_seg in recsys_hip.h)."""
+    table: Tensor
+    idx: Tensor
+    col: int
+    div: int = 1
+    stride: int = 1
+    k: int = 0
+    base: int = 0
+
+
+def _segs_array(segs: Sequence[Segment]):
+    arr = (GatherSeg * len(segs))()
+    for i, s in enumerate(segs):
+        _table(s.table, f"segment {i} table")
+        _idx(s.idx, f"segment {i} idx")
+        arr[i] = GatherSeg(s.table.data_ptr(), s.idx.data_ptr(), s.table.shape[0], s.base,
+                           s.table.shape[1], s.col, s.div, s.stride, s.k, 0)
+    return arr
+
+
+def gather_concat(segs: Sequence[Segment], out_rows: int, out_cols: int,
+                  out: Optional[Tensor] = None) -> Tensor:
+    ref = segs[0].table
+    for s in segs:
+        _same_device(ref, s.table, s.idx)
+        need = ((out_rows - 1) // s.div) * s.stride + s.k + 1 if out_rows else 0
+        if s.idx.numel() < need:
+            raise ValueError("gather_concat: index tensor shorter than the rows it must serve")
+    if out is None:
+        out = torch.empty(out_rows, out_cols, dtype=torch.float32, device=ref.device)
+    else:
+        _req(out, torch.float32, "out", 2)
+    arr = _segs_array(segs)
+    check(lib.rx_gather_concat(arr, len(segs), _p(out), out_rows, out.shape[1], _p(_err_flag(ref.device)),
+                               _dev(ref), _stream(ref)), "rx_gather_concat")
+    _after_index_op(ref.device)
+    return out
+
+
+def gather_concat_bwd(dout: Tensor, col: int, dim: int, div: int) -> Tensor:
+    _req(dout, torch.float32, "dout", 2)
+    occ = torch.empty(dout.shape[0] // div, dim, dtype=torch.float32, device=dout.device)
+    check(lib.rx_gather_concat_bwd(_p(dout), dout.shape[0], dout.shape[1], col, dim, div, _p(occ),
+                                   _dev(dout), _stream(dout)), "rx_gather_concat_bwd")
+    return occ
+
+
+# ------------------------------------------------------------------ MF-family score
+def _mf_args(U, V, users, items, O=None, occs=None, UT=None, T=None, temps=None,
+             user_bias=None, item_bias=None, bias=None, lin_w=None, lin_b=None) -> Tuple[MFArgs, int, int]:
+    _table(U, "user table"); _table(V, "item table")
+    _idx(users, "user_code"); _idx(items, "item_code")
+    if users.dim() != 1:
+        raise ValueError(f"user_code: expected shape [B], got {tuple(users.shape)}")
+    B = users.shape[0]
+    if items.dim() == 1:
+        N = 1
+    elif items.dim() == 2:
+        N = items.shape[1]
+    else:
+        raise ValueError(f"item_code: expected [B] or [B, N], got {tuple(items.shape)}")
+    if items.shape[0] != B:
+        raise ValueError("user_code and item_code disagree on the batch size")
+    dim = U.shape[1]
+    if V.shape[1] != dim:
+        raise ValueError("user and item tables disagree on the embedding width")
+    _same_device(U, V, users, items, O, occs, UT, T, temps, user_bias, item_bias, bias, lin_w, lin_b)
+    for t, nm, shp in ((O, "occupation table", None), (UT, "user temporal table", (U.shape[0], dim)),
+                       (T, "temporal table", None)):
+        if t is not None:
+            _table(t, nm)
+            if t.shape[1] != dim or (shp and tuple(t.shape) != shp):
+                raise ValueError(f"{nm}: bad shape {tuple(t.shape)}")
+    for t, nm in ((occs, "user_occupation"), (temps, "item_timestamp_rank")):
+        if t is not None:
+            _idx(t, nm)
+            if tuple(t.shape) != (B,):
+                raise ValueError(f"{nm}: expected shape [{B}], got {tuple(t.shape)}")
+    for t, nm, n in ((user_bias, "user_bias", U.shape[0]), (item_bias, "item_bias", V.shape[0]),
+                     (bias, "bias", 1), (lin_w, "lin_w", dim), (lin_b, "lin_b", 1)):
+        if t is not None:
+            _req(t, torch.float32, nm)
+            if t.numel() != n:
+                raise ValueError(f"{nm}: expected {n} elements, got {t.numel()}")
+    a = MFArgs(U.data_ptr(), U.shape[0], V.data_ptr(), V.shape[0],
+               0 if O is None else O.data_ptr(), 0 if O is None else O.shape[0],
+               0 if UT is None else UT.data_ptr(), 0 if T is None else T.data_ptr(),
+               0 if T is None else T.shape[0],
+               0 if user_bias is None else user_bias.data_ptr(),
+               0 if item_bias is None else item_bias.data_ptr(),
+               0 if bias is None else bias.data_ptr(),
+               0 if lin_w is None else lin_w.data_ptr(), 0 if lin_b is None else lin_b.data_ptr(),
+               users.data_ptr(), items.data_ptr(),
+               0 if occs is None else occs.data_ptr(), 0 if temps is None else temps.data_ptr(),
+               B, N, dim)
+    return a, B, N
+
+
+def mf_score_fwd(U, V, users, items, **kw) -> Tensor:
+    a, B, N = _mf_args(U, V, users, items, **kw)
+    logits = torch.empty(B, N, dtype=torch.float32, device=U.device)
+    check(lib.rx_mf_score_fwd(C.byref(a), _p(logits), _p(_err_flag(U.device)), _dev(U), _stream(U)),
+          "rx_mf_score_fwd")
+    _after_index_op(U.device)
+    return logits
+
+
+def mf_score_bwd(g: Tensor, U, V, users, items, **kw):
+    """Returns (user_occ [B,D], item_occ [B*N,D], utemp_occ, temp_occ, gsum [B], linw_grad [D])."""
+    a, B, N = _mf_args(U, V, users, items, **kw)
+    _req(g, torch.float32, "grad_logits")
+    if g.numel() != B * N:
+        raise ValueError("grad_logits: wrong number of elements")
+    dim, dev = U.shape[1], U.device
+    user_occ = torch.empty(B, dim, dtype=torch.float32, device=dev)
+    item_occ = torch.empty(B * N, dim, dtype=torch.float32, device=dev)
+    has_t = kw.get("UT") is not None
+    utemp_occ = torch.empty(B, dim, dtype=torch.float32, device=dev) if has_t else None
+    temp_occ = torch.empty(B, dim, dtype=torch.float32, device=dev) if has_t else None
+    gsum = torch.empty(B, dtype=torch.float32, device=dev)
+    has_w = kw.get("lin_w") is not None
+    part = None
+    if has_w:
+        grid = int(lib.rx_mf_bwd_grid(B, dim))
+        part = torch.empty(max(grid, 1), dim, dtype=torch.float32, device=dev)
+    check(lib.rx_mf_score_bwd(C.byref(a), _p(g), _p(user_occ), _p(item_occ), _p(utemp_occ), _p(temp_occ),
+                              _p(gsum), _p(part), _dev(U), _stream(U)), "rx_mf_score_bwd")
+    linw_grad = None
+    if has_w:
+        linw_grad = torch.empty(dim, dtype=torch.float32, device=dev)
+        check(lib.rx_colsum_partials(_p(part), part.shape[0] if B else 0, dim, _p(linw_grad), _dev(U),
+                                     _stream(U)), "rx_colsum_partials")
+    return user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad
+
+
+# ------------------------------------------------------------------ GMF product
+def gmf_mul_fwd(U, V, users, items, out: Optional[Tensor] = None, col: int = 0) -> Tensor:
+    _table(U, "user table"); _table(V, "item table"); _idx(users, "user_code"); _idx(items, "item_code")
+    _same_device(U, V, users, items)
+    B = users.shape[0]
+    N = items.shape[1] if items.dim() == 2 else 1
+    dim = U.shape[1]
+    if out is None:
+        out = torch.empty(B * N, dim, dtype=torch.float32, device=U.device)
+    _req(out, torch.float32, "out", 2)
+    check(lib.rx_gmf_mul_fwd(_p(U), U.shape[0], _p(V), V.shape[0], _p(users), _p(items), B, N, dim, _p(out),
+                             out.shape[1], col, _p(_err_flag(U.device)), _dev(U), _stream(U)), "rx_gmf_mul_fwd")
+    _after_index_op(U.device)
+    return out
+
+
+def gmf_mul_bwd(dout: Tensor, U, V, users, items, col: int = 0):
+    _req(dout, torch.float32, "dout", 2)
+    B = users.shape[0]
+    N = items.shape[1] if items.dim() == 2 else 1
+    dim = U.shape[1]
+    user_occ = torch.empty(B, dim, dtype=torch.float32, device=U.device)
+    item_occ = torch.empty(B * N, dim, dtype=torch.float32, device=U.device)
+    check(lib.rx_gmf_mul_bwd(_p(U), U.shape[0], _p(V), V.shape[0], _p(users), _p(items), B, N, dim, _p(dout),
+                             dout.shape[1], col, _p(user_occ), _p(item_occ), _dev(U), _stream(U)), "rx_gmf_mul_bwd")
+    return user_occ, item_occ
+
+
+# ------------------------------------------------------------------ FM second order
+def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True):
+    _table(feat, "feature table")
+    _idx(ex_idx, "ex_idx"); _idx(ex_base, "ex_base"); _idx(item_idx, "item_idx")
+    if ex_idx.dim() != 2:
+        raise ValueError(f"ex_idx: expected [B, F], got {tuple(ex_idx.shape)}")
+    B, F = ex_idx.shape
+    if ex_base.numel() != F:
+        raise ValueError("ex_base: one offset per field expected")
+    if item_idx.dim() == 1:
+        N = 1
+    elif item_idx.dim() == 2:
+        N = item_idx.shape[1]
+    else:
+        raise ValueError("item_idx: expected [B] or [B, N]")
+    if item_idx.shape[0] != B:
+        raise ValueError("ex_idx and item_idx disagree on the batch size")
+    if bias is not None:
+        _req(bias, torch.float32, "bias table")
+        if bias.numel() != feat.shape[0]:
+            raise ValueError("bias table: one entry per feature row expected")
+    _same_device(feat, bias, ex_idx, ex_base, item_idx)
+    a = FMArgs(feat.data_ptr(), 0 if bias is None else bias.data_ptr(), feat.shape[0], ex_idx.data_ptr(),
+               ex_base.data_ptr(), item_idx.data_ptr(), item_base, B, F, N, feat.shape[1],
+               0 if second_order else _lib.RX_FM_NO_SECOND_ORDER)
+    return a, B, F, N
+
+
+def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base: int, want_deep: bool = False,
+            second_order: bool = True):
+    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order)
+    dim = feat.shape[1]
+    logits = torch.empty(B, N, dtype=torch.float32, device=feat.device)
+    deep = torch.empty(B * N, (1 + F) * dim, dtype=torch.float32, device=feat.device) if want_deep else None
+    check(lib.rx_fm2_fwd(C.byref(a), _p(logits), _p(deep), _p(_err_flag(feat.device)), _dev(feat), _stream(feat)),
+          "rx_fm2_fwd")
+    _after_index_op(feat.device)
+    return logits, deep
+
+
+def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True):
+    """Returns (occ [(B*F+B*N), D], bias_occ [(B*F+B*N)] or None)."""
+    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order)
+    _req(g, torch.float32, "grad_logits")
+    if g.numel() != B * N:
+        raise ValueError("grad_logits: wrong number of elements")
+    dim, dev = feat.shape[1], feat.device
+    if d_deep is not None:
+        _req(d_deep, torch.float32, "grad_deep", 2)
+        if tuple(d_deep.shape) != (B * N, (1 + F) * dim):
+            raise ValueError("grad_deep: wrong shape")
+    n = B * (F + N)
+    occ = torch.empty(n, dim, dtype=torch.float32, device=dev)
+    bias_occ = torch.empty(n, dtype=torch.float32, device=dev) if bias is not None else None
+    check(lib.rx_fm2_bwd(C.byref(a), _p(g), _p(d_deep), _p(occ), _p(bias_occ), _dev(feat), _stream(feat)),
+          "rx_fm2_bwd")
+    return occ, bias_occ
+
+
+def fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base: int) -> Tensor:
+    a, B, F, N = _fm_args(feat, None, ex_idx, ex_base, item_idx, item_base)
+    flat = torch.empty(B * (F + N), dtype=torch.int64, device=feat.device)
+    check(lib.rx_fm2_flat_indices(C.byref(a), _p(flat), _dev(feat), _stream(feat)), "rx_fm2_flat_indices")
+    return flat
+
+
+# ------------------------------------------------------------------ BCE
+def bce_with_logits(logits: Tensor, labels: Tensor, want_grad: bool = True):
+    """Returns (loss fp64 scalar tensor, dlogits fp32 like logits or None)."""
+    _req(logits, torch.float32, "logits")
+    if labels.dtype not in (torch.float64, torch.float32):
+        raise TypeError(f"label: expected float64 or float32, got {labels.dtype}")
+    _req(labels, labels.dtype, "label")
+    if labels.shape != logits.shape:
+        raise ValueError(f"label shape {tuple(labels.shape)} != logits shape {tuple(logits.shape)}")
+    _same_device(logits, labels)
+    M = logits.numel()
+    loss = torch.empty((), dtype=torch.float64, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    nb = int(lib.rx_bce_workspace_bytes(M))
+    ws = _ws(nb, logits.device)
+    check(lib.rx_bce_fwd(_p(logits), _p(labels), int(labels.dtype == torch.float64), M, _p(loss), _p(dl), _p(ws),
+                         ws.numel(), _dev(logits), _stream(logits)), "rx_bce_fwd")
+    return loss, dl
+
+
+# ------------------------------------------------------------------ sort / dedup / segmented reduce
+@dataclass
+class SortedIndex:
+    """Result of rx_sort_dedup for one index list (device tensors; n_uniq stays on the device)."""
+    n: int
+    n_rows: int
+    sorted_pos: Tensor   # int32 [n]
+    uniq_rows: Tensor    # int64 [n]  (first n_uniq valid)
+    seg_off: Tensor      # int32 [n+1]
+    n_uniq: Tensor       # int32 [1]
+    inverse: Optional[Tensor] = None
+
+
+def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False) -> SortedIndex:
+    _idx(idx, "indices")
+    flat = idx.reshape(-1)
+    n, dev = flat.numel(), idx.device
+    sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    uniq = torch.empty(n, dtype=torch.int64, device=dev)
+    seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nu = torch.empty(1, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
+    ws = _ws(int(lib.rx_sort_dedup_workspace_bytes(n)), dev)
+    check(lib.rx_sort_dedup(_p(flat), n, n_rows, _p(sorted_pos), _p(uniq), _p(seg), _p(nu), _p(inv), _p(ws),
+                            ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)), "rx_sort_dedup")
+    return SortedIndex(n, n_rows, sorted_pos, uniq, seg, nu, inv)
+
+
+def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state: Optional[Tensor] = None,
+              lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None,
+              want_sq: bool = False, occ_ld: Optional[int] = None, dim: Optional[int] = None) -> Optional[Tensor]:
+    """Run rx_segreduce.  ``occ`` is [n, dim] (or 1-D for dim == 1); ``target`` the table / dense
+    gradient / compact buffer.  Returns the per-block sum-of-squares partials when asked."""
+    _req(occ, torch.float32, "occurrence gradients")
+    _req(target, torch.float32, "target")
+    if dim is None:
+        dim = occ.shape[1] if occ.dim() == 2 else 1
+    if occ_ld is None:
+        occ_ld = dim
+    if occ.numel() < (si.n - 1) * occ_ld + dim and si.n > 0:
+        raise ValueError("occurrence gradients: too few elements for the index list")
+    sq = None
+    if want_sq:
+        sq = torch.empty(max(int(lib.rx_segreduce_grid(si.n, dim)), 1), dtype=torch.float32, device=occ.device)
+    check(lib.rx_segreduce(_p(occ), occ_ld, si.n, dim, _p(si.sorted_pos), _p(si.uniq_rows), _p(si.seg_off),
+                           _p(si.n_uniq), mode, _p(target), _p(state), si.n_rows, lr, eps, _p(scale), _p(sq),
+                           _dev(occ), _stream(occ)), "rx_segreduce")
+    return sq
+
+
+def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
+               scale=None) -> None:
+    dim = compact.shape[1] if compact.dim() == 2 else 1
+    check(lib.rx_row_update(_p(compact), dim, _p(si.uniq_rows), _p(si.n_uniq), si.n, mode, _p(table), _p(state),
+                            si.n_rows, lr, eps, _p(scale), _dev(table), _stream(table)), "rx_row_update")
+
+
+# ------------------------------------------------------------------ dense optimizers / reductions
+def dense_adam(w, g, m, v, lr, beta1, beta2, eps, step, scale=None):
+    check(lib.rx_dense_adam(_p(w), _p(g), _p(m), _p(v), w.numel(), lr, beta1, beta2, eps, step, _p(scale),
+                            _dev(w), _stream(w)), "rx_dense_adam")
+
+
+def dense_sgd(w, g, lr, scale=None):
+    check(lib.rx_dense_sgd(_p(w), _p(g), w.numel(), lr, _p(scale), _dev(w), _stream(w)), "rx_dense_sgd")
+
+
+def dense_adagrad(w, g, state, lr, eps, scale=None):
+    check(lib.rx_dense_adagrad(_p(w), _p(g), _p(state), w.numel(), lr, eps, _p(scale), _dev(w), _stream(w)),
+          "rx_dense_adagrad")
+
+
+def sumsq_accumulate(x: Tensor, acc: Tensor) -> None:
+    _req(x, torch.float32, "x"); _req(acc, torch.float64, "acc")
+    ws = _ws(int(lib.rx_sumsq_workspace_bytes(x.numel())), x.device)
+    check(lib.rx_sumsq_accumulate(_p(x), x.numel(), _p(acc), _p(ws), ws.numel(), _dev(x), _stream(x)),
+          "rx_sumsq_accumulate")
+
+
+def sum_accumulate(x: Tensor, acc: Tensor) -> None:
+    _req(x, torch.float32, "x"); _req(acc, torch.float64, "acc")
+    ws = _ws(int(lib.rx_sumsq_workspace_bytes(x.numel())), x.device)
+    check(lib.rx_sum_accumulate(_p(x), x.numel(), _p(acc), _p(ws), ws.numel(), _dev(x), _stream(x)),
+          "rx_sum_accumulate")
+
+
+def clip_scale(acc: Tensor, max_norm: float):
+    scale = torch.empty(1, dtype=torch.float32, device=acc.device)
+    total = torch.empty(1, dtype=torch.float32, device=acc.device)
+    check(lib.rx_clip_scale(_p(acc), max_norm, _p(scale), _p(total), _dev(acc), _stream(acc)), "rx_clip_scale")
+    return scale, total
+
+
+def reduce_sum(x: Tensor) -> Tensor:
+    _req(x, torch.float32, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = _ws(int(lib.rx_sumsq_workspace_bytes(x.numel())), x.device)
+    check(lib.rx_reduce_sum(_p(x), x.numel(), _p(out), _p(ws), ws.numel(), _dev(x), _stream(x)), "rx_reduce_sum")
+    return out
+
+
+# ------------------------------------------------------------------ dense layers
+def _mat(t: Tensor, name: str) -> Tuple[Tensor, int]:
+    """2-D fp32 with unit inner stride (a column block of a wider matrix is allowed)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise TypeError(f"{name}: expected a 2-D fp32 GPU tensor")
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        raise ValueError(f"{name}: inner stride must be 1")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t, ld
+
+
+def linear_fwd(x: Tensor, w: Tensor, b: Optional[Tensor], act: int = 0, bf16: bool = False,
+               out: Optional[Tensor] = None) -> Tensor:
+    x, ldx = _mat(x, "x")
+    _req(w, torch.float32, "weight", 2)
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear: x is [{M},{K}] but weight is {tuple(w.shape)}")
+    if b is not None:
+        _req(b, torch.float32, "bias", 1)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    out, ldy = _mat(out, "out")
+    check(lib.rx_linear_fwd(_p(x), ldx, _p(w), _p(b), _p(out), ldy, M, N, K, act, int(bf16), _dev(x), _stream(x)),
+          "rx_linear_fwd")
+    return out
+
+
+def linear_bwd_x(dy: Tensor, w: Tensor, bf16: bool = False, out: Optional[Tensor] = None,
+                 accumulate: bool = False) -> Tensor:
+    dy, ldd = _mat(dy, "dy")
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    out, ldx = _mat(out, "dx")
+    check(lib.rx_linear_bwd_x(_p(dy), ldd, _p(w), _p(out), ldx, M, N, K, int(accumulate), int(bf16), _dev(dy),
+                              _stream(dy)), "rx_linear_bwd_x")
+    return out
+
+
+def linear_bwd_w(dy: Tensor, x: Tensor, want_bias: bool = True, bf16: bool = False):
+    dy, ldd = _mat(dy, "dy")
+    x, ldx = _mat(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    ws = _ws(int(lib.rx_linear_bwd_w_workspace_bytes(M, N, K)), dy.device)
+    check(lib.rx_linear_bwd_w(_p(dy), ldd, _p(x), ldx, _p(dw), _p(db), M, N, K, int(bf16), _p(ws), ws.numel(),
+                              _dev(dy), _stream(dy)), "rx_linear_bwd_w")
+    return dw, db
+
+
+def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
+    _req(dy, torch.float32, "dy"); _req(y, torch.float32, "y")
+    dz = torch.empty_like(dy)
+    check(lib.rx_relu_bwd(_p(dy), _p(y), _p(dz), dy.numel(), _dev(dy), _stream(dy)), "rx_relu_bwd")
+    return dz
+
+
+def cross_combine_fwd(x0, u, xl):
+    xn = torch.empty_like(x0)
+    check(lib.rx_cross_combine_fwd(_p(x0), _p(u), _p(xl), _p(xn), x0.numel(), _dev(x0), _stream(x0)),
+          "rx_cross_combine_fwd")
+    return xn
+
+
+def cross_combine_bwd(dxn, x0, u, dx0_acc):
+    du = torch.empty_like(dxn)
+    dxl = torch.empty_like(dxn)
+    check(lib.rx_cross_combine_bwd(_p(dxn), _p(x0), _p(u), _p(du), _p(dx0_acc), _p(dxl), dxn.numel(), _dev(dxn),
+                                   _stream(dxn)), "rx_cross_combine_bwd")
+    return du, dxl
+
+
+# ------------------------------------------------------------------ exchange helpers / eval
+def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int):
+    _idx(idx, "indices")
+    flat = idx.reshape(-1)
+    n, dev = flat.numel(), idx.device
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    send_local = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _ws(int(lib.rx_bucketize_workspace_bytes(n, world)), dev)
+    check(lib.rx_bucketize_by_owner(_p(flat), n, world, n_rows_global, _p(counts), _p(send_local), _p(perm),
+                                    _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)),
+          "rx_bucketize_by_owner")
+    return counts, send_local, perm
+
+
+def unpermute_rows(rows: Tensor, perm: Tensor) -> Tensor:
+    out = torch.empty_like(rows)
+    dim = rows.shape[1] if rows.dim() == 2 else 1
+    check(lib.rx_unpermute_rows(_p(rows), _p(perm), perm.numel(), dim, _p(out), _dev(rows), _stream(rows)),
+          "rx_unpermute_rows")
+    return out
+
+
+def permute_rows(rows: Tensor, perm: Tensor) -> Tensor:
+    out = torch.empty_like(rows)
+    dim = rows.shape[1] if rows.dim() == 2 else 1
+    check(lib.rx_permute_rows(_p(rows), _p(perm), perm.numel(), dim, _p(out), _dev(rows), _stream(rows)),
+          "rx_permute_rows")
+    return out
+
+
+def topk_codes(scores: Tensor, codes: Optional[Tensor], k: int) -> Tensor:
+    _req(scores, torch.float32, "scores", 2)
+    if codes is not None:
+        _idx(codes, "codes")
+        if codes.shape != scores.shape:
+            raise ValueError("codes and scores must have the same shape")
+    rows, n = scores.shape
+    out = torch.empty(rows, k, dtype=torch.int64, device=scores.device)
+    check(lib.rx_topk_codes(_p(scores), _p(codes), rows, n, k, _p(out), _dev(scores), _stream(scores)),
+          "rx_topk_codes")
+    return out

@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol the header
+declares, and the host wrappers reject bad tensors before any launch (no GPU needed)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "recsys_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from recsys_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in recsys_hip.h but not exported"
+        assert s in _lib.PROTOTYPES, f"{s} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == set(syms)
+    assert _lib.lib.rx_abi_version() == _lib.RX_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from recsys_amd import _lib
+    assert C.sizeof(_lib.GatherSeg) == 56
+    assert C.sizeof(_lib.MFArgs) == 19 * 8 + 8
+    assert C.sizeof(_lib.FMArgs) == 8 * 8 + 16
+
+
+def test_workspace_queries_are_pure_host_calls():
+    from recsys_amd import _lib
+    assert _lib.lib.rx_sort_dedup_workspace_bytes(0) > 0
+    a, b = _lib.lib.rx_sort_dedup_workspace_bytes(1000), _lib.lib.rx_sort_dedup_workspace_bytes(100000)
+    assert 16 * 1000 <= a < b
+    assert _lib.lib.rx_bce_workspace_bytes(10) >= 8
+    assert _lib.lib.rx_segreduce_grid(1024, 16) == 1024 * 4 // 256
+    assert _lib.lib.rx_segreduce_grid(1024, 64) == 1024 * 16 // 256
+    assert _lib.lib.rx_mf_bwd_grid(1024, 64) == 64
+
+
+def test_wrappers_reject_cpu_and_wrong_dtype_tensors():
+    from recsys_amd import ops
+    U, V = torch.randn(4, 8), torch.randn(5, 8)
+    users, items = torch.zeros(3, dtype=torch.int64), torch.zeros(3, 2, dtype=torch.int64)
+    with pytest.raises(ValueError, match="GPU"):
+        ops.mf_score_fwd(U, V, users, items)
+    with pytest.raises(ValueError, match="GPU"):
+        ops.sort_dedup(users, 4)
+    with pytest.raises(TypeError):
+        ops.mf_score_fwd("not a tensor", V, users, items)
+
+
+def test_models_keep_reference_parameter_names():
+    from conftest import MODEL_FIXTURES, group, load_golden, model_kwargs
+    import inspect
+    from recsys_amd.models import matrix_factorization as mf, neuralcf as ncf
+    for fx in MODEL_FIXTURES:
+        rec = load_golden(fx)
+        name = fx.split("_d")[0]
+        cls = getattr(mf, name, None) or getattr(ncf, name)
+        kw = {k: v for k, v in model_kwargs(rec).items() if k in inspect.signature(cls.__init__).parameters}
+        m = cls(**kw)
+        ref = group(rec, "state")
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(ref.keys()), name
+        for k, v in ref.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (name, k)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})
+        sparse = list(m.sparse_parameters())
+        assert sparse and all(p.requires_grad for p in sparse)
+
+
+def test_same_seed_gives_reference_initial_weights():
+    """Construction order and init calls mirror the reference, so the golden initial state (made
+    with torch.manual_seed(100 + i)) is reproduced bit for bit."""
+    from conftest import MODEL_FIXTURES, group, load_golden, model_kwargs
+    import inspect
+    from recsys_amd.models import matrix_factorization as mf, neuralcf as ncf
+    order = ["VanillaMF", "BiasMF", "SideFeaturesMF", "TemporalMF", "FactorizationMachine", "GMF", "MLP",
+             "NeuMF", "WidenDeep", "DeepFactorizationMachine"]
+    for fx in MODEL_FIXTURES:
+        rec = load_golden(fx)
+        name = fx.split("_d")[0]
+        cls = getattr(mf, name, None) or getattr(ncf, name)
+        kw = {k: v for k, v in model_kwargs(rec).items() if k in inspect.signature(cls.__init__).parameters}
+        torch.manual_seed(100 + order.index(name))
+        m = cls(**kw)
+        for k, v in group(rec, "state").items():
+            assert torch.equal(m.state_dict()[k], torch.from_numpy(v)), (name, k)

@@ -1,0 +1,291 @@
+"""Kernel-level parity on the GPU, called through the C ABI (recsys_amd.ops wraps ctypes 1:1).
+
+Integer / index results (gathered rows, sort order, distinct-row sets, run offsets, owner
+buckets, top-k codes) must be bit-exact against torch / numpy on the CPU; floating-point results
+are compared with rtol 1e-5 against the fp32 CPU oracle (tolerance scaled by the tensor's
+magnitude, see conftest.assert_close)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from recsys_amd import ops as o
+    return o
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------ gather
+@pytest.mark.parametrize("dim", [1, 3, 16, 20, 64, 128, 260])
+def test_gather_rows_bit_exact(ops, dim):
+    g = _gen(dim)
+    table = torch.randn(97, dim, generator=g)
+    users = torch.randint(0, 97, (33,), generator=g)
+    items = torch.randint(0, 97, (33, 5), generator=g)
+    ex = torch.randint(0, 30, (33, 3), generator=g)
+    td, ud, idd, exd = table.cuda(), users.cuda(), items.cuda(), ex.cuda()
+    segs = [ops.Segment(td, ud, 0, div=5), ops.Segment(td, idd, dim), ops.Segment(td, exd, 2 * dim, div=5, stride=3, k=1, base=7)]
+    out = ops.gather_concat(segs, 33 * 5, 3 * dim).cpu()
+    exp = torch.cat([table[users][:, None, :].expand(33, 5, dim), table[items], table[ex[:, 1] + 7][:, None, :].expand(33, 5, dim)], -1)
+    assert torch.equal(out, exp.reshape(33 * 5, 3 * dim))
+
+
+def test_gather_out_of_range_raises(ops):
+    table = torch.randn(10, 8).cuda()
+    bad = torch.tensor([0, 10, 3]).cuda()
+    with pytest.raises(IndexError):
+        ops.gather_concat([ops.Segment(table, bad, 0)], 3, 8)
+    neg = torch.tensor([0, -1, 3]).cuda()
+    with pytest.raises(IndexError):
+        ops.gather_concat([ops.Segment(table, neg, 0)], 3, 8)
+    ok = torch.tensor([0, 9, 3]).cuda()
+    ops.gather_concat([ops.Segment(table, ok, 0)], 3, 8)
+
+
+def test_empty_batch(ops):
+    table = torch.randn(10, 8).cuda()
+    out = ops.gather_concat([ops.Segment(table, torch.zeros(0, dtype=torch.int64).cuda(), 0)], 0, 8)
+    assert out.shape == (0, 8)
+    si = ops.sort_dedup(torch.zeros(0, dtype=torch.int64).cuda(), 10)
+    assert int(si.n_uniq.item()) == 0
+
+
+# ------------------------------------------------------------------ sort / dedup
+@pytest.mark.parametrize("n,n_rows", [(1, 1), (5, 3), (64, 7), (1000, 50), (4096, 4096), (4097, 100000),
+                                      (70001, 6040), (300000, 33_000_000), (200000, 2**32)])
+def test_sort_dedup_bit_exact(ops, n, n_rows):
+    g = _gen(n)
+    if n_rows > 2**31:
+        idx = torch.randint(0, 2**31, (n,), generator=g) * 2 + torch.randint(0, 2, (n,), generator=g)
+    else:
+        # skewed like item popularity: many repeats of small ids plus a uniform tail
+        idx = torch.where(torch.rand(n, generator=g) < 0.5, torch.randint(0, max(n_rows // 50, 1), (n,), generator=g),
+                          torch.randint(0, n_rows, (n,), generator=g))
+    si = ops.sort_dedup(idx.cuda(), n_rows, want_inverse=True)
+    nu = int(si.n_uniq.item())
+    exp_sorted, exp_pos = torch.sort(idx, stable=True)
+    uniq, inv, counts = torch.unique(idx, sorted=True, return_inverse=True, return_counts=True)
+    assert nu == uniq.numel()
+    assert torch.equal(si.sorted_pos.cpu().long(), exp_pos)
+    assert torch.equal(si.uniq_rows[:nu].cpu(), uniq)
+    seg = si.seg_off[: nu + 1].cpu().long()
+    assert torch.equal(seg[1:] - seg[:-1], counts)
+    assert int(seg[0]) == 0 and int(seg[-1]) == n
+    assert torch.equal(si.inverse.cpu().long(), inv)
+
+
+def test_sort_dedup_is_deterministic(ops):
+    idx = torch.randint(0, 1000, (50000,), generator=_gen(1)).cuda()
+    a = ops.sort_dedup(idx, 1000)
+    b = ops.sort_dedup(idx, 1000)
+    nu = int(a.n_uniq.item())
+    assert nu == int(b.n_uniq.item())
+    assert torch.equal(a.sorted_pos, b.sorted_pos) and torch.equal(a.seg_off[: nu + 1], b.seg_off[: nu + 1])
+    assert torch.equal(a.uniq_rows[:nu], b.uniq_rows[:nu])
+
+
+def test_sort_dedup_flags_out_of_range(ops):
+    idx = torch.tensor([1, 5, 2]).cuda()
+    ops.sort_dedup(idx, 5)
+    with pytest.raises(IndexError):
+        ops.raise_if_index_error()
+
+
+# ------------------------------------------------------------------ segmented reduce + updates
+@pytest.mark.parametrize("dim", [1, 5, 16, 64, 128])
+def test_segreduce_dense_matches_index_add(ops, dim):
+    from recsys_amd import _lib
+    g = _gen(dim + 3)
+    n, rows = 5000, 300
+    idx = torch.randint(0, rows, (n,), generator=g)
+    occ = torch.randn(n, dim, generator=g)
+    si = ops.sort_dedup(idx.cuda(), rows)
+    grad = torch.zeros(rows, dim).cuda()
+    sq = ops.segreduce(occ.cuda(), si, _lib.RX_SEG_DENSE, grad, want_sq=True)
+    exp = torch.zeros(rows, dim, dtype=torch.float64).index_add_(0, idx, occ.double())
+    assert_close(grad.cpu().numpy(), exp.numpy(), what="dense grad")
+    assert_close(float(sq.double().sum().item()), float((exp ** 2).sum()), what="sum of squares")
+    # run-to-run bitwise reproducibility
+    grad2 = torch.zeros(rows, dim).cuda()
+    ops.segreduce(occ.cuda(), si, _lib.RX_SEG_DENSE, grad2)
+    assert torch.equal(grad, grad2)
+    # untouched rows are exactly zero, touched-row set is exact
+    touched = torch.zeros(rows, dtype=torch.bool)
+    touched[idx] = True
+    assert torch.equal((grad.cpu() != 0).any(1) | ~touched, torch.ones(rows, dtype=torch.bool)) or dim == 1
+    assert not grad.cpu()[~touched].any()
+
+
+@pytest.mark.parametrize("mode", ["sgd", "adagrad", "rowwise_adagrad"])
+@pytest.mark.parametrize("dim", [1, 16, 64])
+def test_fused_row_update_matches_torch_optim(ops, mode, dim):
+    from recsys_amd import _lib
+    g = _gen(11)
+    n, rows, lr = 3000, 200, 0.1
+    w0 = torch.randn(rows, dim, generator=g)
+    w_ref = w0.clone().requires_grad_(True)
+    w_dev = w0.clone().cuda()
+    state = None
+    if mode == "adagrad":
+        state = torch.zeros(rows, dim).cuda()
+        opt = torch.optim.Adagrad([w_ref], lr=lr)
+    elif mode == "rowwise_adagrad":
+        state = torch.zeros(rows).cuda()
+        opt = None
+        ref_state = torch.zeros(rows)
+    else:
+        opt = torch.optim.SGD([w_ref], lr=lr)
+    code = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}[mode]
+    for step in range(3):
+        idx = torch.randint(0, rows // 2, (n,), generator=g)  # upper half never touched
+        occ = torch.randn(n, dim, generator=g)
+        si = ops.sort_dedup(idx.cuda(), rows)
+        ops.segreduce(occ.cuda(), si, code, w_dev, state=state, lr=lr, eps=1e-10)
+        grad = torch.zeros(rows, dim).index_add_(0, idx, occ)
+        if opt is not None:
+            opt.zero_grad()
+            w_ref.grad = grad
+            opt.step()
+        else:
+            with torch.no_grad():
+                ref_state += (grad ** 2).mean(1)
+                touched = torch.zeros(rows, dtype=torch.bool)
+                touched[idx] = True
+                upd = lr * grad / (ref_state.sqrt()[:, None] + 1e-10)
+                w_ref -= torch.where(touched[:, None], upd, torch.zeros_like(upd))
+    assert_close(w_dev.cpu().numpy(), w_ref.detach().numpy(), what=f"{mode} weights")
+    assert torch.equal(w_dev.cpu()[rows // 2:], w0[rows // 2:]), "untouched rows must not move"
+
+
+def test_two_phase_clip_update(ops):
+    from recsys_amd import _lib
+    g = _gen(5)
+    n, rows, dim, lr = 2000, 100, 16, 0.5
+    w0 = torch.randn(rows, dim, generator=g)
+    idx = torch.randint(0, rows, (n,), generator=g)
+    occ = torch.randn(n, dim, generator=g)
+    si = ops.sort_dedup(idx.cuda(), rows)
+    compact = torch.empty(n, dim).cuda()
+    sq = ops.segreduce(occ.cuda(), si, _lib.RX_SEG_COMPACT, compact, want_sq=True)
+    acc = torch.zeros(1, dtype=torch.float64).cuda()
+    ops.sum_accumulate(sq, acc)
+    scale, total = ops.clip_scale(acc, 1.0)
+    w = w0.clone().cuda()
+    ops.row_update(compact, si, _lib.RX_SEG_SGD, w, lr=lr, scale=scale)
+    grad = torch.zeros(rows, dim).index_add_(0, idx, occ)
+    wr = w0.clone().requires_grad_(True)
+    wr.grad = grad.clone()
+    tn = torch.nn.utils.clip_grad_norm_([wr], 1.0)
+    assert_close(total.item(), tn.item(), what="total norm")
+    with torch.no_grad():
+        wr -= lr * wr.grad
+    assert_close(w.cpu().numpy(), wr.detach().numpy(), what="clipped sgd")
+
+
+# ------------------------------------------------------------------ dense layers
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 3, 5), (130, 32, 64), (257, 64, 128), (1000, 1, 32),
+                                   (513, 107, 214), (300, 214, 429), (2048, 128, 256)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_fp32_matches_cpu(ops, M, N, K, act):
+    g = _gen(M * 7 + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), act).cpu()
+    exp = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if act:
+        exp = exp.relu()
+    assert_close(y.numpy(), exp.numpy(), what="linear fwd")
+    dy = torch.randn(M, N, generator=g)
+    dx = ops.linear_bwd_x(dy.cuda(), w.cuda()).cpu()
+    assert_close(dx.numpy(), (dy.double() @ w.double()).numpy(), what="linear bwd x")
+    dw, db = ops.linear_bwd_w(dy.cuda(), x.cuda())
+    assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), what="linear bwd w")
+    assert_close(db.cpu().numpy(), dy.double().sum(0).numpy(), what="linear bwd b")
+
+
+def test_linear_tile_layout_asymmetric(ops):
+    """A = I against an asymmetric B catches a transposed accumulator write."""
+    n = 96
+    x = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 40.0
+    y = ops.linear_fwd(x.cuda(), w.cuda(), None, 0).cpu()
+    assert torch.equal(y, w.T.contiguous())
+    y16 = ops.linear_fwd(x.cuda(), w.cuda(), None, 0, bf16=True).cpu()
+    assert torch.equal(y16, w.T.contiguous())  # small integers are exact in bf16
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 32, 64), (513, 107, 214), (1024, 256, 432)])
+def test_linear_bf16_within_1e2(ops, M, N, K):
+    g = _gen(M + 1)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), 0, bf16=True).cpu()
+    exp = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert_close(y.numpy(), exp.numpy(), rtol=1e-2, what="bf16 linear fwd")
+    dy = torch.randn(M, N, generator=g)
+    dx = ops.linear_bwd_x(dy.cuda(), w.cuda(), bf16=True).cpu()
+    assert_close(dx.numpy(), (dy.double() @ w.double()).numpy(), rtol=1e-2, what="bf16 bwd x")
+    dw, db = ops.linear_bwd_w(dy.cuda(), x.cuda(), bf16=True)
+    assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=1e-2, what="bf16 bwd w")
+
+
+def test_linear_on_column_block(ops):
+    g = _gen(2)
+    wide = torch.randn(200, 96, generator=g).cuda()
+    w = torch.randn(16, 32, generator=g).cuda()
+    y = ops.linear_fwd(wide[:, 32:64], w, None, 0).cpu()
+    assert_close(y.numpy(), (wide[:, 32:64].cpu().double() @ w.cpu().double().T).numpy(), what="column block")
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_bce_matches_torch(ops, dtype):
+    g = _gen(9)
+    x = torch.randn(333, 5, generator=g) * 4
+    y = (torch.rand(333, 5, generator=g) < 0.3).to(dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y)
+    ref.backward()
+    loss, dl = ops.bce_with_logits(x.cuda(), y.cuda())
+    assert loss.dtype == torch.float64
+    assert_close(loss.item(), ref.item(), rtol=1e-6 if dtype == torch.float32 else 1e-9, what="bce loss")
+    assert_close(dl.cpu().numpy(), xr.grad.numpy(), what="bce grad")
+
+
+# ------------------------------------------------------------------ top-k, exchange helpers
+@pytest.mark.parametrize("rows,n,k", [(37, 100, 10), (5, 64, 64), (3, 1000, 5), (1, 7, 1)])
+def test_topk_matches_numpy_argsort(ops, rows, n, k):
+    rng = np.random.RandomState(rows)
+    scores = rng.randn(rows, n).astype(np.float32)
+    codes = np.stack([rng.permutation(5000)[:n] for _ in range(rows)]).astype(np.int64)
+    exp = np.take_along_axis(codes, np.argsort(scores, axis=1)[:, ::-1][:, :k], axis=1)
+    got = ops.topk_codes(torch.from_numpy(scores).cuda(), torch.from_numpy(codes).cuda(), k).cpu().numpy()
+    assert np.array_equal(got, exp)
+    got_cols = ops.topk_codes(torch.from_numpy(scores).cuda(), None, k).cpu().numpy()
+    assert np.array_equal(got_cols, np.argsort(scores, axis=1)[:, ::-1][:, :k])
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bucketize_by_owner(ops, world):
+    g = _gen(world)
+    n, rows = 10000, 5000
+    idx = torch.randint(0, rows, (n,), generator=g)
+    counts, send_local, perm = ops.bucketize_by_owner(idx.cuda(), world, rows)
+    owner = idx % world
+    exp_perm = torch.sort(owner, stable=True)[1]
+    assert torch.equal(perm.cpu().long(), exp_perm)
+    assert torch.equal(counts.cpu(), torch.bincount(owner, minlength=world))
+    assert torch.equal(send_local.cpu(), (idx // world)[exp_perm])
+    rows_t = torch.randn(n, 16, generator=g)
+    back = ops.unpermute_rows(rows_t.cuda(), perm).cpu()
+    exp = torch.empty_like(rows_t)
+    exp[exp_perm] = rows_t
+    assert torch.equal(back, exp)
+    assert torch.equal(ops.permute_rows(back.cuda(), perm).cpu(), rows_t)
