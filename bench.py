@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Train-step throughput of the embedding + interaction hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+A *step* is one pass of fwd + bwd + update over one batch of seeded synthetic input that is
+already resident in HBM.  A *sample* is one batch row.  The default workload is the
+Criteo-shaped 26-field factorization machine (D = 16, batch 65536 per GPU): the configuration
+on which "embedding HBM GB/s vs peak" is meaningful.  The step follows the reference's train
+step (recsys/utils.py:96-103: zero_grad, loss, backward, global grad-norm clip at 1.0,
+optimizer step) with the optimizer being the fused sparse SGD row update.
+
+Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel of the step by its
+algorithmic bytes (DESIGN.md lists the per-kernel formulas) over its average duration, measured
+with HIP events on the launch stream inside the timed region.  ``cpu_baseline`` is the CPU oracle
+(a PyTorch restatement of the reference modules and train step) timed on this host's cores on a
+bounded number of steps of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+# ----------------------------------------------------------------------------- workloads
+def build_workload(name: str, device, rank: int, world: int, clip):
+    """Returns dict(model, opt, batches, samples_per_step, desc, algo_bytes fn)."""
+    from recsys_amd import synthetic
+    from recsys_amd.models import fields
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+
+    torch.manual_seed(1234)
+    n_batches = 8
+    if name in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+        dims = synthetic.criteo_field_dims()
+        B, D = 65536, 16
+        cls = {"fm_criteo": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM, "dcnv2_criteo": fields.DCNv2}[name]
+        with torch.device(device):
+            model = cls(dims, D)
+        batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
+        desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
+                "items_per_row": 1, "optimizer": "fused sparse SGD", "clip_norm": clip}
+        lr = 0.05
+    elif name in ("mf_ml1m", "neumf_ml1m"):
+        B = 1024 if name == "mf_ml1m" else 8192
+        D = 64
+        with torch.device(device):
+            if name == "mf_ml1m":
+                model = VanillaMF(synthetic.ML1M["n_users"], synthetic.ML1M["n_items"], D)
+            else:
+                model = NeuMF(synthetic.ML1M["n_users"], synthetic.ML1M["n_items"], D)
+        batches = [synthetic.ml1m_batch(B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
+        desc = {"workload": name, "rows": synthetic.ML1M["n_users"] + synthetic.ML1M["n_items"], "dim": D,
+                "batch_per_gpu": B, "items_per_row": 5, "optimizer": "fused sparse SGD", "clip_norm": clip}
+        lr = 0.05
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    model.train()
+    opt = FusedOptimizer(model, kind="sgd", lr=lr, clip_norm=clip)
+    return dict(model=model, opt=opt, batches=batches, B=B, desc=desc)
+
+
+def one_step(w, i):
+    batch = w["batches"][i % len(w["batches"])]
+    w["opt"].zero_grad()
+    loss = w["model"].loss(batch)
+    loss.backward()
+    w["opt"].step()
+    return loss
+
+
+# ----------------------------------------------------------------------------- per-op timing
+class OpTimer:
+    """Wraps chosen functions of recsys_amd.ops with HIP events recorded on the launch stream."""
+
+    def __init__(self, names):
+        from recsys_amd import ops
+        self.ops, self.names, self.events, self.saved = ops, list(names), {n: [] for n in names}, {}
+
+    def __enter__(self):
+        for n in self.names:
+            fn = getattr(self.ops, n)
+            self.saved[n] = fn
+
+            def wrapped(*a, __fn=fn, __n=n, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = __fn(*a, **k)
+                e.record()
+                self.events[__n].append((s, e))
+                return out
+
+            setattr(self.ops, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.saved.items():
+            setattr(self.ops, n, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, evs in self.events.items():
+            if evs:
+                ms = [s.elapsed_time(e) for s, e in evs]
+                out[n] = (sum(ms) / len(ms), len(ms))
+        return out
+
+
+ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", "row_update", "bce_with_logits",
+           "mf_score_fwd", "mf_score_bwd", "gather_concat", "gather_concat_bwd", "gmf_mul_fwd", "gmf_mul_bwd",
+           "linear_fwd", "linear_bwd_x", "linear_bwd_w", "relu_bwd", "sumsq_accumulate", "sum_accumulate",
+           "clip_scale", "reduce_sum", "cross_combine_fwd", "cross_combine_bwd"]
+
+
+def algo_bytes(desc, op):
+    """Algorithmic HBM bytes of one launch of the step's dominant kernels (fp32, 8-byte indices)."""
+    B, D = desc["batch_per_gpu"], desc["dim"]
+    if desc["workload"] in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+        F = desc["fields"]
+        if op == "fm2_fwd":  # index + row + bias entry per field, one logit out
+            return B * (F * (8 + 4 * D + 4) + 4)
+        if op == "fm2_bwd":  # logit grad in; indices + rows re-read; per-occurrence grad rows (+bias) out
+            return B * (4 + F * (8 + 4 * D) + F * (4 * D + 4))
+        if op == "segreduce":  # sorted positions + per-occurrence rows in; unique rows read+write (rho = 1 bound)
+            return B * F * (4 + 4 * D + 2 * 4 * D)
+    return None
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(name, desc, clip, budget_s=25.0):
+    """The oracle's train step (dense gradients, clip_grad_norm_, torch SGD) on the host cores."""
+    from oracle.fields import FieldOracle
+    from oracle.models import OracleModel, init_state
+    from recsys_amd import synthetic
+    from recsys_amd.models import fields
+
+    threads = torch.get_num_threads()
+    B = desc["batch_per_gpu"]
+    if name in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+        dims = synthetic.criteo_field_dims()
+        cls = {"fm_criteo": "FieldFM", "deepfm_criteo": "FieldDeepFM", "dcnv2_criteo": "DCNv2"}[name]
+        torch.manual_seed(1234)
+        m = getattr(fields, cls)(dims, desc["dim"])
+        oracle = FieldOracle(cls, m.state_dict(), dims, dropout=0.1)
+        del m
+        batches = [synthetic.criteo_batch(dims, B, seed=i, device="cpu") for i in range(2)]
+    else:
+        mname = "VanillaMF" if name == "mf_ml1m" else "NeuMF"
+        st = init_state(mname, n_users=synthetic.ML1M["n_users"], n_items=synthetic.ML1M["n_items"],
+                        embedding_dim=desc["dim"], seed=0)
+        oracle = OracleModel(mname, st, n_users=synthetic.ML1M["n_users"], n_items=synthetic.ML1M["n_items"])
+        batches = [synthetic.ml1m_batch(B, seed=i, device="cpu") for i in range(2)]
+    opt = torch.optim.SGD(oracle.parameters(), lr=0.05)
+
+    def step(i):
+        opt.zero_grad()
+        loss = oracle.loss(batches[i % 2])
+        loss.backward()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(oracle.parameters(), clip)
+        opt.step()
+        return loss.item()
+
+    step(0)  # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step(n)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": B * n / el, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the same workload (batch {B}) after 1 warm-up step, dense gradients + "
+                      f"clip_grad_norm_ + torch.optim.SGD, {el:.1f} s"}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="fm_criteo")
+    ap.add_argument("--no-clip", action="store_true", help="skip the global grad-norm clip (one-phase fused update)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
+    ap.add_argument("--extra", default="", help="comma list of further workloads to time briefly and append")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from recsys_amd import ops
+    ops.set_index_check("deferred")
+    clip = None if args.no_clip else 1.0
+
+    def run(name, steps, warmup, timed_op=None):
+        w = build_workload(name, device, rank, world, clip)
+        for i in range(warmup):
+            one_step(w, i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        timer = OpTimer([timed_op] if timed_op else [])
+        t0 = time.perf_counter()
+        with timer:
+            for i in range(steps):
+                loss = one_step(w, warmup + i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ops.raise_if_index_error()
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return w, el, timer.summary(), float(loss.item())
+
+    if args.op_profile and rank == 0:
+        w = build_workload(args.workload, device, rank, world, clip)
+        for i in range(5):
+            one_step(w, i)
+        with OpTimer(ALL_OPS) as t:
+            for i in range(20):
+                one_step(w, i)
+        for n, (ms, cnt) in sorted(t.summary().items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
+        del w
+
+    dominant = {"fm_criteo": "fm2_bwd", "deepfm_criteo": "linear_bwd_w", "dcnv2_criteo": "linear_bwd_w",
+                "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
+    w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, dominant)
+    B = w["B"]
+    value = B * world * args.steps / el
+    out = {
+        "metric": "train samples/sec (fwd+bwd+update)", "value": value, "unit": "samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": dict(w["desc"], global_batch=B * world, parallelism=f"dp{world}" if world > 1 else "single"),
+        "final_loss": last_loss,
+    }
+    roof = None
+    if dominant in ops_ms:
+        ms, cnt = ops_ms[dominant]
+        ab = algo_bytes(w["desc"], dominant)
+        if ab:
+            ach = ab / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": ms * 1e3,
+                    "algorithmic_bytes_per_launch": ab}
+    out["roofline"] = roof
+    del w
+    torch.cuda.empty_cache()
+
+    extras = [x for x in args.extra.split(",") if x]
+    if extras and rank == 0 and world == 1:
+        out["other_workloads"] = []
+        for name in extras:
+            w2, el2, _, _ = run(name, 30, 5)
+            out["other_workloads"].append({"workload": name, "samples_per_s": w2["B"] * 30 / el2,
+                                           "ms_per_step": 1e3 * el2 / 30})
+            del w2
+            torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, out["config"], clip)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

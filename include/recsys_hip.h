@@ -150,17 +150,21 @@ int rx_gmf_mul_bwd(const float* user_table, int64_t n_users, const float* item_t
  * logits[b,n] = sum_f bias[ex_f] + bias[item_n]
  *             + 0.5 * sum_d [ (sum_f e_f + v_n)^2 - (sum_f e_f^2 + v_n^2) ]_d
  * deep_out (may be NULL) receives the gathered rows as the DeepFM tower input
- * [B*N, (1+F)*dim]: item row first, then the F rows (deep_factorization_machine.py:94-102).
+ * [B*N, deep_ld]: item row first, then the F rows (deep_factorization_machine.py:94-102).
+ * d_logits may be NULL when only the gathered rows are wanted (DCN-v2 input).
  * With N == 1 and F = 25 this is the 26-field Criteo-shaped FM.
  */
 typedef struct {
   const float* feat;        /* [n_feat, dim] */
   const float* bias;        /* [n_feat] (the [n_feat,1] table) or NULL */
   int64_t n_feat;
-  const int64_t* ex_idx;    /* [B, F] */
+  const int64_t* ex_idx;    /* [B, F], row stride ex_ld */
   const int64_t* ex_base;   /* device [F] offsets */
-  const int64_t* item_idx;  /* [B, N] */
+  const int64_t* item_idx;  /* [B, N], row stride item_ld */
   int64_t item_base;
+  int64_t ex_ld;            /* >= F: lets ex_idx / item_idx be column blocks of one [B, F+N] matrix */
+  int64_t item_ld;          /* >= N */
+  int64_t deep_ld;          /* row stride of deep_out / d_deep, >= (1+F)*dim (room for dense features) */
   int64_t B; int32_t F; int32_t N; int32_t dim;
   int32_t flags;            /* RX_FM_NO_SECOND_ORDER: bias sums only (the wide part of
                                recsys/models/neuralcf/widendeep.py:69-77); rows still feed deep_out */
@@ -197,6 +201,8 @@ int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int6
  * parameter of the reference models).  Stable LSD radix sort of (row, position) pairs,
  * then run-length compaction:
  *   sorted_pos [n] int32   positions 0..n-1 ordered by (row, position)
+ *   sorted_slot[n] int32   index into uniq_rows of the row at each sorted position (may be NULL;
+ *                          rx_segreduce needs it)
  *   uniq_rows  [n] int64   distinct rows ascending (first *n_uniq entries valid)
  *   seg_off    [n+1] int32 start of each row's run in sorted_pos; seg_off[*n_uniq] = n
  *   n_uniq     [1] int32   (device)
@@ -205,30 +211,39 @@ int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int6
  * clamped.  Equal to torch.sort(stable=True) / torch.unique(sorted=True, return_inverse). */
 size_t rx_sort_dedup_workspace_bytes(int64_t n);
 int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
-                  int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
+                  int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                   int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
                   void* stream);
 
 /* ------------------------------------------------------------------ segmented reduce + update
- * Second stage.  For each distinct row u (fixed order: positions ascending) the gradient
+ * Second stage.  For each distinct row u the gradient
  *   G_u = sum_{p in run u} occ[sorted_pos[p], :]
- * is formed by one lane group without atomics, then consumed according to `mode`:
+ * is formed without atomics in an order fixed by the sort (runs are cut every 32 sorted
+ * positions: position order inside a piece, piece order across pieces, so hot rows cost no
+ * more wall time than cold ones), then consumed according to `mode`:
  *   RX_SEG_DENSE   grad[row, :]  = G_u                   (grad pre-zeroed by the caller)
  *   RX_SEG_COMPACT grad[u, :]    = G_u
  *   RX_SEG_SGD     w[row] -= lr * scale * G_u                              (torch.optim.SGD)
  *   RX_SEG_ADAGRAD state[row] += (scale G_u)^2 ; w[row] -= lr * scale G_u / (sqrt(state)+eps)
  *                                                                      (torch.optim.Adagrad)
  *   RX_SEG_ROWWISE_ADAGRAD  state[row] (one float per row) += mean_d (scale G_u)^2
+ * A companion scalar table addressed by the same rows (the [n,1] bias / wide table that the
+ * reference gathers with the same indices, factorization_machine.py:40-51) can ride along:
+ * d_occ2 [n] per-occurrence gradients, d_target2 / d_state2 its table (or dense / compact
+ * gradient) and Adagrad state; all three NULL when absent.
  * scale = *d_scale if d_scale != NULL else 1 (global-norm clip factor, recsys/utils.py:101).
- * d_sq_part (may be NULL) [rx_segreduce_grid(n, dim)] receives per-block sum of G_u^2. */
+ * d_sq_part (may be NULL) [rx_segreduce_grid(n, dim)] receives per-block sums of G_u^2.
+ * ws: rx_segreduce_workspace_bytes(n, dim) bytes, 16-byte aligned (cross-piece partial sums). */
 enum { RX_SEG_DENSE = 0, RX_SEG_COMPACT = 1, RX_SEG_SGD = 2, RX_SEG_ADAGRAD = 3,
        RX_SEG_ROWWISE_ADAGRAD = 4 };
 int64_t rx_segreduce_grid(int64_t n, int32_t dim);
+size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim);
 int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
-                 const int32_t* d_sorted_pos, const int64_t* d_uniq_rows,
-                 const int32_t* d_seg_off, const int32_t* d_n_uniq, int mode, float* d_target,
-                 float* d_state, int64_t n_rows, float lr, float eps, const float* d_scale,
-                 float* d_sq_part, int device, void* stream);
+                 const int32_t* d_sorted_pos, const int32_t* d_sorted_slot,
+                 const int64_t* d_uniq_rows, const int32_t* d_seg_off, const int32_t* d_n_uniq,
+                 int mode, float* d_target, float* d_state, const float* d_occ2, float* d_target2,
+                 float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
+                 float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
 
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above
@@ -289,12 +304,14 @@ int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int devic
 
 /* ------------------------------------------------------------------ DCN-v2 cross layer
  * No counterpart in the reference.  x_{l+1} = x0 * (x_l W^T + b) + x_l, W [d,d].
- * fwd: XW = rx_linear_fwd(x_l, W, b) then rx_cross_combine; bwd elementwise part:
- *   given dXn: dU = dXn * x0 ; dX0 += dXn * U ; dXl (+)= dXn          (U = x_l W^T + b) */
-int rx_cross_combine_fwd(const float* x0, const float* u, const float* xl, float* xn, int64_t n,
-                         int device, void* stream);
-int rx_cross_combine_bwd(const float* dxn, const float* x0, const float* u, float* du,
-                         float* dx0_acc, float* dxl, int64_t n, int device, void* stream);
+ * fwd: U = rx_linear_fwd(x_l, W, b) then xn = x0 * U + x_l; bwd elementwise part, given dXn:
+ *   dU = dXn * x0 ; dX0 += dXn * U ; dXl = dXn.   All operands [rows, cols] with own row strides. */
+int rx_cross_combine_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* xl,
+                         int64_t ldl, float* xn, int64_t ldn, int64_t rows, int32_t cols, int device,
+                         void* stream);
+int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u,
+                         int64_t ldu, float* du, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl,
+                         int64_t ldxl, int64_t rows, int32_t cols, int device, void* stream);
 
 /* ------------------------------------------------------------------ row-sharded exchange helpers
  * No counterpart in the reference (single device).  Row r of a table lives on rank r % G at

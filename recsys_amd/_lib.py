@@ -31,7 +31,8 @@ class MFArgs(C.Structure):
 
 class FMArgs(C.Structure):
     _fields_ = [("feat", vp), ("bias", vp), ("n_feat", i64), ("ex_idx", vp), ("ex_base", vp),
-                ("item_idx", vp), ("item_base", i64), ("B", i64), ("F", i32), ("N", i32),
+                ("item_idx", vp), ("item_base", i64), ("ex_ld", i64), ("item_ld", i64),
+                ("deep_ld", i64), ("B", i64), ("F", i32), ("N", i32),
                 ("dim", i32), ("flags", i32)]
 
 
@@ -55,9 +56,10 @@ PROTOTYPES = {
     "rx_bce_workspace_bytes": (sz, [i64]),
     "rx_bce_fwd": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, sz, C.c_int, vp]),
     "rx_sort_dedup_workspace_bytes": (sz, [i64]),
-    "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
+    "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_segreduce_grid": (i64, [i64, i32]),
-    "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, vp, i64, f32, f32, vp, vp, C.c_int, vp]),
+    "rx_segreduce_workspace_bytes": (sz, [i64, i32]),
+    "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
     "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),
@@ -72,8 +74,8 @@ PROTOTYPES = {
     "rx_linear_bwd_w_workspace_bytes": (sz, [i64, i32, i32]),
     "rx_linear_bwd_w": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, C.c_int, vp, sz, C.c_int, vp]),
     "rx_relu_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
-    "rx_cross_combine_fwd": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, vp]),
-    "rx_cross_combine_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, C.c_int, vp]),
+    "rx_cross_combine_fwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
+    "rx_cross_combine_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rx_bucketize_by_owner": (C.c_int, [vp, i64, i32, i64, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_unpermute_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),

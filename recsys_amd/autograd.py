@@ -23,18 +23,22 @@ Tensor = torch.Tensor
 
 
 def table_backward(param: Optional[Tensor], si: SortedIndex, occ: Tensor, dim: Optional[int] = None,
-                   occ_ld: Optional[int] = None) -> Optional[Tensor]:
+                   occ_ld: Optional[int] = None, param2: Optional[Tensor] = None,
+                   occ2: Optional[Tensor] = None):
     """Reduce per-occurrence gradients ``occ`` (rows ordered like the index list behind ``si``)
-    into ``param``'s gradient, or apply the parameter's fused sparse rule."""
+    into ``param``'s gradient, or apply the parameter's fused sparse rule.  ``param2`` / ``occ2``:
+    a companion [rows, 1] table gathered with the same indices, handled in the same launches.
+    Returns the dense gradient (or None), or a pair when a companion is given."""
     if param is None:
-        return None
+        return None if param2 is None else (None, None)
     rule = getattr(param, "_rx_sparse", None)
     if rule is not None:
-        rule.apply(param, occ, si, dim=dim, occ_ld=occ_ld)
-        return None
+        rule.apply(param, occ, si, dim=dim, occ_ld=occ_ld, param2=param2, occ2=occ2)
+        return None if param2 is None else (None, None)
     grad = torch.zeros_like(param)
-    ops.segreduce(occ, si, _lib.RX_SEG_DENSE, grad, dim=dim, occ_ld=occ_ld)
-    return grad
+    grad2 = torch.zeros_like(param2) if param2 is not None else None
+    ops.segreduce(occ, si, _lib.RX_SEG_DENSE, grad, dim=dim, occ_ld=occ_ld, occ2=occ2, target2=grad2)
+    return grad if param2 is None else (grad, grad2)
 
 
 # ------------------------------------------------------------------ MF-family score
@@ -82,12 +86,16 @@ class MFScore(Function):
 # ------------------------------------------------------------------ FM second order (+ DeepFM tower input)
 class FM2(Function):
     """FM bias + second-order term over one shared table (rx_fm2_fwd / _bwd).  Returns
-    ``(logits[B,N], deep[B*N,(1+F)*D] or None)``."""
+    ``(logits[B,N] or None, deep[B*N, deep_cols] or None)``.  ``deep`` holds the gathered rows
+    [item, field 0..F-1] in its first (1+F)*D columns; further columns (``deep_cols`` wider) start
+    hold ``extra`` (dense features, which get no gradient)."""
 
     @staticmethod
-    def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True):
+    def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True,
+                deep_cols=None, want_logits=True, extra=None):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
-        logits, deep = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep, second_order)
+        logits, deep = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep,
+                                   second_order, deep_cols, want_logits, extra)
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
         ctx.second_order = second_order
         return logits, deep
@@ -95,20 +103,20 @@ class FM2(Function):
     @staticmethod
     def backward(ctx, g, g_deep):
         ex_idx, ex_base, item_idx, item_base, feat, bias_table = ctx.args
-        if g is None:
-            g = torch.zeros(item_idx.shape[0], item_idx.shape[1] if item_idx.dim() == 2 else 1,
-                            dtype=torch.float32, device=feat.device)
-        g = g.contiguous()
-        if g_deep is not None:
+        if g is not None:
+            g = g.contiguous()
+        if g_deep is not None and g_deep.stride(-1) != 1:
             g_deep = g_deep.contiguous()
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         occ, bias_occ = ops.fm2_bwd(g, g_deep, feat, bias_flat, ex_idx, ex_base, item_idx, item_base,
                                     ctx.second_order)
         flat = ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base)
         s = ops.sort_dedup(flat, feat.shape[0])
-        gfeat = table_backward(feat, s, occ)
-        gbias = table_backward(bias_table, s, bias_occ, dim=1) if bias_table is not None else None
-        return (None, None, None, None, gfeat, gbias, None, None)
+        if bias_table is not None:
+            gfeat, gbias = table_backward(feat, s, occ, param2=bias_table, occ2=bias_occ)
+        else:
+            gfeat, gbias = table_backward(feat, s, occ), None
+        return (None, None, None, None, gfeat, gbias, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------ tower-input assembly
@@ -203,8 +211,10 @@ class CrossLayer(Function):
     @staticmethod
     def backward(ctx, dxn):
         x0, xl, w, u = ctx.saved_tensors
-        dxn = dxn.contiguous()
-        dx0 = torch.zeros_like(x0)
+        if dxn.stride(-1) != 1:
+            dxn = dxn.contiguous()
+        dx0 = ops._padded(x0.shape[0], x0.shape[1], x0.device)
+        dx0.zero_()
         du, dxl = ops.cross_combine_bwd(dxn, x0, u, dx0)
         ops.linear_bwd_x(du, w, ctx.bf16, out=dxl, accumulate=True)
         dw, db = ops.linear_bwd_w(du, xl, True, ctx.bf16)

@@ -460,46 +460,61 @@ extern "C" int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n
 }
 
 // ---------------------------------------------------------------- DCN-v2 cross combine
+// 2-D elementwise kernels with one row stride per operand (x0 usually lives in a padded
+// tower-input buffer).
 __global__ void __launch_bounds__(RX_BLOCK)
-cross_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ u, const float* __restrict__ xl,
-                 float* __restrict__ xn, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    xn[i] = x0[i] * u[i] + xl[i];
-}
-
-__global__ void __launch_bounds__(RX_BLOCK)
-cross_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x0, const float* __restrict__ u,
-                 float* __restrict__ du, float* __restrict__ dx0_acc, float* __restrict__ dxl, int64_t n) {
+cross_fwd_kernel(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ u, int64_t ldu,
+                 const float* __restrict__ xl, int64_t ldl, float* __restrict__ xn, int64_t ldn,
+                 int64_t rows, int cols) {
+  const int64_t n = rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float d = dxn[i];
-    du[i] = d * x0[i];
-    dx0_acc[i] += d * u[i];
-    dxl[i] = d;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    xn[r * ldn + c] = x0[r * ld0 + c] * u[r * ldu + c] + xl[r * ldl + c];
   }
 }
 
-extern "C" int rx_cross_combine_fwd(const float* x0, const float* u, const float* xl, float* xn, int64_t n,
-                                    int device, void* stream) {
+__global__ void __launch_bounds__(RX_BLOCK)
+cross_bwd_kernel(const float* __restrict__ dxn, int64_t ldd, const float* __restrict__ x0, int64_t ld0,
+                 const float* __restrict__ u, int64_t ldu, float* __restrict__ du, int64_t lddu,
+                 float* __restrict__ dx0_acc, int64_t ldx0, float* __restrict__ dxl, int64_t ldxl,
+                 int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float d = dxn[r * ldd + c];
+    du[r * lddu + c] = d * x0[r * ld0 + c];
+    dx0_acc[r * ldx0 + c] += d * u[r * ldu + c];
+    dxl[r * ldxl + c] = d;
+  }
+}
+
+extern "C" int rx_cross_combine_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu,
+                                    const float* xl, int64_t ldl, float* xn, int64_t ldn, int64_t rows,
+                                    int32_t cols, int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(n >= 0, "rx_cross_combine_fwd: bad n");
-  if (n == 0) return 0;
+  RX_REQUIRE(rows >= 0 && cols >= 1 && ld0 >= cols && ldu >= cols && ldl >= cols && ldn >= cols, "rx_cross_combine_fwd: bad shape");
+  if (rows == 0) return 0;
   RX_REQUIRE(x0 && u && xl && xn, "rx_cross_combine_fwd: null argument");
-  int64_t grid = rx_cdiv(n, RX_BLOCK);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(cross_fwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, x0, u, xl, xn, n);
+  int64_t grid = rx_cdiv(rows * cols, RX_BLOCK);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cross_fwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, x0, ld0, u, ldu, xl, ldl, xn, ldn, rows, cols);
   RX_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int rx_cross_combine_bwd(const float* dxn, const float* x0, const float* u, float* du,
-                                    float* dx0_acc, float* dxl, int64_t n, int device, void* stream) {
+extern "C" int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0,
+                                    const float* u, int64_t ldu, float* du, int64_t lddu, float* dx0_acc,
+                                    int64_t ldx0, float* dxl, int64_t ldxl, int64_t rows, int32_t cols,
+                                    int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(n >= 0, "rx_cross_combine_bwd: bad n");
-  if (n == 0) return 0;
+  RX_REQUIRE(rows >= 0 && cols >= 1 && ldd >= cols && ld0 >= cols && ldu >= cols && lddu >= cols && ldx0 >= cols && ldxl >= cols, "rx_cross_combine_bwd: bad shape");
+  if (rows == 0) return 0;
   RX_REQUIRE(dxn && x0 && u && du && dx0_acc && dxl, "rx_cross_combine_bwd: null argument");
-  int64_t grid = rx_cdiv(n, RX_BLOCK);
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(cross_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, x0, u, du, dx0_acc, dxl, n);
+  int64_t grid = rx_cdiv(rows * cols, RX_BLOCK);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cross_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, ldd, x0, ld0, u, ldu, du, lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols);
   RX_LAUNCH_CHECK();
   return 0;
 }

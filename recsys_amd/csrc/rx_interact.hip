@@ -374,9 +374,13 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
   const int64_t b0 = (int64_t)blockIdx.x * spb;
   const int F = a.F, N = a.N, dim = a.dim;
   {
-    const int64_t n_here = min((int64_t)spb, a.B - b0) * F;
-    const int64_t* src = a.ex_idx + b0 * F;
-    for (int j = threadIdx.x; j < n_here; j += blockDim.x) lds_idx[j] = src[j] + a.ex_base[j % F];
+    const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
+    const int n_here = (int)rows_here * F;
+    const int64_t* src = a.ex_idx + b0 * a.ex_ld;
+    for (int j = threadIdx.x; j < n_here; j += blockDim.x) {
+      const int r = j / F, f = j - r * F;
+      lds_idx[j] = src[r * a.ex_ld + f] + a.ex_base[f];
+    }
   }
   __syncthreads();
   const int my = threadIdx.x / group;
@@ -384,7 +388,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
   const int64_t b = b0 + my;
   if (b >= a.B) return;
   int32_t* ef = lg == 0 ? err_flag : nullptr;
-  const int64_t deep_ld = (int64_t)(1 + F) * dim;
+  const int64_t deep_ld = a.deep_ld;
 
   RowRegs<VEC, CH> S = row_zero<VEC, CH>(), Q = row_zero<VEC, CH>();
   float bsum = 0.f;
@@ -402,7 +406,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
         row_store<VEC, CH>(deep_out + (b * N + n) * deep_ld + (int64_t)(1 + f) * dim, e, lg, group, dim);
   }
   for (int n = 0; n < N; ++n) {
-    const int64_t row = a.item_idx[b * N + n] + a.item_base;
+    const int64_t row = a.item_idx[b * a.item_ld + n] + a.item_base;
     const bool ok = rx_row_ok(row, a.n_feat, ef);
     RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
     float acc = 0.f;
@@ -413,7 +417,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
     }
     acc = rx_group_sum(acc, group);
     if (deep_out) row_store<VEC, CH>(deep_out + (b * N + n) * deep_ld, v, lg, group, dim);
-    if (lg == 0) {
+    if (lg == 0 && logits) {
       float bt = bsum;
       if (a.bias && ok) bt += a.bias[row];
       logits[b * N + n] = (a.flags & RX_FM_NO_SECOND_ORDER) ? bt : bt + 0.5f * acc;
@@ -430,16 +434,20 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
   const int64_t b0 = (int64_t)blockIdx.x * spb;
   const int F = a.F, N = a.N, dim = a.dim;
   {
-    const int64_t n_here = min((int64_t)spb, a.B - b0) * F;
-    const int64_t* src = a.ex_idx + b0 * F;
-    for (int j = threadIdx.x; j < n_here; j += blockDim.x) lds_idx[j] = src[j] + a.ex_base[j % F];
+    const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
+    const int n_here = (int)rows_here * F;
+    const int64_t* src = a.ex_idx + b0 * a.ex_ld;
+    for (int j = threadIdx.x; j < n_here; j += blockDim.x) {
+      const int r = j / F, f = j - r * F;
+      lds_idx[j] = src[r * a.ex_ld + f] + a.ex_base[f];
+    }
   }
   __syncthreads();
   const int my = threadIdx.x / group;
   const int lg = threadIdx.x % group;
   const int64_t b = b0 + my;
   if (b >= a.B) return;
-  const int64_t deep_ld = (int64_t)(1 + F) * dim;
+  const int64_t deep_ld = a.deep_ld;
   float* item_occ = occ + a.B * F * (int64_t)dim;
 
   // without the second-order term only the tower gradient (d_deep) reaches the rows
@@ -458,7 +466,7 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
   for (int n = 0; n < N; ++n) {
     const float gn = g[b * N + n];
     G += gn;
-    const int64_t row = a.item_idx[b * N + n] + a.item_base;
+    const int64_t row = a.item_idx[b * a.item_ld + n] + a.item_base;
     const bool ok = row >= 0 && row < a.n_feat;
     RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
     RowRegs<VEC, CH> dv;
@@ -495,9 +503,11 @@ fm2_flat_kernel(rx_fm_args a, int64_t* __restrict__ flat) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n_ex = a.B * a.F;
   if (i < n_ex)
-    flat[i] = a.ex_idx[i] + a.ex_base[i % a.F];
-  else if (i < n_ex + a.B * a.N)
-    flat[i] = a.item_idx[i - n_ex] + a.item_base;
+    flat[i] = a.ex_idx[(i / a.F) * a.ex_ld + (i % a.F)] + a.ex_base[i % a.F];
+  else if (i < n_ex + a.B * a.N) {
+    const int64_t q = i - n_ex;
+    flat[i] = a.item_idx[(q / a.N) * a.item_ld + (q % a.N)] + a.item_base;
+  }
 }
 
 static int fm_check(const rx_fm_args* a, const char* who) {
@@ -505,6 +515,8 @@ static int fm_check(const rx_fm_args* a, const char* who) {
   RX_REQUIRE(a->B >= 0 && a->F >= 1 && a->N >= 1, "%s: bad shape B=%lld F=%d N=%d", who, (long long)a->B, a->F, a->N);
   RX_REQUIRE(a->feat && a->ex_idx && a->ex_base && a->item_idx, "%s: null table or index pointer", who);
   RX_REQUIRE(a->n_feat > 0, "%s: empty table", who);
+  RX_REQUIRE(a->ex_ld >= a->F && a->item_ld >= a->N, "%s: index row strides smaller than F / N", who);
+  RX_REQUIRE(a->deep_ld >= (int64_t)(1 + a->F) * a->dim, "%s: deep_ld smaller than (1+F)*dim", who);
   return 0;
 }
 
@@ -519,12 +531,12 @@ extern "C" int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_ou
                           int device, void* stream) {
   RX_ENTER(device);
   if (fm_check(a, "rx_fm2_fwd")) return 1;
-  RX_REQUIRE(d_logits, "rx_fm2_fwd: null logits");
+  RX_REQUIRE(d_logits || d_deep_out, "rx_fm2_fwd: neither logits nor deep_out requested");
   if (a->B == 0) return 0;
   RxRowShape sh;
   size_t lds;
   if (fm_launch_shape(a, &sh, &lds, "rx_fm2_fwd")) return 1;
-  RX_REQUIRE(!d_deep_out || sh.vec == 1 || rx_aligned16(d_deep_out), "rx_fm2_fwd: deep_out must be 16-byte aligned");
+  RX_REQUIRE(!d_deep_out || sh.vec == 1 || (rx_aligned16(d_deep_out) && a->deep_ld % 4 == 0), "rx_fm2_fwd: deep_out must be 16-byte aligned with deep_ld a multiple of 4");
   const unsigned grid = (unsigned)rx_cdiv(a->B, RX_BLOCK / sh.group);
   RX_DISPATCH_SHAPE(sh, fm2_fwd_kernel, dim3(grid), dim3(RX_BLOCK), lds, (hipStream_t)stream, *a, d_logits, d_deep_out, sh.group, err_flag);
   RX_LAUNCH_CHECK();
@@ -540,6 +552,7 @@ extern "C" int rx_fm2_bwd(const rx_fm_args* a, const float* d_g, const float* d_
   RxRowShape sh;
   size_t lds;
   if (fm_launch_shape(a, &sh, &lds, "rx_fm2_bwd")) return 1;
+  RX_REQUIRE(!d_deep || sh.vec == 1 || (rx_aligned16(d_deep) && a->deep_ld % 4 == 0), "rx_fm2_bwd: d_deep must be 16-byte aligned with deep_ld a multiple of 4");
   const unsigned grid = (unsigned)rx_cdiv(a->B, RX_BLOCK / sh.group);
   RX_DISPATCH_SHAPE(sh, fm2_bwd_kernel, dim3(grid), dim3(RX_BLOCK), lds, (hipStream_t)stream, *a, d_g, d_deep, d_occ, d_bias_occ, sh.group);
   RX_LAUNCH_CHECK();

@@ -13,12 +13,13 @@
 //           and uses no float or global atomics.
 #include "rx_common.h"
 
-#define SORT_BITS 8
-#define SORT_BINS (1 << SORT_BITS)
+#define SORT_MAX_BITS 11
+#define SORT_MAX_BINS (1 << SORT_MAX_BITS)
 #define SORT_ITEMS 16
 #define SORT_TILE (RX_BLOCK * SORT_ITEMS)  // 4096 keys per block
 #define SORT_WAVES (RX_BLOCK / 64)
 #define SORT_WAVE_KEYS (64 * SORT_ITEMS)
+#define SCAN_TILE (RX_BLOCK * 8)           // entries of the count array per scan block
 
 // keys: int64 rows -> uint32 (rows < 2^32), clamped into range; values: positions.
 __global__ void __launch_bounds__(RX_BLOCK)
@@ -35,59 +36,102 @@ sort_init_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t n_rows, uin
   vals[i] = (uint32_t)i;
 }
 
+// counts[digit][block] for this pass (bins = 1 << bits)
 __global__ void __launch_bounds__(RX_BLOCK)
-sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ block_hist,
+sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int bits, uint32_t* __restrict__ block_hist,
                  int n_blocks) {
-  __shared__ uint32_t h[SORT_BINS];
-  for (int i = threadIdx.x; i < SORT_BINS; i += blockDim.x) h[i] = 0;
+  extern __shared__ uint32_t h[];
+  const int bins = 1 << bits;
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) h[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = base + it * RX_BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (SORT_BINS - 1)], 1u);
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (bins - 1)], 1u);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < SORT_BINS; d += blockDim.x) block_hist[(int64_t)d * n_blocks + blockIdx.x] = h[d];
+  for (int d = threadIdx.x; d < bins; d += blockDim.x) block_hist[(int64_t)d * n_blocks + blockIdx.x] = h[d];
 }
 
-// Exclusive scan of block_hist viewed as one array of SORT_BINS * n_blocks counts (digit
-// major), in place.  One 1024-thread block; each thread owns a contiguous slice.
+// Exclusive scan of the digit-major count array in two levels: every block scans its own
+// SCAN_TILE entries in place and publishes its total; one block then scans the totals; the
+// scatter kernel adds the two.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds4, uint32_t* total) {
+  // wave inclusive scan by shuffles, then the 4 wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += lds4[w];
+  if (total) *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+scan_tiles_kernel(uint32_t* __restrict__ data, int64_t total, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+  uint32_t v[8], sum = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = (base + e < total) ? data[base + e] : 0u;
+    sum += v[e];
+  }
+  uint32_t tile_total;
+  uint32_t run = block_exclusive_scan(sum, lds4, &tile_total);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (base + e < total) data[base + e] = run;
+    run += v[e];
+  }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tile_total;
+}
+
+// In-place exclusive scan of up to a few hundred thousand tile totals by one block.
 __global__ void __launch_bounds__(1024)
-sort_scan_kernel(uint32_t* __restrict__ block_hist, int64_t total) {
+scan_totals_kernel(uint32_t* __restrict__ sums, int64_t count) {
   __shared__ uint32_t part[1024];
   const int t = threadIdx.x;
-  const int64_t per = (total + 1023) / 1024;
-  const int64_t lo = t * per, hi = (lo + per < total) ? lo + per : total;
+  const int64_t per = (count + 1023) / 1024;
+  const int64_t lo = t * per, hi = (lo + per < count) ? lo + per : count;
   uint32_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += block_hist[i];
+  for (int64_t i = lo; i < hi; ++i) s += sums[i];
   part[t] = s;
   __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
   for (int off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (t >= off) ? part[t - off] : 0;
+    const uint32_t v = (t >= off) ? part[t - off] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
-  uint32_t run = part[t] - s;  // exclusive prefix of this slice
+  uint32_t run = part[t] - s;
   for (int64_t i = lo; i < hi; ++i) {
-    const uint32_t c = block_hist[i];
-    block_hist[i] = run;
+    const uint32_t c = sums[i];
+    sums[i] = run;
     run += c;
   }
 }
 
 __global__ void __launch_bounds__(RX_BLOCK)
 sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
-                    int shift, const uint32_t* __restrict__ block_off, int n_blocks,
-                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t wave_cnt[SORT_WAVES][SORT_BINS];  // running counters, then wave bases
+                    int shift, int bits, const uint32_t* __restrict__ block_off,
+                    const uint32_t* __restrict__ tile_off, int n_blocks, uint32_t* __restrict__ keys_out,
+                    uint32_t* __restrict__ vals_out) {
+  extern __shared__ uint32_t wave_cnt[];  // [SORT_WAVES][bins]: running counters, then wave bases
+  const int bins = 1 << bits;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < SORT_WAVES * SORT_BINS; i += blockDim.x) (&wave_cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < SORT_WAVES * bins; i += blockDim.x) wave_cnt[i] = 0;
   __syncthreads();
 
+  uint32_t* my_cnt = wave_cnt + wave * bins;
   const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_WAVE_KEYS;
   uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -97,11 +141,14 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     const bool live = i < n;
     key[it] = live ? keys_in[i] : 0xFFFFFFFFu;
     val[it] = live ? vals_in[i] : 0u;
-    const uint32_t d = (key[it] >> shift) & (SORT_BINS - 1);
+  }
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const bool live = (wbase + it * 64 + lane) < n;
+    const uint32_t d = (key[it] >> shift) & (bins - 1);
     // lanes (live ones) holding the same digit
     unsigned long long peers = __ballot(live);
-#pragma unroll
-    for (int bit = 0; bit < SORT_BITS; ++bit) {
+    for (int bit = 0; bit < bits; ++bit) {
       const bool set = (d >> bit) & 1u;
       const unsigned long long m = __ballot(set);
       peers &= set ? m : ~m;
@@ -110,8 +157,8 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
     if (live) {
       const int leader = __ffsll((long long)peers) - 1;
       if (lane == leader) {
-        base = wave_cnt[wave][d];
-        wave_cnt[wave][d] = base + (uint32_t)__popcll(peers);
+        base = my_cnt[d];
+        my_cnt[d] = base + (uint32_t)__popcll(peers);
       }
       base = __shfl(base, leader, 64);
       rank[it] = base + (uint32_t)__popcll(peers & lt_mask);
@@ -121,12 +168,13 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   }
   __syncthreads();
   // per digit: exclusive prefix over the block's waves, plus this block's global start
-  for (int d = threadIdx.x; d < SORT_BINS; d += blockDim.x) {
-    uint32_t run = block_off[(int64_t)d * n_blocks + blockIdx.x];
+  for (int d = threadIdx.x; d < bins; d += blockDim.x) {
+    const int64_t e = (int64_t)d * n_blocks + blockIdx.x;
+    uint32_t run = block_off[e] + tile_off[e / SCAN_TILE];
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
-      const uint32_t c = wave_cnt[w][d];
-      wave_cnt[w][d] = run;
+      const uint32_t c = wave_cnt[w * bins + d];
+      wave_cnt[w * bins + d] = run;
       run += c;
     }
   }
@@ -135,8 +183,8 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = wbase + it * 64 + lane;
     if (i < n) {
-      const uint32_t d = (key[it] >> shift) & (SORT_BINS - 1);
-      const uint32_t dst = wave_cnt[wave][d] + rank[it];
+      const uint32_t d = (key[it] >> shift) & (bins - 1);
+      const uint32_t dst = my_cnt[d] + rank[it];
       keys_out[dst] = key[it];
       vals_out[dst] = val[it];
     }
@@ -144,18 +192,19 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------- run-length compaction
-#define DEDUP_TILE (RX_BLOCK * 8)
+#define DEDUP_ITEMS 2
+#define DEDUP_TILE (RX_BLOCK * DEDUP_ITEMS)
 
 __device__ __forceinline__ bool is_head(const uint32_t* keys, int64_t i) { return i == 0 || keys[i] != keys[i - 1]; }
 
 __global__ void __launch_bounds__(RX_BLOCK)
 dedup_count_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t wsum[RX_BLOCK / 64];
-  const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE;
+  const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE + (int64_t)threadIdx.x * DEDUP_ITEMS;
   uint32_t c = 0;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int64_t i = base + (int64_t)threadIdx.x * 8 + it;
+  for (int it = 0; it < DEDUP_ITEMS; ++it) {
+    const int64_t i = base + it;
     if (i < n && is_head(keys, i)) ++c;
   }
   for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
@@ -164,84 +213,86 @@ dedup_count_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __res
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// block_counts holds the exclusive scan of the per-block head counts on entry
 __global__ void __launch_bounds__(RX_BLOCK)
 dedup_write_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
-                   const uint32_t* __restrict__ block_counts, int n_blocks,
+                   const uint32_t* __restrict__ block_base, int n_blocks,
                    int32_t* __restrict__ sorted_pos, int64_t* __restrict__ uniq_rows,
                    int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq,
-                   int32_t* __restrict__ inverse) {
-  __shared__ uint32_t red[RX_BLOCK];
-  __shared__ uint32_t block_base;
-  // start slot of this block = sum of the counts of all earlier blocks
-  uint32_t s = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += blockDim.x) s += block_counts[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = RX_BLOCK / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) block_base = red[0];
-  __syncthreads();
-  const uint32_t bbase = block_base;
-  __syncthreads();
-
-  const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE + (int64_t)threadIdx.x * 8;
-  bool head[8];
+                   int32_t* __restrict__ inverse, int32_t* __restrict__ sorted_slot) {
+  __shared__ uint32_t lds4[4];
+  const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE + (int64_t)threadIdx.x * DEDUP_ITEMS;
+  bool head[DEDUP_ITEMS];
+  uint32_t k[DEDUP_ITEMS], v[DEDUP_ITEMS];
   uint32_t c = 0;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < DEDUP_ITEMS; ++it) {
     const int64_t i = base + it;
+    k[it] = i < n ? keys[i] : 0u;
+    v[it] = i < n ? vals[i] : 0u;
     head[it] = i < n && is_head(keys, i);
     c += head[it] ? 1u : 0u;
   }
-  // exclusive scan of c over the block (thread order == key order)
-  red[threadIdx.x] = c;
-  __syncthreads();
-  for (int off = 1; off < RX_BLOCK; off <<= 1) {
-    uint32_t v = (threadIdx.x >= off) ? red[threadIdx.x - off] : 0;
-    __syncthreads();
-    red[threadIdx.x] += v;
-    __syncthreads();
-  }
-  uint32_t slot = bbase + red[threadIdx.x] - c;  // slot of this thread's first head
+  uint32_t tile_total;
+  uint32_t slot = block_base[blockIdx.x] + block_exclusive_scan(c, lds4, &tile_total);
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < DEDUP_ITEMS; ++it) {
     const int64_t i = base + it;
     if (i < n) {
       if (head[it]) {
-        uniq_rows[slot] = (int64_t)keys[i];
+        uniq_rows[slot] = (int64_t)k[it];
         seg_off[slot] = (int32_t)i;
         ++slot;
       }
-      sorted_pos[i] = (int32_t)vals[i];
-      if (inverse) inverse[vals[i]] = (int32_t)(slot - 1);
+      sorted_pos[i] = (int32_t)v[it];
+      if (sorted_slot) sorted_slot[i] = (int32_t)(slot - 1);
+      if (inverse) inverse[v[it]] = (int32_t)(slot - 1);
     }
   }
-  if (blockIdx.x == n_blocks - 1 && threadIdx.x == RX_BLOCK - 1) {
-    const uint32_t total = bbase + red[RX_BLOCK - 1];
+  if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) {
+    const uint32_t total = block_base[blockIdx.x] + tile_total;
     n_uniq[0] = (int32_t)total;
     seg_off[total] = (int32_t)n;
   }
 }
 
-// workspace layout: keys A | keys B | vals A | vals B | block hist | dedup block counts
+__global__ void __launch_bounds__(RX_BLOCK)
+add_tile_offsets_kernel(uint32_t* __restrict__ data, int64_t total, const uint32_t* __restrict__ tile_off) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+  const uint32_t off = tile_off[blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (base + e < total) data[base + e] += off;
+}
+
+// Digit width: the fewest passes with digits of at most SORT_MAX_BITS bits, spread evenly.
+static void sort_plan(int64_t n_rows, int* passes, int* bits_per_pass) {
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)n_rows) ++bits;
+  *passes = (bits + SORT_MAX_BITS - 1) / SORT_MAX_BITS;
+  *bits_per_pass = (bits + *passes - 1) / *passes;
+}
+
+// workspace layout: keys A | keys B | vals A | vals B | block hist | tile sums | dedup block counts
 struct SortWs {
-  uint32_t *ka, *kb, *va, *vb, *hist, *counts;
+  uint32_t *ka, *kb, *va, *vb, *hist, *tiles, *counts;
   size_t bytes;
 };
 
 static SortWs sort_ws_layout(void* ws, int64_t n) {
   SortWs w;
-  const size_t n_al = rx_align_up((size_t)(n > 0 ? n : 1) * 4, 256);
-  const int64_t nb = rx_cdiv(n > 0 ? n : 1, SORT_TILE);
-  const int64_t ndb = rx_cdiv(n > 0 ? n : 1, DEDUP_TILE);
+  const int64_t nn = n > 0 ? n : 1;
+  const size_t n_al = rx_align_up((size_t)nn * 4, 256);
+  const int64_t nb = rx_cdiv(nn, SORT_TILE);
+  const int64_t hist_entries = nb * SORT_MAX_BINS;
+  const int64_t ndb = rx_cdiv(nn, DEDUP_TILE);
   char* p = (char*)ws;
   w.ka = (uint32_t*)p; p += n_al;
   w.kb = (uint32_t*)p; p += n_al;
   w.va = (uint32_t*)p; p += n_al;
   w.vb = (uint32_t*)p; p += n_al;
-  w.hist = (uint32_t*)p; p += rx_align_up((size_t)nb * SORT_BINS * 4, 256);
+  w.hist = (uint32_t*)p; p += rx_align_up((size_t)hist_entries * 4, 256);
+  w.tiles = (uint32_t*)p; p += rx_align_up((size_t)(rx_cdiv(hist_entries, SCAN_TILE) + rx_cdiv(ndb, SCAN_TILE) + 2) * 4, 256);
   w.counts = (uint32_t*)p; p += rx_align_up((size_t)ndb * 4, 256);
   w.bytes = (size_t)(p - (char*)ws);
   return w;
@@ -249,10 +300,28 @@ static SortWs sort_ws_layout(void* ws, int64_t n) {
 
 extern "C" size_t rx_sort_dedup_workspace_bytes(int64_t n) { return sort_ws_layout(nullptr, n).bytes; }
 
+// one stable counting pass on `bits` bits starting at `shift`
+static int sort_pass(const SortWs& w, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout,
+                     int64_t n, int shift, int bits, hipStream_t st) {
+  const int nb = (int)rx_cdiv(n, SORT_TILE);
+  const int bins = 1 << bits;
+  const int64_t entries = (int64_t)nb * bins;
+  const int n_tiles = (int)rx_cdiv(entries, SCAN_TILE);
+  hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(RX_BLOCK), bins * sizeof(uint32_t), st, kin, n, shift, bits, w.hist, nb);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.hist, entries, w.tiles);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(RX_BLOCK), SORT_WAVES * bins * sizeof(uint32_t), st, kin, vin, n, shift, bits, w.hist, w.tiles, nb, kout, vout);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
-                             int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
-                             int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag,
-                             int device, void* stream) {
+                             int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off,
+                             int32_t* d_n_uniq, int32_t* d_inverse, void* ws, size_t ws_bytes,
+                             int32_t* err_flag, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && n < (1ll << 31), "rx_sort_dedup: n=%lld outside [0, 2^31)", (long long)n);
   RX_REQUIRE(n_rows >= 1 && n_rows <= (1ll << 32), "rx_sort_dedup: n_rows=%lld outside [1, 2^32]", (long long)n_rows);
@@ -266,29 +335,31 @@ extern "C" int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, in
   RX_REQUIRE(d_idx && d_sorted_pos && d_uniq_rows && ws, "rx_sort_dedup: null argument");
   RX_REQUIRE(ws_bytes >= rx_sort_dedup_workspace_bytes(n), "rx_sort_dedup: workspace %zu < %zu bytes", ws_bytes, rx_sort_dedup_workspace_bytes(n));
   SortWs w = sort_ws_layout(ws, n);
-  int bits = 1;
-  while (bits < 32 && (1ull << bits) < (unsigned long long)n_rows) ++bits;
-  const int passes = (bits + SORT_BITS - 1) / SORT_BITS;
-  const int nb = (int)rx_cdiv(n, SORT_TILE);
+  int passes, bits;
+  sort_plan(n_rows, &passes, &bits);
 
   hipLaunchKernelGGL(sort_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, n_rows, w.ka, w.va, err_flag);
   RX_LAUNCH_CHECK();
   uint32_t *kin = w.ka, *kout = w.kb, *vin = w.va, *vout = w.vb;
   for (int p = 0; p < passes; ++p) {
-    const int shift = p * SORT_BITS;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(RX_BLOCK), 0, st, kin, n, shift, w.hist, nb);
-    RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, w.hist, (int64_t)nb * SORT_BINS);
-    RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(RX_BLOCK), 0, st, kin, vin, n, shift, w.hist, nb, kout, vout);
-    RX_LAUNCH_CHECK();
+    if (sort_pass(w, kin, vin, kout, vout, n, p * bits, bits, st)) return 1;
     uint32_t* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }
   const int ndb = (int)rx_cdiv(n, DEDUP_TILE);
+  const int n_tiles = (int)rx_cdiv(ndb, SCAN_TILE);
   hipLaunchKernelGGL(dedup_count_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, n, w.counts);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dedup_write_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, vin, n, w.counts, ndb, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse);
+  // exclusive scan of the block counts: tiles in place + totals, then fold the totals back in
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
+  RX_LAUNCH_CHECK();
+  if (n_tiles > 1) {
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(add_tile_offsets_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
+    RX_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(dedup_write_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, vin, n, w.counts, ndb, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, d_sorted_slot);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -312,12 +383,15 @@ owner_init_kernel(const int64_t* __restrict__ idx, int64_t n, int G, int64_t n_r
 
 __global__ void __launch_bounds__(RX_BLOCK)
 owner_finish_kernel(const int64_t* __restrict__ idx, const uint32_t* __restrict__ perm_in, int64_t n, int G,
-                    int64_t n_rows_global, const uint32_t* __restrict__ scanned_hist, int n_blocks,
-                    int64_t* __restrict__ counts, int64_t* __restrict__ send_local, int32_t* __restrict__ perm) {
+                    int64_t n_rows_global, const uint32_t* __restrict__ scanned_hist,
+                    const uint32_t* __restrict__ tile_off, int n_blocks, int64_t* __restrict__ counts,
+                    int64_t* __restrict__ send_local, int32_t* __restrict__ perm) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < G) {
-    const int64_t lo = scanned_hist[(int64_t)j * n_blocks];
-    const int64_t hi = (j + 1 < SORT_BINS) ? (int64_t)scanned_hist[(int64_t)(j + 1) * n_blocks] : n;
+    // start of digit d = scanned count entry (d, block 0); bin G exists and is empty
+    const int64_t e0 = j * n_blocks, e1 = (j + 1) * n_blocks;
+    const int64_t lo = (int64_t)scanned_hist[e0] + tile_off[e0 / SCAN_TILE];
+    const int64_t hi = (int64_t)scanned_hist[e1] + tile_off[e1 / SCAN_TILE];
     counts[j] = hi - lo;
   }
   if (j >= n) return;
@@ -338,7 +412,7 @@ extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G,
                                      int64_t* d_counts, int64_t* d_send_local, int32_t* d_perm, void* ws,
                                      size_t ws_bytes, int32_t* err_flag, int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(G >= 1 && G < SORT_BINS, "rx_bucketize_by_owner: G=%d outside 1..%d", G, SORT_BINS - 1);
+  RX_REQUIRE(G >= 1 && G < SORT_MAX_BINS, "rx_bucketize_by_owner: G=%d outside 1..%d", G, SORT_MAX_BINS - 1);
   RX_REQUIRE(n >= 0 && n < (1ll << 31) && n_rows_global >= 1, "rx_bucketize_by_owner: bad sizes");
   RX_REQUIRE(d_counts, "rx_bucketize_by_owner: null counts");
   hipStream_t st = (hipStream_t)stream;
@@ -350,16 +424,13 @@ extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G,
   RX_REQUIRE(ws_bytes >= rx_bucketize_workspace_bytes(n, G), "rx_bucketize_by_owner: workspace too small");
   SortWs w = sort_ws_layout(ws, n);
   const int nb = (int)rx_cdiv(n, SORT_TILE);
+  int bits = 1;
+  while ((1 << bits) < G + 1) ++bits;  // one spare bin so that bin G marks the end of bin G-1
   hipLaunchKernelGGL(owner_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, G, n_rows_global, w.ka, w.va, err_flag);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(RX_BLOCK), 0, st, w.ka, n, 0, w.hist, nb);
-  RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, w.hist, (int64_t)nb * SORT_BINS);
-  RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(RX_BLOCK), 0, st, w.ka, w.va, n, 0, w.hist, nb, w.kb, w.vb);
-  RX_LAUNCH_CHECK();
+  if (sort_pass(w, w.ka, w.va, w.kb, w.vb, n, 0, bits, st)) return 1;
   const int64_t work = n > G ? n : G;
-  hipLaunchKernelGGL(owner_finish_kernel, dim3((unsigned)rx_cdiv(work, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, w.vb, n, G, n_rows_global, w.hist, nb, d_counts, d_send_local, d_perm);
+  hipLaunchKernelGGL(owner_finish_kernel, dim3((unsigned)rx_cdiv(work, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, w.vb, n, G, n_rows_global, w.hist, w.tiles, nb, d_counts, d_send_local, d_perm);
   RX_LAUNCH_CHECK();
   return 0;
 }

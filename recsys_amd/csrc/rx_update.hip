@@ -21,6 +21,7 @@ struct SegArgs {
   int64_t n;
   int dim;
   const int32_t* sorted_pos;
+  const int32_t* sorted_slot;
   const int64_t* uniq_rows;
   const int32_t* seg_off;
   const int32_t* n_uniq;
@@ -32,7 +33,29 @@ struct SegArgs {
   const float* scale;
   float* sq_part;
   int group;
+  // companion scalar table addressed by the same rows (the D=1 bias table of FM / Wide&Deep)
+  const float* occ2;
+  float* target2;
+  float* state2;
+  // cross-piece workspace
+  float* partials;    // [pieces][2][dim]
+  float* partials2;   // [pieces][2]
+  int32_t* tail_row;  // [pieces] slot of the run that leaves the piece to the right, or -1
 };
+
+// Optimizer arithmetic for one scalar (companion table entry).
+__device__ __forceinline__ void apply_scalar(const SegArgs& a, float g, int64_t row, int64_t u, float scale) {
+  if (a.mode == RX_SEG_DENSE) { a.target2[row] = g; return; }
+  if (a.mode == RX_SEG_COMPACT) { a.target2[u] = g; return; }
+  g *= scale;
+  if (a.mode == RX_SEG_SGD) {
+    a.target2[row] = a.target2[row] - a.lr * g;
+  } else {  // Adagrad; row-wise Adagrad of a width-1 row is the same rule
+    const float s = a.state2[row] + g * g;
+    a.state2[row] = s;
+    a.target2[row] = a.target2[row] - a.lr * (g / (sqrtf(s) + a.eps));
+  }
+}
 
 template <int VEC, int CH>
 __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int64_t row, int64_t u, int lg,
@@ -105,24 +128,152 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
   }
 }
 
+// Runs are cut at fixed position boundaries (SEG_CHUNK sorted positions per lane group), so a
+// row hit thousands of times (Zipf heads, tiny fields) costs no more wall time than a cold one:
+//   pass 1  one lane group per piece.  The block first stages its (slot, position) tile in LDS
+//           with one coalesced sweep; each group then walks its 32 positions in order, loading
+//           occurrence rows a batch at a time so several HBM reads are in flight.  A run that
+//           lies entirely inside the piece is finished and applied on the spot; a run that
+//           crosses a piece boundary leaves a partial sum in partials[piece][0 = entered from the
+//           left | 1 = leaves to the right], and the piece records the run that leaves it.
+//   pass 2  one wavefront per piece whose tail run continues: its 64/group lane slots add the
+//           run's partials (stride = slots, piece order inside a slot), a fixed xor tree joins
+//           the slots, and slot 0 applies the row.
+// The order of additions depends only on the sort, so results are bitwise reproducible.
+#define SEG_CHUNK 32
+
+template <int VEC, int CH>
+__device__ __forceinline__ float acc_sq(const Acc<VEC, CH>& g, int lg, int group, int dim) {
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = (lg + k * group) * VEC;
+    if (c < dim) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) sq += g.p[k].v[i] * g.p[k].v[i];
+    }
+  }
+  return sq;
+}
+
+__device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* sq_lds) {
+  sq = rx_wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) sq_lds[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) sq_part[blockIdx.x] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
+}
+
 template <int VEC, int CH>
 __global__ void __launch_bounds__(RX_BLOCK)
-segreduce_kernel(SegArgs a) {
-  __shared__ float sq_lds[RX_BLOCK];
+segreduce_chunk_kernel(SegArgs a) {
+  extern __shared__ int2 meta[];  // [groups per block][SEG_CHUNK] = (slot, position); slot -1 past the end
+  __shared__ float sq_lds[RX_BLOCK / 64];
+  constexpr int BATCH = 8 / CH;
   const int group = a.group, dim = a.dim;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t u = gid / group;
-  const int lg = (int)(gid % group);
-  const int64_t nu = a.n_uniq[0];
-  const bool live = u < nu;
+  const int gpb = RX_BLOCK / group;
+  const int64_t piece0 = (int64_t)blockIdx.x * gpb;
+  {
+    const int64_t base = piece0 * SEG_CHUNK;
+    for (int j = threadIdx.x; j < gpb * SEG_CHUNK; j += RX_BLOCK) {
+      const int64_t p = base + j;
+      meta[j] = (p < a.n) ? make_int2(a.sorted_slot[p], a.sorted_pos[p]) : make_int2(-1, 0);
+    }
+  }
+  __syncthreads();
+  const int my = threadIdx.x / group;
+  const int lg = threadIdx.x % group;
+  const int64_t piece = piece0 + my;
+  const int64_t lo = piece * SEG_CHUNK;
   float sq = 0.f;
-  if (live) {
-    const int64_t row = a.uniq_rows[u];
-    const int lo = a.seg_off[u], hi = a.seg_off[u + 1];
+  if (lo < a.n) {
+    const int64_t hi = (lo + SEG_CHUNK < a.n) ? lo + SEG_CHUNK : a.n;
+    const float scale = a.scale ? a.scale[0] : 1.f;
+    const int2* mine = meta + my * SEG_CHUNK;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
-    for (int p = lo; p < hi; ++p) {
-      const float* src = a.occ + (int64_t)a.sorted_pos[p] * a.occ_ld;
+    float g2 = 0.f;
+    int cur = mine[0].x;
+    int tail = -1;
+    auto flush = [&](int u) {
+      const int64_t run_lo = a.seg_off[u], run_hi = a.seg_off[u + 1];
+      if (run_lo >= lo && run_hi <= hi) {
+        const int64_t row = a.uniq_rows[u];
+        if (a.sq_part) {
+          sq += acc_sq<VEC, CH>(g, lg, group, dim);
+          if (a.occ2 && lg == 0) sq += g2 * g2;
+        }
+        if (row >= 0 && row < a.n_rows) {
+          if (a.occ2 && lg == 0) apply_scalar(a, g2, row, u, scale);
+          apply_row<VEC, CH>(a, g, row, u, lg, scale);
+        }
+      } else {
+        const int side = run_lo < lo ? 0 : 1;
+        float* dst = a.partials + (piece * 2 + side) * (int64_t)dim;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = (lg + k * group) * VEC;
+          if (c < dim) rx_store<VEC>(dst + c, g.p[k]);
+        }
+        if (a.occ2 && lg == 0) a.partials2[piece * 2 + side] = g2;
+        if (side == 1) tail = u;
+      }
+      ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
+      g2 = 0.f;
+    };
+#pragma unroll 1
+    for (int b0 = 0; b0 < SEG_CHUNK; b0 += BATCH) {
+      int sl[BATCH];
+      Acc<VEC, CH> rows[BATCH];
+      float s2[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const int2 m = mine[b0 + j];
+        sl[j] = m.x;
+        const float* src = a.occ + (int64_t)m.y * a.occ_ld;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = (lg + k * group) * VEC;
+          rows[j].p[k] = (m.x >= 0 && c < dim) ? rx_load<VEC>(src + c) : rx_zero<VEC>();
+        }
+        s2[j] = (a.occ2 && lg == 0 && m.x >= 0) ? a.occ2[m.y] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        if (sl[j] != cur) {
+          if (cur >= 0) flush(cur);
+          cur = sl[j];
+        }
+        ACC_FOREACH(k, i) g.p[k].v[i] += rows[j].p[k].v[i];
+        g2 += s2[j];
+      }
+    }
+    if (cur >= 0) flush(cur);
+    if (lg == 0) a.tail_row[piece] = tail;
+  }
+  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
+}
+
+template <int VEC, int CH>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
+  __shared__ float sq_lds[RX_BLOCK / 64];
+  const int group = a.group, dim = a.dim;
+  const int lane = threadIdx.x & 63;
+  const int64_t piece = (int64_t)blockIdx.x * (RX_BLOCK / 64) + (threadIdx.x >> 6);
+  float sq = 0.f;
+  const int u = piece < n_pieces ? a.tail_row[piece] : -1;  // wave-uniform
+  if (u >= 0) {
+    const int64_t run_hi = a.seg_off[u + 1];
+    const int64_t last = (run_hi - 1) / SEG_CHUNK;
+    const int n_parts = (int)(last - piece) + 1;
+    const int slots = 64 / group;
+    const int s = lane / group, lg = lane % group;
+    Acc<VEC, CH> g;
+    ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
+    float g2 = 0.f;
+    for (int q = s; q < n_parts; q += slots) {
+      const int64_t e = (piece + q) * 2 + (q == 0 ? 1 : 0);
+      const float* src = a.partials + e * (int64_t)dim;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int c = (lg + k * group) * VEC;
@@ -132,35 +283,30 @@ segreduce_kernel(SegArgs a) {
           for (int i = 0; i < VEC; ++i) g.p[k].v[i] += x.v[i];
         }
       }
+      if (a.occ2 && lg == 0) g2 += a.partials2[e];
     }
-    if (a.sq_part) {
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int c = (lg + k * group) * VEC;
-        if (c < dim) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) sq += g.p[k].v[i] * g.p[k].v[i];
-        }
+    for (int m = group; m < 64; m <<= 1) {
+      ACC_FOREACH(k, i) g.p[k].v[i] += __shfl_xor(g.p[k].v[i], m, 64);
+      g2 += __shfl_xor(g2, m, 64);
+    }
+    if (s == 0) {
+      const int64_t row = a.uniq_rows[u];
+      if (a.sq_part) {
+        sq = acc_sq<VEC, CH>(g, lg, group, dim);
+        if (a.occ2 && lg == 0) sq += g2 * g2;
+      }
+      if (row >= 0 && row < a.n_rows) {
+        const float scale = a.scale ? a.scale[0] : 1.f;
+        if (a.occ2 && lg == 0) apply_scalar(a, g2, row, u, scale);
+        apply_row<VEC, CH>(a, g, row, u, lg, scale);
       }
     }
-    if (row >= 0 && row < a.n_rows) {
-      const float scale = a.scale ? a.scale[0] : 1.f;
-      apply_row<VEC, CH>(a, g, row, u, lg, scale);
-    }
   }
-  if (a.sq_part) {
-    sq_lds[threadIdx.x] = sq;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = 0.f;
-      for (int t = 0; t < RX_BLOCK; ++t) s += sq_lds[t];
-      a.sq_part[blockIdx.x] = s;
-    }
-  }
+  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
 }
 
 // 16-byte accesses need 16-byte aligned rows; widths that are not a multiple of 4 use
-// scalar lanes.  The launch grid is a pure function of (n, dim): rx_segreduce_grid().
+// scalar lanes.  Launch grids are pure functions of (n, dim).
 static int seg_shape(int dim, int64_t occ_ld, const void* occ, const void* target, const void* state,
                      RxRowShape* sh, const char* who) {
   *sh = rx_row_shape(dim);
@@ -169,23 +315,40 @@ static int seg_shape(int dim, int64_t occ_ld, const void* occ, const void* targe
                "%s: dim %d is a multiple of 4, so buffers must be 16-byte aligned and the row stride a multiple of 4", who, dim);
   }
   if (sh->chunks == 3) sh->chunks = 4;
+  if (sh->group < 2) sh->group = 2;  // keeps the LDS index tile of pass 1 at <= 32 KiB
   RX_REQUIRE(sh->chunks <= 4, "%s: dim %d unsupported (above 256 it must be a multiple of 4)", who, dim);
   return 0;
 }
 
-extern "C" int64_t rx_segreduce_grid(int64_t n, int32_t dim) {
-  if (n <= 0 || dim < 1 || dim > RX_MAX_DIM) return 0;
-  return rx_cdiv(n * rx_row_shape(dim).group, RX_BLOCK);
+static int seg_group(int dim) {
+  const int g = rx_row_shape(dim).group;
+  return g < 2 ? 2 : g;
 }
 
-#define SEG_DISPATCH(sh, KERNEL, grid, st, args)                                                   \
+static int64_t seg_pieces(int64_t n) { return rx_cdiv(n, SEG_CHUNK); }
+static int64_t seg_grid1(int64_t n, int dim) { return rx_cdiv(seg_pieces(n) * seg_group(dim), RX_BLOCK); }
+static int64_t seg_grid2(int64_t n) { return rx_cdiv(seg_pieces(n), RX_BLOCK / 64); }
+
+extern "C" int64_t rx_segreduce_grid(int64_t n, int32_t dim) {
+  if (n <= 0 || dim < 1 || dim > RX_MAX_DIM) return 0;
+  return seg_grid1(n, dim) + seg_grid2(n);
+}
+
+extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
+  if (n <= 0 || dim < 1) return 256;
+  const size_t pieces = (size_t)seg_pieces(n);
+  return rx_align_up(pieces * 2 * dim * sizeof(float), 256) + rx_align_up(pieces * 2 * sizeof(float), 256) +
+         rx_align_up(pieces * sizeof(int32_t), 256);
+}
+
+#define SEG_DISPATCH(sh, KERNEL, grid, lds, st, ...)                                               \
   do {                                                                                             \
-    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(RX_BLOCK), 0, st, args); \
-    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(RX_BLOCK), 0, st, args); \
-    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(RX_BLOCK), 0, st, args); \
-    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(RX_BLOCK), 0, st, args); \
-    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(RX_BLOCK), 0, st, args); \
-    else hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(RX_BLOCK), 0, st, args);                  \
+    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__);          \
   } while (0)
 
 static int mode_check(int mode, const float* state, const char* who, bool allow_grad_modes) {
@@ -195,22 +358,38 @@ static int mode_check(int mode, const float* state, const char* who, bool allow_
 }
 
 extern "C" int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
-                            const int32_t* d_sorted_pos, const int64_t* d_uniq_rows,
-                            const int32_t* d_seg_off, const int32_t* d_n_uniq, int mode,
-                            float* d_target, float* d_state, int64_t n_rows, float lr, float eps,
-                            const float* d_scale, float* d_sq_part, int device, void* stream) {
+                            const int32_t* d_sorted_pos, const int32_t* d_sorted_slot,
+                            const int64_t* d_uniq_rows, const int32_t* d_seg_off,
+                            const int32_t* d_n_uniq, int mode, float* d_target, float* d_state,
+                            const float* d_occ2, float* d_target2, float* d_state2, int64_t n_rows,
+                            float lr, float eps, const float* d_scale, float* d_sq_part, void* ws,
+                            size_t ws_bytes, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && dim >= 1 && dim <= RX_MAX_DIM && occ_ld >= dim, "rx_segreduce: bad shape n=%lld dim=%d ld=%lld", (long long)n, dim, (long long)occ_ld);
   if (mode_check(mode, d_state, "rx_segreduce", true)) return 1;
+  RX_REQUIRE((d_occ2 == nullptr) == (d_target2 == nullptr), "rx_segreduce: companion gradient and target come as a pair");
+  RX_REQUIRE(!d_occ2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || d_state2, "rx_segreduce: companion Adagrad state missing");
   if (n == 0) return 0;
-  RX_REQUIRE(d_occ && d_sorted_pos && d_uniq_rows && d_seg_off && d_n_uniq && d_target, "rx_segreduce: null argument");
+  RX_REQUIRE(d_occ && d_sorted_pos && d_sorted_slot && d_uniq_rows && d_seg_off && d_n_uniq && d_target && ws, "rx_segreduce: null argument");
   RX_REQUIRE(n_rows >= 1, "rx_segreduce: n_rows must be positive");
+  RX_REQUIRE(ws_bytes >= rx_segreduce_workspace_bytes(n, dim) && rx_aligned16(ws), "rx_segreduce: workspace too small or unaligned");
   RxRowShape sh;
   if (seg_shape(dim, occ_ld, d_occ, d_target, mode == RX_SEG_ADAGRAD ? d_state : nullptr, &sh, "rx_segreduce")) return 1;
-  SegArgs a{d_occ, occ_ld, n, dim, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, mode, d_target, d_state, n_rows, lr, eps, d_scale, d_sq_part, sh.group};
-  // the grid always matches rx_segreduce_grid() so that d_sq_part has one slot per block
-  const unsigned grid = (unsigned)rx_segreduce_grid(n, dim);
-  SEG_DISPATCH(sh, segreduce_kernel, dim3(grid), (hipStream_t)stream, a);
+  const size_t pieces = (size_t)seg_pieces(n);
+  char* w = (char*)ws;
+  float* partials = (float*)w; w += rx_align_up(pieces * 2 * dim * sizeof(float), 256);
+  float* partials2 = (float*)w; w += rx_align_up(pieces * 2 * sizeof(float), 256);
+  int32_t* tail_row = (int32_t*)w;
+  SegArgs a{d_occ, occ_ld, n, dim, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, mode, d_target,
+            d_state, n_rows, lr, eps, d_scale, d_sq_part, sh.group, d_occ2, d_target2, d_state2, partials,
+            partials2, tail_row};
+  const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n);
+  const size_t lds = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK * sizeof(int2);
+  hipStream_t st = (hipStream_t)stream;
+  SEG_DISPATCH(sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
+  RX_LAUNCH_CHECK();
+  if (d_sq_part) a.sq_part = d_sq_part + g1;
+  SEG_DISPATCH(sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -246,9 +425,10 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   RX_REQUIRE(d_compact && d_uniq_rows && d_n_uniq && d_w && n_rows >= 1, "rx_row_update: null argument");
   RxRowShape sh;
   if (seg_shape(dim, dim, d_compact, d_w, mode == RX_SEG_ADAGRAD ? d_state : nullptr, &sh, "rx_row_update")) return 1;
-  SegArgs a{d_compact, dim, n_max, dim, nullptr, d_uniq_rows, nullptr, d_n_uniq, mode, d_w, d_state, n_rows, lr, eps, d_scale, nullptr, sh.group};
+  SegArgs a{d_compact, dim, n_max, dim, nullptr, nullptr, d_uniq_rows, nullptr, d_n_uniq, mode, d_w, d_state,
+            n_rows, lr, eps, d_scale, nullptr, sh.group, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
-  SEG_DISPATCH(sh, row_update_kernel, dim3(grid), (hipStream_t)stream, a);
+  SEG_DISPATCH(sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,134 @@
+"""Multi-field models over Criteo-shaped inputs: 26 sparse fields sharing one row-offset table
+(+ 13 dense features for the deep parts).  They have no counterpart in the reference; they
+generalise its 4-field FactorizationMachine / DeepFactorizationMachine
+(recsys/models/matrix_factorization/factorization_machine.py,
+recsys/models/neuralcf/deep_factorization_machine.py) and add a DCN-v2 cross network.
+
+Batch dict: ``sparse`` int64 [B, n_fields] (index inside each field), ``dense`` fp32
+[B, n_dense], ``label`` [B, 1].  The last sparse field plays the reference's "item" role with
+N = 1, so the same rx_fm2 kernels serve both shapes.  Tower input column order:
+[last field, field 0 .. field n-2, dense].
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+from torch import nn
+
+from .. import autograd as rxa
+from .base import HotPathModule, as_index, run_tower
+
+
+class _FieldTable(HotPathModule):
+    def _init_fields(self, field_dims: Sequence[int], embedding_dim: int):
+        self.field_dims = [int(x) for x in field_dims]
+        self.n_fields = len(self.field_dims)
+        self.embedding_dim = embedding_dim
+        self.n_features = sum(self.field_dims)
+        offs = [0]
+        for d in self.field_dims[:-1]:
+            offs.append(offs[-1] + d)
+        self._offsets = offs
+
+    def _split(self, inputs):
+        sparse = as_index(inputs["sparse"], "sparse")
+        if sparse.dim() != 2 or sparse.shape[1] != self.n_fields:
+            raise ValueError(f"sparse: expected [B, {self.n_fields}], got {tuple(sparse.shape)}")
+        base = getattr(self, "_ex_base", None)
+        if base is None or base.device != sparse.device:
+            base = torch.tensor(self._offsets[:-1], dtype=torch.int64, device=sparse.device)
+            self._ex_base = base
+        F = self.n_fields - 1
+        return sparse[:, :F], base, sparse[:, F:], self._offsets[-1]
+
+
+class FieldFM(_FieldTable):
+    """logit = sum_f bias[f] + 0.5 * sum_d[(sum_f e_f)^2 - sum_f e_f^2]."""
+    _sparse_names = ["feature_embedding.weight", "bias_embedding.weight"]
+
+    def __init__(self, field_dims, embedding_dim):
+        super().__init__()
+        self._init_fields(field_dims, embedding_dim)
+        self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
+        self.bias_embedding = nn.Embedding(self.n_features, 1)
+
+    def forward(self, inputs):
+        ex, base, item, item_base = self._split(inputs)
+        logits, _ = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
+                                  self.bias_embedding.weight, False, True)
+        return logits
+
+
+def _bn_stack(input_dim, hidden_dims, dropout):
+    layers = []
+    for width in hidden_dims:
+        layers.extend([nn.Linear(input_dim, width), nn.BatchNorm1d(width), nn.ReLU(), nn.Dropout(p=dropout)])
+        input_dim = width
+    layers.append(nn.Linear(input_dim, 1))
+    return nn.Sequential(*layers)
+
+
+class FieldDeepFM(_FieldTable):
+    """FieldFM + the reference's BatchNorm tower over [embeddings, dense]; hidden widths follow the
+    reference rule [in, in/2, in/4] (deep_factorization_machine.py:47-51)."""
+    _sparse_names = ["feature_embedding.weight", "bias_embedding.weight"]
+
+    def __init__(self, field_dims, embedding_dim, n_dense=13, dropout=0.1):
+        super().__init__()
+        self._init_fields(field_dims, embedding_dim)
+        self.n_dense = n_dense
+        self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
+        self.bias_embedding = nn.Embedding(self.n_features, 1)
+        d_in = self.n_fields * embedding_dim + n_dense
+        self.deep_mlp = _bn_stack(d_in, [d_in, d_in // 2, d_in // 4], dropout)
+
+    def forward(self, inputs):
+        ex, base, item, item_base = self._split(inputs)
+        d_emb = self.n_fields * self.embedding_dim
+        fm, x = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
+                              self.bias_embedding.weight, True, True, d_emb + self.n_dense, True,
+                              _dense_input(inputs, self.n_dense, ex.shape[0]))
+        return fm + run_tower(self.deep_mlp, x)
+
+
+def _dense_input(inputs, n_dense, rows):
+    if not n_dense:
+        return None
+    dense = inputs["dense"]
+    if dense.dtype != torch.float32 or tuple(dense.shape) != (rows, n_dense):
+        raise ValueError(f"dense: expected fp32 [{rows}, {n_dense}]")
+    return dense
+
+
+class DCNv2(_FieldTable):
+    """x0 = [26 embeddings, dense]; ``n_cross`` layers x_{l+1} = x0 * (W_l x_l + b_l) + x_l; then
+    MLP (1024, 512, 256) with ReLU and a final Linear(., 1).  GEMM operands are rounded to bf16 for
+    the matrix cores (fp32 accumulation, fp32 master weights) when ``bf16`` is set."""
+    _sparse_names = ["feature_embedding.weight"]
+
+    def __init__(self, field_dims, embedding_dim, n_dense=13, n_cross=3, mlp_dims=(1024, 512, 256), bf16=True):
+        super().__init__()
+        self._init_fields(field_dims, embedding_dim)
+        self.n_dense, self.bf16 = n_dense, bf16
+        self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
+        d = self.n_fields * embedding_dim + n_dense
+        self.input_dim = d
+        self.cross = nn.ModuleList([nn.Linear(d, d) for _ in range(n_cross)])
+        layers, i = [], d
+        for w in mlp_dims:
+            layers.extend([nn.Linear(i, w), nn.ReLU()])
+            i = w
+        layers.append(nn.Linear(i, 1))
+        self.mlp = nn.Sequential(*layers)
+        nn.init.normal_(self.feature_embedding.weight, std=0.05)
+
+    def forward(self, inputs):
+        ex, base, item, item_base = self._split(inputs)
+        d_emb = self.n_fields * self.embedding_dim
+        _, x0 = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight, None, True, False,
+                              d_emb + self.n_dense, False, _dense_input(inputs, self.n_dense, ex.shape[0]))
+        x = x0
+        for layer in self.cross:
+            x = rxa.CrossLayer.apply(x0, x, layer.weight, layer.bias, self.bf16)
+        return run_tower(self.mlp, x, bf16=self.bf16)

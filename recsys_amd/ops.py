@@ -267,20 +267,36 @@ def gmf_mul_bwd(dout: Tensor, U, V, users, items, col: int = 0):
 
 
 # ------------------------------------------------------------------ FM second order
-def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True):
+def _idx_matrix(t: Tensor, name: str):
+    """int64 [B, C] (or [B]) index matrix with unit inner stride; returns (tensor, cols, row stride).
+    A column block of a wider matrix (e.g. ``sparse[:, :25]``) is accepted as is."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU, got device {t.device}")
+    if t.dtype != torch.int64:
+        raise TypeError(f"{name}: expected int64 indices, got {t.dtype}")
+    if t.dim() == 1:
+        return t, 1, (t.stride(0) if t.shape[0] > 1 else 1)
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected [B] or [B, C], got {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: inner stride must be 1")
+    ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    return t, t.shape[1], max(ld, t.shape[1])
+
+
+def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True,
+             deep_ld: Optional[int] = None):
     _table(feat, "feature table")
-    _idx(ex_idx, "ex_idx"); _idx(ex_base, "ex_base"); _idx(item_idx, "item_idx")
+    _idx(ex_base, "ex_base")
+    ex_idx, F, ex_ld = _idx_matrix(ex_idx, "ex_idx")
+    item_idx, N, item_ld = _idx_matrix(item_idx, "item_idx")
     if ex_idx.dim() != 2:
         raise ValueError(f"ex_idx: expected [B, F], got {tuple(ex_idx.shape)}")
-    B, F = ex_idx.shape
+    B = ex_idx.shape[0]
     if ex_base.numel() != F:
         raise ValueError("ex_base: one offset per field expected")
-    if item_idx.dim() == 1:
-        N = 1
-    elif item_idx.dim() == 2:
-        N = item_idx.shape[1]
-    else:
-        raise ValueError("item_idx: expected [B] or [B, N]")
     if item_idx.shape[0] != B:
         raise ValueError("ex_idx and item_idx disagree on the batch size")
     if bias is not None:
@@ -288,18 +304,37 @@ def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order
         if bias.numel() != feat.shape[0]:
             raise ValueError("bias table: one entry per feature row expected")
     _same_device(feat, bias, ex_idx, ex_base, item_idx)
+    dim = feat.shape[1]
+    if deep_ld is None:
+        deep_ld = (1 + F) * dim
     a = FMArgs(feat.data_ptr(), 0 if bias is None else bias.data_ptr(), feat.shape[0], ex_idx.data_ptr(),
-               ex_base.data_ptr(), item_idx.data_ptr(), item_base, B, F, N, feat.shape[1],
+               ex_base.data_ptr(), item_idx.data_ptr(), item_base, ex_ld, item_ld, deep_ld, B, F, N, dim,
                0 if second_order else _lib.RX_FM_NO_SECOND_ORDER)
     return a, B, F, N
 
 
 def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base: int, want_deep: bool = False,
-            second_order: bool = True):
-    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order)
+            second_order: bool = True, deep_cols: Optional[int] = None, want_logits: bool = True,
+            extra: Optional[Tensor] = None):
+    """``deep_cols`` > (1+F)*dim allocates a wider tower-input buffer whose spare columns receive
+    ``extra`` (dense features, fp32 [B*N, deep_cols - (1+F)*dim]); the buffer's row stride is
+    rounded up to a multiple of 4 floats."""
     dim = feat.shape[1]
-    logits = torch.empty(B, N, dtype=torch.float32, device=feat.device)
-    deep = torch.empty(B * N, (1 + F) * dim, dtype=torch.float32, device=feat.device) if want_deep else None
+    F = ex_idx.shape[1]
+    deep_ld = None
+    if want_deep:
+        cols = max(deep_cols or 0, (1 + F) * dim)
+        deep_ld = (cols + 3) // 4 * 4
+    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order, deep_ld)
+    logits = torch.empty(B, N, dtype=torch.float32, device=feat.device) if want_logits else None
+    deep = None
+    if want_deep:
+        buf = torch.empty(B * N, deep_ld, dtype=torch.float32, device=feat.device)
+        deep = buf[:, :cols] if cols != deep_ld else buf
+        if cols > (1 + F) * dim:
+            if extra is None or tuple(extra.shape) != (B * N, cols - (1 + F) * dim) or extra.dtype != torch.float32:
+                raise ValueError("extra: expected fp32 [B*N, deep_cols - (1+F)*dim]")
+            buf[:, (1 + F) * dim:cols].copy_(extra)
     check(lib.rx_fm2_fwd(C.byref(a), _p(logits), _p(deep), _p(_err_flag(feat.device)), _dev(feat), _stream(feat)),
           "rx_fm2_fwd")
     _after_index_op(feat.device)
@@ -307,16 +342,26 @@ def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base: int, want_deep: bo
 
 
 def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True):
-    """Returns (occ [(B*F+B*N), D], bias_occ [(B*F+B*N)] or None)."""
-    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order)
+    """Returns (occ [(B*F+B*N), D], bias_occ [(B*F+B*N)] or None).  ``d_deep`` may be a column
+    block (unit inner stride) of a wider gradient matrix."""
+    deep_ld = None
+    if d_deep is not None:
+        d_deep, deep_ld = _mat(d_deep, "grad_deep")
+        if feat.shape[1] % 4 == 0 and (deep_ld % 4 != 0 or d_deep.data_ptr() % 16 != 0):
+            # 16-byte row accesses need an aligned row stride: re-home the gradient once
+            padded = torch.empty(d_deep.shape[0], (d_deep.shape[1] + 3) // 4 * 4, dtype=torch.float32,
+                                 device=d_deep.device)
+            padded[:, :d_deep.shape[1]].copy_(d_deep)
+            d_deep, deep_ld = padded, padded.shape[1]
+    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base, second_order, deep_ld)
+    dim, dev = feat.shape[1], feat.device
+    if g is None:
+        g = torch.zeros(B * N, dtype=torch.float32, device=dev)
     _req(g, torch.float32, "grad_logits")
     if g.numel() != B * N:
         raise ValueError("grad_logits: wrong number of elements")
-    dim, dev = feat.shape[1], feat.device
-    if d_deep is not None:
-        _req(d_deep, torch.float32, "grad_deep", 2)
-        if tuple(d_deep.shape) != (B * N, (1 + F) * dim):
-            raise ValueError("grad_deep: wrong shape")
+    if d_deep is not None and (d_deep.shape[0] != B * N or d_deep.shape[1] < (1 + F) * dim):
+        raise ValueError("grad_deep: wrong shape")
     n = B * (F + N)
     occ = torch.empty(n, dim, dtype=torch.float32, device=dev)
     bias_occ = torch.empty(n, dtype=torch.float32, device=dev) if bias is not None else None
@@ -359,6 +404,7 @@ class SortedIndex:
     n: int
     n_rows: int
     sorted_pos: Tensor   # int32 [n]
+    sorted_slot: Tensor  # int32 [n]  index into uniq_rows per sorted position
     uniq_rows: Tensor    # int64 [n]  (first n_uniq valid)
     seg_off: Tensor      # int32 [n+1]
     n_uniq: Tensor       # int32 [1]
@@ -370,21 +416,29 @@ def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False) -> SortedIn
     flat = idx.reshape(-1)
     n, dev = flat.numel(), idx.device
     sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    sorted_slot = torch.empty(n, dtype=torch.int32, device=dev)
     uniq = torch.empty(n, dtype=torch.int64, device=dev)
     seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
     nu = torch.empty(1, dtype=torch.int32, device=dev)
     inv = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
     ws = _ws(int(lib.rx_sort_dedup_workspace_bytes(n)), dev)
-    check(lib.rx_sort_dedup(_p(flat), n, n_rows, _p(sorted_pos), _p(uniq), _p(seg), _p(nu), _p(inv), _p(ws),
-                            ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)), "rx_sort_dedup")
-    return SortedIndex(n, n_rows, sorted_pos, uniq, seg, nu, inv)
+    check(lib.rx_sort_dedup(_p(flat), n, n_rows, _p(sorted_pos), _p(sorted_slot), _p(uniq), _p(seg), _p(nu),
+                            _p(inv), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)), "rx_sort_dedup")
+    return SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
 
 
 def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state: Optional[Tensor] = None,
               lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None,
-              want_sq: bool = False, occ_ld: Optional[int] = None, dim: Optional[int] = None) -> Optional[Tensor]:
+              want_sq: bool = False, occ_ld: Optional[int] = None, dim: Optional[int] = None,
+              occ2: Optional[Tensor] = None, target2: Optional[Tensor] = None,
+              state2: Optional[Tensor] = None) -> Optional[Tensor]:
     """Run rx_segreduce.  ``occ`` is [n, dim] (or 1-D for dim == 1); ``target`` the table / dense
-    gradient / compact buffer.  Returns the per-block sum-of-squares partials when asked."""
+    gradient / compact buffer.  ``occ2`` / ``target2`` / ``state2``: companion scalar table on the
+    same rows.  Returns the per-block sum-of-squares partials when asked."""
+    if occ2 is not None:
+        _req(occ2, torch.float32, "companion gradients"); _req(target2, torch.float32, "companion target")
+        if occ2.numel() < si.n:
+            raise ValueError("companion gradients: too few elements")
     _req(occ, torch.float32, "occurrence gradients")
     _req(target, torch.float32, "target")
     if dim is None:
@@ -396,9 +450,11 @@ def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state:
     sq = None
     if want_sq:
         sq = torch.empty(max(int(lib.rx_segreduce_grid(si.n, dim)), 1), dtype=torch.float32, device=occ.device)
-    check(lib.rx_segreduce(_p(occ), occ_ld, si.n, dim, _p(si.sorted_pos), _p(si.uniq_rows), _p(si.seg_off),
-                           _p(si.n_uniq), mode, _p(target), _p(state), si.n_rows, lr, eps, _p(scale), _p(sq),
-                           _dev(occ), _stream(occ)), "rx_segreduce")
+    ws = _ws(int(lib.rx_segreduce_workspace_bytes(si.n, dim)), occ.device)
+    check(lib.rx_segreduce(_p(occ), occ_ld, si.n, dim, _p(si.sorted_pos), _p(si.sorted_slot), _p(si.uniq_rows),
+                           _p(si.seg_off), _p(si.n_uniq), mode, _p(target), _p(state), _p(occ2), _p(target2),
+                           _p(state2), si.n_rows, lr, eps, _p(scale), _p(sq), _p(ws), ws.numel(), _dev(occ),
+                           _stream(occ)), "rx_segreduce")
     return sq
 
 
@@ -488,7 +544,10 @@ def linear_bwd_x(dy: Tensor, w: Tensor, bf16: bool = False, out: Optional[Tensor
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
-        out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+        # rows padded to a multiple of 4 floats so that consumers can use 16-byte accesses
+        kp = (K + 3) // 4 * 4
+        buf = torch.empty(M, kp, dtype=torch.float32, device=dy.device)
+        out = buf if kp == K else buf[:, :K]
     out, ldx = _mat(out, "dx")
     check(lib.rx_linear_bwd_x(_p(dy), ldd, _p(w), _p(out), ldx, M, N, K, int(accumulate), int(bf16), _dev(dy),
                               _stream(dy)), "rx_linear_bwd_x")
@@ -515,18 +574,33 @@ def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
     return dz
 
 
+def _padded(rows: int, cols: int, device) -> Tensor:
+    """fp32 [rows, cols] whose row stride is a multiple of 4 floats."""
+    cp = (cols + 3) // 4 * 4
+    buf = torch.empty(rows, cp, dtype=torch.float32, device=device)
+    return buf if cp == cols else buf[:, :cols]
+
+
 def cross_combine_fwd(x0, u, xl):
-    xn = torch.empty_like(x0)
-    check(lib.rx_cross_combine_fwd(_p(x0), _p(u), _p(xl), _p(xn), x0.numel(), _dev(x0), _stream(x0)),
-          "rx_cross_combine_fwd")
+    x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u"); xl, ldl = _mat(xl, "xl")
+    rows, cols = x0.shape
+    xn = _padded(rows, cols, x0.device)
+    xn, ldn = _mat(xn, "xn")
+    check(lib.rx_cross_combine_fwd(_p(x0), ld0, _p(u), ldu, _p(xl), ldl, _p(xn), ldn, rows, cols, _dev(x0),
+                                   _stream(x0)), "rx_cross_combine_fwd")
     return xn
 
 
 def cross_combine_bwd(dxn, x0, u, dx0_acc):
-    du = torch.empty_like(dxn)
-    dxl = torch.empty_like(dxn)
-    check(lib.rx_cross_combine_bwd(_p(dxn), _p(x0), _p(u), _p(du), _p(dx0_acc), _p(dxl), dxn.numel(), _dev(dxn),
-                                   _stream(dxn)), "rx_cross_combine_bwd")
+    dxn, ldd = _mat(dxn, "dxn"); x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u")
+    dx0_acc, ldx0 = _mat(dx0_acc, "dx0")
+    rows, cols = dxn.shape
+    du = _padded(rows, cols, dxn.device)
+    dxl = _padded(rows, cols, dxn.device)
+    _, lddu = _mat(du, "du")
+    _, ldxl = _mat(dxl, "dxl")
+    check(lib.rx_cross_combine_bwd(_p(dxn), ldd, _p(x0), ld0, _p(u), ldu, _p(du), lddu, _p(dx0_acc), ldx0,
+                                   _p(dxl), ldxl, rows, cols, _dev(dxn), _stream(dxn)), "rx_cross_combine_bwd")
     return du, dxl
 
 

@@ -38,16 +38,26 @@ class SparseRule:
             self.state = torch.zeros(shape, dtype=torch.float32, device=param.device)
         return self.state
 
-    def apply(self, param, occ, si, dim=None, occ_ld=None):
+    def apply(self, param, occ, si, dim=None, occ_ld=None, param2=None, occ2=None):
         table = param.data
         state = self._state_for(param)
+        rule2 = getattr(param2, "_rx_sparse", None) if param2 is not None else None
+        if param2 is not None and rule2 is None:
+            raise RuntimeError("companion table must carry a sparse rule when its main table does")
+        table2 = param2.data if param2 is not None else None
+        state2 = rule2._state_for(param2) if rule2 is not None else None
         if self.owner.clip_norm is None:
-            ops.segreduce(occ, si, self.mode, table, state=state, lr=self.lr, eps=self.eps, dim=dim, occ_ld=occ_ld)
+            ops.segreduce(occ, si, self.mode, table, state=state, lr=self.lr, eps=self.eps, dim=dim, occ_ld=occ_ld,
+                          occ2=occ2, target2=table2, state2=state2)
             return
         d = dim if dim is not None else (occ.shape[1] if occ.dim() == 2 else 1)
         compact = torch.empty(max(si.n, 1), d, dtype=torch.float32, device=table.device)
-        sq = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, compact, dim=dim, occ_ld=occ_ld, want_sq=True)
+        compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if param2 is not None else None
+        sq = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, compact, dim=dim, occ_ld=occ_ld, want_sq=True,
+                           occ2=occ2, target2=compact2)
         self.owner._pending.append((self, param, compact, si, sq))
+        if param2 is not None:
+            self.owner._pending.append((rule2, param2, compact2, si, None))
 
 
 class FusedOptimizer:
@@ -121,7 +131,8 @@ class FusedOptimizer:
                 if p.grad is not None:
                     ops.sumsq_accumulate(p.grad.contiguous().reshape(-1), acc)
             for (_, _, _, _, sq) in self._pending:
-                ops.sum_accumulate(sq, acc)
+                if sq is not None:
+                    ops.sum_accumulate(sq, acc)
             scale, self.last_total_norm = ops.clip_scale(acc, float(self.clip_norm))
             for (rule, param, compact, si, _) in self._pending:
                 ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,

@@ -26,12 +26,22 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.rx_abi_version() == _lib.RX_ABI_VERSION
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The header is plain C; sizeof/offsetof from gcc must equal the ctypes mirrors."""
     import ctypes as C
+    import subprocess
     from recsys_amd import _lib
-    assert C.sizeof(_lib.GatherSeg) == 56
-    assert C.sizeof(_lib.MFArgs) == 19 * 8 + 8
-    assert C.sizeof(_lib.FMArgs) == 8 * 8 + 16
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "recsys_hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rx_gather_seg), sizeof(rx_mf_args), sizeof(rx_fm_args),'
+        ' offsetof(rx_gather_seg, dim), offsetof(rx_mf_args, B), offsetof(rx_fm_args, flags));return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    exp = [C.sizeof(_lib.GatherSeg), C.sizeof(_lib.MFArgs), C.sizeof(_lib.FMArgs), _lib.GatherSeg.dim.offset,
+           _lib.MFArgs.B.offset, _lib.FMArgs.flags.offset]
+    assert got == exp
 
 
 def test_workspace_queries_are_pure_host_calls():
@@ -40,8 +50,9 @@ def test_workspace_queries_are_pure_host_calls():
     a, b = _lib.lib.rx_sort_dedup_workspace_bytes(1000), _lib.lib.rx_sort_dedup_workspace_bytes(100000)
     assert 16 * 1000 <= a < b
     assert _lib.lib.rx_bce_workspace_bytes(10) >= 8
-    assert _lib.lib.rx_segreduce_grid(1024, 16) == 1024 * 4 // 256
-    assert _lib.lib.rx_segreduce_grid(1024, 64) == 1024 * 16 // 256
+    assert _lib.lib.rx_segreduce_grid(1024, 16) == 1 + 8
+    assert _lib.lib.rx_segreduce_grid(1024, 64) == 2 + 8
+    assert _lib.lib.rx_segreduce_workspace_bytes(1024, 16) == 32 * 2 * 16 * 4 + 256 + 256
     assert _lib.lib.rx_mf_bwd_grid(1024, 64) == 64
 
 

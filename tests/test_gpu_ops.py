@@ -289,3 +289,44 @@ def test_bucketize_by_owner(ops, world):
     exp[exp_perm] = rows_t
     assert torch.equal(back, exp)
     assert torch.equal(ops.permute_rows(back.cuda(), perm).cpu(), rows_t)
+
+
+@pytest.mark.parametrize("skew", ["uniform", "hot"])
+@pytest.mark.parametrize("mode", ["dense", "sgd", "adagrad"])
+def test_segreduce_companion_and_long_runs(ops, skew, mode):
+    """Rows hit thousands of times (runs crossing many 32-position pieces) and the companion
+    scalar table handled in the same launches."""
+    from recsys_amd import _lib
+    g = _gen(21)
+    n, rows, dim, lr = 40000, 500, 16, 0.1
+    if skew == "hot":
+        idx = torch.where(torch.rand(n, generator=g) < 0.7, torch.randint(0, 3, (n,), generator=g),
+                          torch.randint(0, rows, (n,), generator=g))
+    else:
+        idx = torch.randint(0, rows, (n,), generator=g)
+    occ, occ2 = torch.randn(n, dim, generator=g), torch.randn(n, generator=g)
+    si = ops.sort_dedup(idx.cuda(), rows)
+    G = torch.zeros(rows, dim, dtype=torch.float64).index_add_(0, idx, occ.double())
+    G2 = torch.zeros(rows, dtype=torch.float64).index_add_(0, idx, occ2.double())
+    if mode == "dense":
+        grad, grad2 = torch.zeros(rows, dim).cuda(), torch.zeros(rows, 1).cuda()
+        sq = ops.segreduce(occ.cuda(), si, _lib.RX_SEG_DENSE, grad, occ2=occ2.cuda(), target2=grad2, want_sq=True)
+        assert_close(grad.cpu().numpy(), G.numpy(), what="dense grad")
+        assert_close(grad2.cpu().numpy()[:, 0], G2.numpy(), what="companion grad")
+        assert_close(float(sq.double().sum()), float((G ** 2).sum() + (G2 ** 2).sum()), what="sum of squares")
+        grad_b, grad2_b = torch.zeros(rows, dim).cuda(), torch.zeros(rows, 1).cuda()
+        ops.segreduce(occ.cuda(), si, _lib.RX_SEG_DENSE, grad_b, occ2=occ2.cuda(), target2=grad2_b)
+        assert torch.equal(grad, grad_b) and torch.equal(grad2, grad2_b)
+        return
+    w0, b0 = torch.randn(rows, dim, generator=g), torch.randn(rows, 1, generator=g)
+    w, b = w0.clone().cuda(), b0.clone().cuda()
+    if mode == "sgd":
+        ops.segreduce(occ.cuda(), si, _lib.RX_SEG_SGD, w, lr=lr, occ2=occ2.cuda(), target2=b)
+        assert_close(w.cpu().numpy(), (w0.double() - lr * G).numpy(), what="sgd rows")
+        assert_close(b.cpu().numpy()[:, 0], (b0[:, 0].double() - lr * G2).numpy(), what="sgd companion")
+    else:
+        st, st2 = torch.zeros(rows, dim).cuda(), torch.zeros(rows, 1).cuda()
+        ops.segreduce(occ.cuda(), si, _lib.RX_SEG_ADAGRAD, w, state=st, lr=lr, eps=1e-10, occ2=occ2.cuda(), target2=b, state2=st2)
+        assert_close(st.cpu().numpy(), (G ** 2).numpy(), what="adagrad state")
+        assert_close(w.cpu().numpy(), (w0.double() - lr * G / (G.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad rows")
+        assert_close(b.cpu().numpy()[:, 0], (b0[:, 0].double() - lr * G2 / (G2.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad companion")
