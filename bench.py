@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
 # ----------------------------------------------------------------------------- workloads
-def build_workload(name: str, device, rank: int, world: int, clip):
+def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bool = True):
     """Returns dict(model, opt, batches, samples_per_step, desc, algo_bytes fn)."""
     from recsys_amd import synthetic
     from recsys_amd.models import fields
@@ -70,10 +70,22 @@ def build_workload(name: str, device, rank: int, world: int, clip):
         raise SystemExit(f"unknown workload {name}")
     model.train()
     opt = FusedOptimizer(model, kind="sgd", lr=lr, clip_norm=clip)
-    return dict(model=model, opt=opt, batches=batches, B=B, desc=desc)
+    w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None)
+    if use_graph:
+        from recsys_amd.graph import GraphedTrainStep
+        gs = GraphedTrainStep(model, opt)
+        for b in batches:
+            gs.add_batch(b)
+        w["graphed"] = gs
+        desc["launch"] = "one HIP graph replay per step"
+    else:
+        desc["launch"] = "eager"
+    return w
 
 
 def one_step(w, i):
+    if w.get("graphed") is not None:
+        return w["graphed"](i % len(w["batches"]))
     batch = w["batches"][i % len(w["batches"])]
     w["opt"].zero_grad()
     loss = w["model"].loss(batch)
@@ -197,6 +209,7 @@ def main():
     ap.add_argument("--workload", default="fm_criteo")
     ap.add_argument("--no-clip", action="store_true", help="skip the global grad-norm clip (one-phase fused update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
     ap.add_argument("--extra", default="", help="comma list of further workloads to time briefly and append")
     args = ap.parse_args()
@@ -218,8 +231,8 @@ def main():
     ops.set_index_check("deferred")
     clip = None if args.no_clip else 1.0
 
-    def run(name, steps, warmup, timed_op=None):
-        w = build_workload(name, device, rank, world, clip)
+    def run(name, steps, warmup, timed_op=None, use_graph=True):
+        w = build_workload(name, device, rank, world, clip, use_graph)
         for i in range(warmup):
             one_step(w, i)
         torch.cuda.synchronize()
@@ -244,7 +257,7 @@ def main():
         return w, el, timer.summary(), float(loss.item())
 
     if args.op_profile and rank == 0:
-        w = build_workload(args.workload, device, rank, world, clip)
+        w = build_workload(args.workload, device, rank, world, clip, use_graph=False)
         for i in range(5):
             one_step(w, i)
         with OpTimer(ALL_OPS) as t:
@@ -256,7 +269,12 @@ def main():
 
     dominant = {"fm_criteo": "fm2_bwd", "deepfm_criteo": "linear_bwd_w", "dcnv2_criteo": "linear_bwd_w",
                 "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
-    w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, dominant)
+    use_graph = not args.no_graph
+    w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
+    if use_graph:
+        # the dominant kernel is timed with HIP events on the launch stream in a short eager pass of
+        # the same steps (events cannot bracket a single node of a replayed graph)
+        _, _, ops_ms, _ = run(args.workload, min(args.steps, 30), 5, dominant, use_graph=False)
     B = w["B"]
     value = B * world * args.steps / el
     out = {

@@ -600,12 +600,12 @@ bce_kernel(const float* __restrict__ logits, const void* __restrict__ labels, in
   }
 }
 
+// one wavefront: lane l adds partial[l], partial[l+64], ... in order, then a fixed xor tree
 __global__ void bce_final_kernel(const double* __restrict__ partial, int n, int64_t M, double* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    loss[0] = s / (double)M;
-  }
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = rx_wave_sum_f64(s);
+  if (threadIdx.x == 0) loss[0] = s / (double)M;
 }
 
 extern "C" size_t rx_bce_workspace_bytes(int64_t M) {

@@ -43,26 +43,31 @@ struct SegArgs {
   int32_t* tail_row;  // [pieces] slot of the run that leaves the piece to the right, or -1
 };
 
-// Optimizer arithmetic for one scalar (companion table entry).
+// Optimizer arithmetic for one scalar (companion table entry).  MODE is a template parameter:
+// the walk below reaches its flush code from every position of an unrolled batch, and a
+// run-time switch over all optimizers at each site overflowed the instruction cache.
+template <int MODE>
 __device__ __forceinline__ void apply_scalar(const SegArgs& a, float g, int64_t row, int64_t u, float scale) {
-  if (a.mode == RX_SEG_DENSE) { a.target2[row] = g; return; }
-  if (a.mode == RX_SEG_COMPACT) { a.target2[u] = g; return; }
-  g *= scale;
-  if (a.mode == RX_SEG_SGD) {
-    a.target2[row] = a.target2[row] - a.lr * g;
+  if constexpr (MODE == RX_SEG_DENSE) {
+    a.target2[row] = g;
+  } else if constexpr (MODE == RX_SEG_COMPACT) {
+    a.target2[u] = g;
+  } else if constexpr (MODE == RX_SEG_SGD) {
+    a.target2[row] = a.target2[row] - a.lr * (g * scale);
   } else {  // Adagrad; row-wise Adagrad of a width-1 row is the same rule
+    g *= scale;
     const float s = a.state2[row] + g * g;
     a.state2[row] = s;
     a.target2[row] = a.target2[row] - a.lr * (g / (sqrtf(s) + a.eps));
   }
 }
 
-template <int VEC, int CH>
+template <int VEC, int CH, int MODE>
 __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int64_t row, int64_t u, int lg,
                                           float scale) {
   const int dim = a.dim, group = a.group;
-  if (a.mode == RX_SEG_DENSE || a.mode == RX_SEG_COMPACT) {
-    float* dst = a.target + (a.mode == RX_SEG_DENSE ? row : u) * (int64_t)dim;
+  if constexpr (MODE == RX_SEG_DENSE || MODE == RX_SEG_COMPACT) {
+    float* dst = a.target + (MODE == RX_SEG_DENSE ? row : u) * (int64_t)dim;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int c = (lg + k * group) * VEC;
@@ -72,7 +77,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
   }
   ACC_FOREACH(k, i) g.p[k].v[i] *= scale;
   float* w = a.target + row * (int64_t)dim;
-  if (a.mode == RX_SEG_SGD) {
+  if constexpr (MODE == RX_SEG_SGD) {
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int c = (lg + k * group) * VEC;
@@ -83,7 +88,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
         rx_store<VEC>(w + c, x);
       }
     }
-  } else if (a.mode == RX_SEG_ADAGRAD) {
+  } else if constexpr (MODE == RX_SEG_ADAGRAD) {
     float* st = a.state + row * (int64_t)dim;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -101,7 +106,7 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
         rx_store<VEC>(w + c, x);
       }
     }
-  } else {  // RX_SEG_ROWWISE_ADAGRAD
+  } else if constexpr (MODE == RX_SEG_ROWWISE_ADAGRAD) {
     float sq = 0.f;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -163,20 +168,30 @@ __device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* 
   if (threadIdx.x == 0) sq_part[blockIdx.x] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
 }
 
-template <int VEC, int CH>
+template <int VEC, int CH, int MODE>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_kernel(SegArgs a) {
-  extern __shared__ int2 meta[];  // [groups per block][SEG_CHUNK] = (slot, position); slot -1 past the end
+  // LDS tile of the block's sorted positions, staged by one coalesced sweep:
+  //   meta[1 + j] = (slot, position) of sorted position base + j; slot -1 past the end
+  //   meta[0], meta[1 + T] = the neighbours just outside the tile (only their slot is used)
+  //   rowid[j] = table row of that slot
+  // so the walk below never waits on a dependent global load except the rows themselves.
+  extern __shared__ int2 meta[];
   __shared__ float sq_lds[RX_BLOCK / 64];
   constexpr int BATCH = 8 / CH;
   const int group = a.group, dim = a.dim;
   const int gpb = RX_BLOCK / group;
+  const int T = gpb * SEG_CHUNK;
+  uint32_t* rowid = reinterpret_cast<uint32_t*>(meta + T + 2);
   const int64_t piece0 = (int64_t)blockIdx.x * gpb;
   {
     const int64_t base = piece0 * SEG_CHUNK;
-    for (int j = threadIdx.x; j < gpb * SEG_CHUNK; j += RX_BLOCK) {
-      const int64_t p = base + j;
-      meta[j] = (p < a.n) ? make_int2(a.sorted_slot[p], a.sorted_pos[p]) : make_int2(-1, 0);
+    for (int j = threadIdx.x; j < T + 2; j += RX_BLOCK) {
+      const int64_t p = base + j - 1;
+      int2 m = make_int2(-1, 0);
+      if (p >= 0 && p < a.n) m = make_int2(a.sorted_slot[p], a.sorted_pos[p]);
+      meta[j] = m;
+      if (j >= 1 && j <= T) rowid[j - 1] = m.x >= 0 ? (uint32_t)a.uniq_rows[m.x] : 0u;
     }
   }
   __syncthreads();
@@ -186,28 +201,33 @@ segreduce_chunk_kernel(SegArgs a) {
   const int64_t lo = piece * SEG_CHUNK;
   float sq = 0.f;
   if (lo < a.n) {
-    const int64_t hi = (lo + SEG_CHUNK < a.n) ? lo + SEG_CHUNK : a.n;
+    const int len = (int)((lo + SEG_CHUNK < a.n) ? SEG_CHUNK : a.n - lo);
     const float scale = a.scale ? a.scale[0] : 1.f;
-    const int2* mine = meta + my * SEG_CHUNK;
+    const int2* mine = meta + 1 + my * SEG_CHUNK;  // mine[-1] and mine[len] are the neighbours
+    const uint32_t* myrow = rowid + my * SEG_CHUNK;
+    const int left = mine[-1].x, right = mine[len].x;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
     int cur = mine[0].x;
+    int run_start = 0;
     int tail = -1;
-    auto flush = [&](int u) {
-      const int64_t run_lo = a.seg_off[u], run_hi = a.seg_off[u + 1];
-      if (run_lo >= lo && run_hi <= hi) {
-        const int64_t row = a.uniq_rows[u];
+    // flush the run of slot u that covers piece positions [run_start, end)
+    auto flush = [&](int u, int end) {
+      const bool entered = (run_start == 0) && (left == u);
+      const bool leaves = (end == len) && (right == u);
+      if (!entered && !leaves) {
+        const int64_t row = (int64_t)myrow[run_start];
         if (a.sq_part) {
           sq += acc_sq<VEC, CH>(g, lg, group, dim);
           if (a.occ2 && lg == 0) sq += g2 * g2;
         }
-        if (row >= 0 && row < a.n_rows) {
-          if (a.occ2 && lg == 0) apply_scalar(a, g2, row, u, scale);
-          apply_row<VEC, CH>(a, g, row, u, lg, scale);
+        if (row < a.n_rows) {
+          if (a.occ2 && lg == 0) apply_scalar<MODE>(a, g2, row, u, scale);
+          apply_row<VEC, CH, MODE>(a, g, row, u, lg, scale);
         }
       } else {
-        const int side = run_lo < lo ? 0 : 1;
+        const int side = entered ? 0 : 1;
         float* dst = a.partials + (piece * 2 + side) * (int64_t)dim;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
@@ -219,41 +239,61 @@ segreduce_chunk_kernel(SegArgs a) {
       }
       ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
       g2 = 0.f;
+      run_start = end;
     };
+    // Loads are issued unconditionally (out-of-range batch entries re-read the piece's last
+    // position, out-of-range columns re-read column 0) and masked afterwards: a load under a
+    // run-time branch would make the compiler wait for each one before issuing the next.
+    bool col_ok[CH];
+    int col[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      col_ok[k] = c < dim;
+      col[k] = col_ok[k] ? c : 0;
+    }
+    const bool has2 = a.occ2 != nullptr;
 #pragma unroll 1
     for (int b0 = 0; b0 < SEG_CHUNK; b0 += BATCH) {
+      if (b0 >= len) break;
       int sl[BATCH];
       Acc<VEC, CH> rows[BATCH];
       float s2[BATCH];
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        const int2 m = mine[b0 + j];
+        const int jj = (b0 + j < len) ? b0 + j : len - 1;
+        const int2 m = mine[jj];
         sl[j] = m.x;
         const float* src = a.occ + (int64_t)m.y * a.occ_ld;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          const int c = (lg + k * group) * VEC;
-          rows[j].p[k] = (m.x >= 0 && c < dim) ? rx_load<VEC>(src + c) : rx_zero<VEC>();
-        }
-        s2[j] = (a.occ2 && lg == 0 && m.x >= 0) ? a.occ2[m.y] : 0.f;
+        for (int k = 0; k < CH; ++k) rows[j].p[k] = rx_load<VEC>(src + col[k]);
+        s2[j] = has2 ? a.occ2[m.y] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        if (sl[j] != cur) {
-          if (cur >= 0) flush(cur);
-          cur = sl[j];
+        if (b0 + j < len) {
+          if (sl[j] != cur) {
+            flush(cur, b0 + j);
+            cur = sl[j];
+          }
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            if (col_ok[k]) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) g.p[k].v[i] += rows[j].p[k].v[i];
+            }
+          }
+          g2 += s2[j];
         }
-        ACC_FOREACH(k, i) g.p[k].v[i] += rows[j].p[k].v[i];
-        g2 += s2[j];
       }
     }
-    if (cur >= 0) flush(cur);
+    flush(cur, len);
     if (lg == 0) a.tail_row[piece] = tail;
   }
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
 }
 
-template <int VEC, int CH>
+template <int VEC, int CH, int MODE>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
   __shared__ float sq_lds[RX_BLOCK / 64];
@@ -297,8 +337,8 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
       }
       if (row >= 0 && row < a.n_rows) {
         const float scale = a.scale ? a.scale[0] : 1.f;
-        if (a.occ2 && lg == 0) apply_scalar(a, g2, row, u, scale);
-        apply_row<VEC, CH>(a, g, row, u, lg, scale);
+        if (a.occ2 && lg == 0) apply_scalar<MODE>(a, g2, row, u, scale);
+        apply_row<VEC, CH, MODE>(a, g, row, u, lg, scale);
       }
     }
   }
@@ -341,14 +381,25 @@ extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
          rx_align_up(pieces * sizeof(int32_t), 256);
 }
 
-#define SEG_DISPATCH(sh, KERNEL, grid, lds, st, ...)                                               \
+#define SEG_DISPATCH_M(M, sh, KERNEL, grid, lds, st, ...)                                          \
   do {                                                                                             \
-    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<1, 4>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__);          \
+    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<1, 4, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__);       \
+  } while (0)
+
+#define SEG_DISPATCH(mode, sh, KERNEL, grid, lds, st, ...)                                         \
+  do {                                                                                             \
+    switch (mode) {                                                                                \
+      case RX_SEG_DENSE: SEG_DISPATCH_M(RX_SEG_DENSE, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_COMPACT: SEG_DISPATCH_M(RX_SEG_COMPACT, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_SGD: SEG_DISPATCH_M(RX_SEG_SGD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break;  \
+      case RX_SEG_ADAGRAD: SEG_DISPATCH_M(RX_SEG_ADAGRAD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      default: SEG_DISPATCH_M(RX_SEG_ROWWISE_ADAGRAD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+    }                                                                                              \
   } while (0)
 
 static int mode_check(int mode, const float* state, const char* who, bool allow_grad_modes) {
@@ -384,18 +435,19 @@ extern "C" int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32
             d_state, n_rows, lr, eps, d_scale, d_sq_part, sh.group, d_occ2, d_target2, d_state2, partials,
             partials2, tail_row};
   const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n);
-  const size_t lds = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK * sizeof(int2);
+  const size_t tile = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK;
+  const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
   hipStream_t st = (hipStream_t)stream;
-  SEG_DISPATCH(sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
+  SEG_DISPATCH(mode, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
   RX_LAUNCH_CHECK();
   if (d_sq_part) a.sq_part = d_sq_part + g1;
-  SEG_DISPATCH(sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
+  SEG_DISPATCH(mode, sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
   RX_LAUNCH_CHECK();
   return 0;
 }
 
 // ---------------------------------------------------------------- update from a compact gradient
-template <int VEC, int CH>
+template <int VEC, int CH, int MODE>
 __global__ void __launch_bounds__(RX_BLOCK)
 row_update_kernel(SegArgs a) {
   const int group = a.group, dim = a.dim;
@@ -411,7 +463,7 @@ row_update_kernel(SegArgs a) {
     const int c = (lg + k * group) * VEC;
     g.p[k] = (c < dim) ? rx_load<VEC>(a.occ + u * (int64_t)dim + c) : rx_zero<VEC>();
   }
-  apply_row<VEC, CH>(a, g, row, u, lg, a.scale ? a.scale[0] : 1.f);
+  apply_row<VEC, CH, MODE>(a, g, row, u, lg, a.scale ? a.scale[0] : 1.f);
 }
 
 extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
@@ -428,7 +480,7 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   SegArgs a{d_compact, dim, n_max, dim, nullptr, nullptr, d_uniq_rows, nullptr, d_n_uniq, mode, d_w, d_state,
             n_rows, lr, eps, d_scale, nullptr, sh.group, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
-  SEG_DISPATCH(sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
+  SEG_DISPATCH(mode, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -531,11 +583,13 @@ reduce_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict
 }
 
 // mode 0: acc[0] += sum(partial)   mode 1: out_f32[0] = (float)sum(partial)
+// one wavefront: lane l adds partial[l], partial[l+64], ... in order, then a fixed xor tree
 __global__ void reduce_final_kernel(const double* __restrict__ partial, int n, double* __restrict__ acc,
                                     float* __restrict__ out_f32) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += partial[i];
+  for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+  s = rx_wave_sum_f64(s);
+  if (threadIdx.x != 0) return;
   if (acc) acc[0] += s;
   if (out_f32) out_f32[0] = (float)s;
 }

@@ -1,0 +1,73 @@
+"""HIP-graph capture of the whole train step (forward, loss, backward, fused update).
+
+A step of these models is a few dozen short kernels; launched one by one from Python the host,
+not the GPU, sets the pace.  ``GraphedTrainStep`` records the step once per resident batch with
+stream capture (torch.cuda.CUDAGraph drives hipStreamBeginCapture; every C-ABI launch goes to the
+capturing stream) and replays it with one hipGraphLaunch.  Nothing in the step synchronises with
+the host: index errors are reported through the deferred flag (ops.raise_if_index_error), the
+loss stays on the device until asked for.
+
+Limits: the batch tensors are captured by address, so a graph is tied to its batch object
+(``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place);
+``dense_kind="adam"`` bakes the step count into the recording and is refused.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, warmup: int = 3):
+        if getattr(optimizer, "dense_kind", None) == "adam" and optimizer.dense:
+            raise ValueError("dense Adam keeps its step count on the host and cannot be captured")
+        self.model, self.opt, self.warmup = model, optimizer, warmup
+        self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.batches: List[Dict[str, torch.Tensor]] = []
+        self.losses: List[torch.Tensor] = []
+        self._pool = None
+        self._prev_check = None
+
+    def _eager(self, batch):
+        self.opt.zero_grad()
+        loss = self.model.loss(batch)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def add_batch(self, batch: Dict[str, torch.Tensor]) -> int:
+        """Record one graph bound to ``batch``'s tensors.  Before the first recording the step is
+        run eagerly ``warmup`` times on a side stream (these are real train steps on ``batch``);
+        recording itself executes nothing."""
+        if ops._INDEX_CHECK != "deferred":
+            raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
+        dev = next(self.model.parameters()).device
+        if not self.graphs:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):
+                    self._eager(batch)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        self.opt.zero_grad()
+        with torch.cuda.graph(g, pool=self._pool):
+            loss = self._eager(batch)
+        if self._pool is None:
+            self._pool = g.pool()
+        self.graphs.append(g)
+        self.batches.append(batch)
+        self.losses.append(loss)
+        return len(self.graphs) - 1
+
+    def copy_batch(self, slot: int, new_batch: Dict[str, torch.Tensor]) -> None:
+        for k, v in self.batches[slot].items():
+            v.copy_(new_batch[k])
+
+    def __call__(self, slot: int) -> torch.Tensor:
+        self.graphs[slot].replay()
+        return self.losses[slot]

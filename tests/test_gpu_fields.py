@@ -94,3 +94,33 @@ def test_strided_sparse_matrix_is_used_in_place():
     flat = ops.fm2_flat_indices(feat, sparse[:, :5], base, sparse[:, 5:], 50)
     exp = torch.cat([(sparse[:, :5] + base[None]).reshape(-1), sparse[:, 5] + 50])
     assert torch.equal(flat, exp)
+
+
+def test_graphed_step_matches_eager_bitwise():
+    """One hipGraphLaunch per step gives the same weights, bit for bit, as launching each kernel."""
+    from recsys_amd import ops
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.optim import FusedOptimizer
+    results = []
+    for graphed in (False, True):
+        _, m, batch = _pair("FieldDeepFM", B=512)
+        dbatch = {k: v.cuda() for k, v in batch.items()}
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=2)
+                slot = gs.add_batch(dbatch)      # 2 eager warm-up steps; recording executes nothing
+                for _ in range(3):
+                    loss = gs(slot)
+            else:
+                for _ in range(5):
+                    opt.zero_grad(); loss = m.loss(dbatch); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
