@@ -44,6 +44,28 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
 
     torch.manual_seed(1234)
     n_batches = 8
+    if name == "fm_criteo_sharded":
+        # tables row-sharded over the ranks (row r on rank r % G), batch data parallel, index / row /
+        # gradient exchange by all-to-all; per-GPU batch fixed (weak scaling)
+        from recsys_amd.sharded import ShardedFieldFM
+        dims = synthetic.criteo_field_dims()
+        B, D = 65536, 16
+        model = ShardedFieldFM(dims, D, device)
+        model.set_rule("sgd", 0.05)
+        batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
+        desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
+                "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": None,
+                "launch": "eager (all-to-all split sizes are read back on the host)"}
+
+        class _Opt:
+            def zero_grad(self):
+                pass
+
+            def step(self):
+                pass
+
+        # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
+        return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world)
     if name in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
         B, D = 65536, 16
@@ -89,7 +111,7 @@ def one_step(w, i):
     batch = w["batches"][i % len(w["batches"])]
     w["opt"].zero_grad()
     loss = w["model"].loss(batch)
-    loss.backward()
+    (loss * w["loss_scale"] if w.get("loss_scale") else loss).backward()
     w["opt"].step()
     return loss
 
@@ -141,7 +163,7 @@ ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", 
 def algo_bytes(desc, op):
     """Algorithmic HBM bytes of one launch of the step's dominant kernels (fp32, 8-byte indices)."""
     B, D = desc["batch_per_gpu"], desc["dim"]
-    if desc["workload"] in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+    if desc["workload"] in ("fm_criteo", "fm_criteo_sharded", "deepfm_criteo", "dcnv2_criteo"):
         F = desc["fields"]
         if op == "fm2_fwd":  # index + row + bias entry per field, one logit out
             return B * (F * (8 + 4 * D + 4) + 4)
@@ -267,9 +289,14 @@ def main():
             print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
         del w
 
-    dominant = {"fm_criteo": "fm2_bwd", "deepfm_criteo": "linear_bwd_w", "dcnv2_criteo": "linear_bwd_w",
+    dominant = {"fm_criteo": "fm2_bwd", "fm_criteo_sharded": "fm2_bwd", "deepfm_criteo": "linear_bwd_w", "dcnv2_criteo": "linear_bwd_w",
                 "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
+    if world > 1 and args.workload == "fm_criteo":
+        args.workload = "fm_criteo_sharded"
+    if args.workload == "fm_criteo_sharded":
+        use_graph = False
+        dominant = "fm2_bwd"
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
     if use_graph:
         # the dominant kernel is timed with HIP events on the launch stream in a short eager pass of

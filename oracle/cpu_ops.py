@@ -1,0 +1,129 @@
+"""CPU stand-ins (plain torch) for the kernels the sharded-exchange code calls, with the names and
+result conventions of ``recsys_amd.ops``.  They let the exchange logic (bucketise -> all-to-all ->
+gather -> un-permute, and the gradient path back) run under gloo on machines without a GPU.
+
+Test infrastructure: see ``oracle/__init__.py``.  Only tests inject this module as ``backend``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from recsys_amd import _lib
+
+
+@dataclass
+class Segment:
+    table: torch.Tensor
+    idx: torch.Tensor
+    col: int
+    div: int = 1
+    stride: int = 1
+    k: int = 0
+    base: int = 0
+
+
+@dataclass
+class SortedIndex:
+    n: int
+    n_rows: int
+    sorted_pos: torch.Tensor
+    sorted_slot: torch.Tensor
+    uniq_rows: torch.Tensor
+    seg_off: torch.Tensor
+    n_uniq: torch.Tensor
+    inverse: Optional[torch.Tensor] = None
+
+
+def bucketize_by_owner(idx, world, n_rows_global):
+    flat = idx.reshape(-1)
+    if ((flat < 0) | (flat >= n_rows_global)).any():
+        raise IndexError("index out of range")
+    owner = flat % world
+    perm = torch.sort(owner, stable=True)[1]
+    return torch.bincount(owner, minlength=world), (flat // world)[perm], perm.to(torch.int32)
+
+
+def gather_concat(segs, out_rows, out_cols, out=None):
+    out = torch.empty(out_rows, out_cols) if out is None else out
+    i = torch.arange(out_rows)
+    for s in segs:
+        j = (i // s.div) * s.stride + s.k
+        out[:, s.col:s.col + s.table.shape[1]] = s.table[s.idx.reshape(-1)[j] + s.base]
+    return out
+
+
+def unpermute_rows(rows, perm):
+    out = torch.empty_like(rows)
+    out[perm.long()] = rows
+    return out
+
+
+def permute_rows(rows, perm):
+    return rows[perm.long()]
+
+
+def sort_dedup(idx, n_rows, want_inverse=False):
+    flat = idx.reshape(-1)
+    _, pos = torch.sort(flat, stable=True)
+    uniq, inv, counts = torch.unique(flat, sorted=True, return_inverse=True, return_counts=True)
+    seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
+    seg[1:] = counts.cumsum(0)
+    return SortedIndex(flat.numel(), n_rows, pos.to(torch.int32), inv[pos].to(torch.int32), uniq, seg,
+                       torch.tensor([uniq.numel()], dtype=torch.int32), inv.to(torch.int32))
+
+
+def segreduce(occ, si, mode, target, *, state=None, lr=0.0, eps=0.0, scale=None, want_sq=False, occ_ld=None,
+              dim=None, occ2=None, target2=None, state2=None):
+    occ = occ.reshape(si.n, -1)
+    nu = int(si.n_uniq)
+    G = torch.zeros(nu, occ.shape[1]).index_add_(0, si.sorted_slot.long(), occ[si.sorted_pos.long()])
+    rows = si.uniq_rows[:nu]
+    sc = float(scale) if scale is not None else 1.0
+    t = target.reshape(target.shape[0], -1)
+    if mode == _lib.RX_SEG_DENSE:
+        t[rows] = G
+    elif mode == _lib.RX_SEG_COMPACT:
+        t[:nu] = G
+    elif mode == _lib.RX_SEG_SGD:
+        t[rows] -= lr * sc * G
+    elif mode == _lib.RX_SEG_ADAGRAD:
+        state[rows] += (sc * G) ** 2
+        t[rows] -= lr * sc * G / (state[rows].sqrt() + eps)
+    else:
+        state[rows] += ((sc * G) ** 2).mean(1)
+        t[rows] -= lr * sc * G / (state[rows].sqrt()[:, None] + eps)
+    return (G ** 2).sum().reshape(1) if want_sq else None
+
+
+def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base, want_deep=False, second_order=True, deep_cols=None,
+            want_logits=True, extra=None):
+    ex = feat[ex_idx + ex_base[None, :]]
+    item = feat[item_idx + item_base]
+    b = bias[ex_idx + ex_base[None, :]].sum(1, keepdim=True) + bias[item_idx + item_base]
+    s = ex.sum(1, keepdim=True) + item
+    q = (ex * ex).sum(1, keepdim=True) + item * item
+    return b + 0.5 * (s * s - q).sum(-1), None
+
+
+def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base, second_order=True):
+    ex = feat[ex_idx + ex_base[None, :]]            # [B, F, D]
+    item = feat[item_idx + item_base]               # [B, N, D]
+    B, F, D = ex.shape
+    N = item.shape[1]
+    g = g.reshape(B, N)
+    S = ex.sum(1)
+    Gs = g.sum(1)
+    gv = (g[:, :, None] * item).sum(1)
+    d_ex = Gs[:, None, None] * (S[:, None, :] - ex) + gv[:, None, :]
+    d_item = g[:, :, None] * S[:, None, :]
+    occ = torch.cat([d_ex.reshape(B * F, D), d_item.reshape(B * N, D)])
+    bias_occ = torch.cat([Gs[:, None].expand(B, F).reshape(-1), g.reshape(-1)])
+    return occ, bias_occ
+
+
+def bce_loss(logits, labels):
+    from .models import bce_with_logits
+    return bce_with_logits(logits, labels)

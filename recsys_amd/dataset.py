@@ -1,0 +1,182 @@
+"""Batching for the implicit-feedback pipelines, device resident.
+
+Mirrors the batch contract of recsys/dataset.py (``ImplicitData`` with
+``create_negative_sampled_train_dataloader(n_negatives=4)`` / ``create_test_dataloader()`` /
+``test_dataloader``; batches are dicts with ``user_code [B] i64``, ``item_code [B, 1+n_neg] i64``,
+``user_occupation [B] i64``, ``item_timestamp_rank [B] i64``, ``label [B, 1+n_neg] f64``; test
+batches carry no label, recsys/dataset.py:255-262,276-282) without its per-sample Python
+``__getitem__`` + collate: the positives and their side features are uploaded once, each epoch's
+negatives are drawn, the epoch is permuted once, and batches are contiguous slices of tensors
+that already sit in HBM.
+
+``sampler="numpy"`` draws the negatives with the reference's exact numpy calls
+(recsys/dataset.py:165-187), so a numpy seed reproduces its ``train_data`` bit for bit;
+``sampler="device"`` draws them with torch on the GPU (same distribution, no host work).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterator, Optional
+
+import numpy as np
+import scipy.sparse as scs
+import torch
+
+
+def create_negative_sampled_train_data(train_inputs, negative_samples, n_negatives):
+    """Host sampler with the reference's call sequence: for every positive (u, i), ``n_negatives``
+    draws ``negative_samples[u, randint(0, pool)]``; rows are [u, i_pos, neg_1..neg_n], labels
+    [1, 0, ..., 0] in float64."""
+    rows, cols = train_inputs.nonzero()
+    neg_rows = rows.repeat(n_negatives)
+    neg_cols = np.random.randint(0, negative_samples.shape[1], neg_rows.shape[0])
+    negatives = negative_samples[neg_rows, neg_cols].reshape(-1, n_negatives)
+    data = np.hstack([np.vstack([rows, cols]).T, negatives])
+    labels = np.zeros((data.shape[0], n_negatives + 1), dtype=float)
+    labels[:, 0] = 1
+    return data, labels
+
+
+class EpochLoader:
+    """Iterable over dict batches that are slices of epoch tensors resident on ``device``.
+    ``len()`` is the number of batches (last one may be short, like DataLoader's default)."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], batch_size: int, shuffle: bool,
+                 generator: Optional[torch.Generator] = None):
+        self.tensors, self.batch_size, self.shuffle, self.generator = tensors, batch_size, shuffle, generator
+        self.length = next(iter(tensors.values())).shape[0]
+
+    def __len__(self):
+        return math.ceil(self.length / self.batch_size)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        tensors = self.tensors
+        if self.shuffle:
+            dev = next(iter(tensors.values())).device
+            perm = torch.randperm(self.length, device=dev, generator=self.generator)
+            tensors = {k: v.index_select(0, perm) for k, v in tensors.items()}
+        for lo in range(0, self.length, self.batch_size):
+            yield {k: v[lo:lo + self.batch_size] for k, v in tensors.items()}
+
+
+class ImplicitData:
+    """Same constructor contract as recsys/dataset.py:204-226: ``data`` is the dict written by the
+    reference's split (implicit_matrix, timestamp_matrix, test_codes, test_true,
+    test_timestamp_rank, negative_samples, user_infos)."""
+
+    def __init__(self, data: dict, device="cpu", train_batch_size: int = 512, test_batch_size: int = 1024,
+                 sampler: str = "device"):
+        if sampler not in ("device", "numpy"):
+            raise ValueError(sampler)
+        self.implicit_matrix = data["implicit_matrix"]
+        self.timestamp_matrix = data["timestamp_matrix"]
+        self.test_codes = data["test_codes"]
+        self.test_true = data["test_true"]
+        self.test_timestamp_rank = data["test_timestamp_rank"]
+        self.negative_samples = data["negative_samples"]
+        self.user_infos = data["user_infos"]
+        self.n_users, self.n_items = self.implicit_matrix.shape
+        self.n_occupations = np.unique(self.user_infos[:, -1]).shape[0]
+        self.max_timestamp_rank = int(self.timestamp_matrix.data.max() + 2)
+        self.device = torch.device(device)
+        self.train_batch_size, self.test_batch_size, self.sampler = train_batch_size, test_batch_size, sampler
+        self._test_dataloader = None
+        # positives and their side features never change between epochs: upload them once
+        rows, cols = self.implicit_matrix.nonzero()
+        ts = np.asarray(self.timestamp_matrix[rows, cols]).reshape(-1).astype(np.int64)
+        dev = self.device
+        self._rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
+        self._cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
+        self._occ = torch.from_numpy(self.user_infos[rows, -1].astype(np.int64)).to(dev)
+        self._ts = torch.from_numpy(ts).to(dev)
+        self._pool = torch.from_numpy(np.ascontiguousarray(self.negative_samples).astype(np.int64)).to(dev)
+        self._gen = torch.Generator(device=dev)
+
+    def create_negative_sampled_train_dataloader(self, n_negatives: int = 4) -> EpochLoader:
+        n = self._rows.shape[0]
+        if self.sampler == "numpy":
+            data, labels = create_negative_sampled_train_data(self.implicit_matrix, self.negative_samples, n_negatives)
+            items = torch.from_numpy(np.ascontiguousarray(data[:, 1:]).astype(np.int64)).to(self.device)
+            label = torch.from_numpy(labels).to(self.device)
+        else:
+            draws = torch.randint(0, self._pool.shape[1], (n, n_negatives), device=self.device, generator=self._gen)
+            negatives = self._pool[self._rows[:, None], draws]
+            items = torch.cat([self._cols[:, None], negatives], dim=1)
+            label = torch.zeros(n, n_negatives + 1, dtype=torch.float64, device=self.device)
+            label[:, 0] = 1
+        tensors = {"user_code": self._rows, "item_code": items, "user_occupation": self._occ,
+                   "item_timestamp_rank": self._ts, "label": label}
+        return EpochLoader(tensors, self.train_batch_size, shuffle=True, generator=self._gen)
+
+    def create_test_dataloader(self) -> EpochLoader:
+        if self._test_dataloader is None:
+            dev = self.device
+            users = np.arange(self.n_users)
+            tensors = {
+                "user_code": torch.from_numpy(users.astype(np.int64)).to(dev),
+                "item_code": torch.from_numpy(np.ascontiguousarray(self.test_codes).astype(np.int64)).to(dev),
+                "user_occupation": torch.from_numpy(self.user_infos[users, -1].astype(np.int64)).to(dev),
+                "item_timestamp_rank": torch.from_numpy(np.asarray(self.test_timestamp_rank).astype(np.int64)).to(dev),
+            }
+            self._test_dataloader = EpochLoader(tensors, self.test_batch_size, shuffle=False)
+        return self._test_dataloader
+
+    @property
+    def test_dataloader(self):
+        return self._test_dataloader
+
+
+def synthetic_ml1m_data(seed: int = 0, n_users: int = 6040, n_items: int = 3706, n_occupations: int = 21,
+                        n_train: int = 994_169, pool: int = 500, n_test_codes: int = 100) -> dict:
+    """A ``data`` dict with MovieLens-1M's shape (the real ratings.dat is not redistributable and is
+    absent from the reference checkout): Zipf-like item popularity, at least 20 interactions per
+    user, a top-``pool`` popular-unseen negative pool per user, 1 held-out positive + 99 sampled
+    negatives as test codes (the split the reference builds in recsys/dataset.py:99-156)."""
+    rng = np.random.RandomState(seed)
+    per_user = np.maximum(20, rng.zipf(1.6, n_users) * 20)
+    per_user = np.minimum(per_user, n_items // 2)
+    per_user = np.round(per_user * (n_train + n_users) / per_user.sum()).astype(np.int64)
+    per_user = np.clip(per_user, 20, n_items // 2)
+    pop = 1.0 / np.arange(1, n_items + 1) ** 0.9
+    pop /= pop.sum()
+    rows, cols, ts = [], [], []
+    test_true = np.zeros((n_users, 1), dtype=np.int64)
+    test_ts = np.zeros(n_users, dtype=np.int64)
+    seen = []
+    for u in range(n_users):
+        items = rng.choice(n_items, size=int(per_user[u]), replace=False, p=pop)
+        seen.append(items)
+        test_true[u, 0] = items[-1]
+        test_ts[u] = len(items) - 1
+        rows.append(np.full(len(items) - 1, u)); cols.append(items[:-1]); ts.append(np.arange(len(items) - 1))
+    rows, cols, ts = np.concatenate(rows), np.concatenate(cols), np.concatenate(ts)
+    implicit = scs.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n_users, n_items))
+    timestamps = scs.csr_matrix((ts.astype(np.float64), (rows, cols)), shape=(n_users, n_items))
+    popularity = np.asarray(implicit.sum(0)).reshape(-1)
+    order = np.argsort(-popularity, kind="stable")
+    negative_samples = np.zeros((n_users, pool), dtype=np.int64)
+    for u in range(n_users):
+        mask = np.ones(n_items, dtype=bool)
+        mask[seen[u]] = False
+        negative_samples[u] = order[mask[order]][:pool]
+    negs = np.take_along_axis(negative_samples, rng.randint(0, pool, (n_users, n_test_codes - 1)), 1)
+    user_infos = np.stack([np.arange(n_users), rng.randint(0, 2, n_users), rng.randint(0, 7, n_users),
+                           rng.randint(0, n_occupations, n_users)], 1)
+    user_infos[:n_occupations, -1] = np.arange(n_occupations)
+    return {"implicit_matrix": implicit, "timestamp_matrix": timestamps, "test_codes": np.hstack([test_true, negs]),
+            "test_true": test_true, "test_timestamp_rank": test_ts, "negative_samples": negative_samples,
+            "user_infos": user_infos}
+
+
+def load_ml1m_data(path):
+    """Read the ``ml1m.npz`` written by the reference's own split (recsys/dataset.py:143-156).  That
+    file stores a pickled dict, so only load one you produced yourself."""
+    return np.load(path, allow_pickle=True)["data"].item()
+
+
+def load_implicit_data(device="cpu", train_batch_size: int = 512, test_batch_size: int = 1024, path=None,
+                       sampler: str = "device") -> ImplicitData:
+    """``path`` to a user-built ml1m.npz, or ML-1M-shaped synthetic data when None."""
+    data = load_ml1m_data(path) if path is not None else synthetic_ml1m_data()
+    return ImplicitData(data, device=device, train_batch_size=train_batch_size, test_batch_size=test_batch_size,
+                        sampler=sampler)

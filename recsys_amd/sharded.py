@@ -1,0 +1,204 @@
+"""Row-sharded embedding tables across the GPUs of one node (no counterpart in the reference,
+which is single-device).
+
+Row ``r`` of a table lives on rank ``r % G`` at local row ``r // G`` (round-robin keeps the hot
+low ids of a Zipf field spread over all ranks).  The batch is data parallel.  One lookup is
+
+    bucketise local indices by owner   rx_bucketize_by_owner      (stable, by one radix pass)
+    all-to-all counts, then indices    torch.distributed (RCCL over xGMI on GPUs)
+    owners gather their rows           rx_gather_concat
+    all-to-all rows back, un-permute   rx_unpermute_rows
+
+and the backward ships per-occurrence gradient rows to the owners the same way; each owner then
+runs the deterministic sort -> segmented reduce -> row update on what it received (arrival order is
+(source rank, position), so results do not depend on timing).  The collective itself is issued by
+torch.distributed on the current stream; everything around it is a C-ABI kernel.
+
+``backend`` is the module providing the kernels (``recsys_amd.ops``).  Tests on machines without a
+GPU pass a CPU stand-in with the same function names to exercise the exchange logic under gloo.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def _ops():
+    from . import ops
+    return ops
+
+
+class ShardedTable:
+    """fp32 table of ``n_rows`` global rows x ``dim``, this rank holding rows r with r % G == rank."""
+
+    def __init__(self, n_rows: int, dim: int, device, group=None, backend=None, init_std: float = 1.0,
+                 seed: int = 0, full_weight: Optional[torch.Tensor] = None):
+        self.group = group
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_rows, self.dim, self.device = n_rows, dim, torch.device(device)
+        self.ops = backend if backend is not None else _ops()
+        self.local_rows = (n_rows - self.rank + self.G - 1) // self.G
+        if full_weight is not None:
+            self.weight = full_weight[self.rank::self.G].to(self.device).contiguous().float()
+        else:
+            g = torch.Generator(device=self.device).manual_seed(seed * 1000 + self.rank)
+            self.weight = torch.randn(self.local_rows, dim, device=self.device, generator=g) * init_std
+        self.grad: Optional[torch.Tensor] = None      # dense local gradient (when no rule is set)
+        self.rule = None                               # (mode, lr, eps, state) for the fused row update
+
+    def set_rule(self, kind: str, lr: float, eps: float = 1e-10):
+        mode = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}[kind]
+        state = None
+        if kind == "adagrad":
+            state = torch.zeros_like(self.weight)
+        elif kind == "rowwise_adagrad":
+            state = torch.zeros(self.local_rows, device=self.device)
+        self.rule = (mode, lr, eps, state)
+
+    # ---- exchange plan for one index list -------------------------------------------------
+    def plan(self, idx: torch.Tensor):
+        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows)
+        if self.G == 1:
+            return dict(send=[idx.numel()], recv=[idx.numel()], recv_idx=send_local, perm=perm, n=idx.numel())
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)
+        send = counts.tolist()          # one host sync per lookup: split sizes must be host integers
+        recv = recv_counts.tolist()
+        recv_idx = torch.empty(sum(recv), dtype=torch.int64, device=idx.device)
+        dist.all_to_all_single(recv_idx, send_local, recv, send, group=self.group)
+        return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm, n=idx.numel())
+
+    def _to_owners(self, rows_in_send_order: torch.Tensor, plan) -> torch.Tensor:
+        if self.G == 1:
+            return rows_in_send_order
+        out = torch.empty((sum(plan["recv"]),) + tuple(rows_in_send_order.shape[1:]), dtype=rows_in_send_order.dtype,
+                          device=rows_in_send_order.device)
+        dist.all_to_all_single(out, rows_in_send_order, plan["recv"], plan["send"], group=self.group)
+        return out
+
+    def _from_owners(self, rows_at_owner: torch.Tensor, plan) -> torch.Tensor:
+        if self.G == 1:
+            return rows_at_owner
+        out = torch.empty((plan["n"],) + tuple(rows_at_owner.shape[1:]), dtype=rows_at_owner.dtype,
+                          device=rows_at_owner.device)
+        dist.all_to_all_single(out, rows_at_owner, plan["send"], plan["recv"], group=self.group)
+        return out
+
+    def gather(self, plan) -> torch.Tensor:
+        """Rows for the planned index list, in the list's own order: [n, dim]."""
+        seg = self.ops.Segment(self.weight, plan["recv_idx"], 0)
+        mine = self.ops.gather_concat([seg], plan["recv_idx"].numel(), self.dim)
+        back = self._from_owners(mine, plan)
+        return self.ops.unpermute_rows(back, plan["perm"])
+
+    def scatter_grad(self, occ: torch.Tensor, plan):
+        """Send per-occurrence gradient rows (list order) to the owners and reduce / update there."""
+        sent = self.ops.permute_rows(occ.contiguous(), plan["perm"])
+        got = self._to_owners(sent, plan)
+        if got.shape[0] == 0:
+            return
+        si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
+        if self.rule is None:
+            if self.grad is None:
+                self.grad = torch.zeros_like(self.weight)
+            g = torch.zeros_like(self.weight)
+            self.ops.segreduce(got, si, _lib.RX_SEG_DENSE, g, dim=self.dim)
+            self.grad += g
+        else:
+            mode, lr, eps, state = self.rule
+            self.ops.segreduce(got, si, mode, self.weight, state=state, lr=lr, eps=eps, dim=self.dim)
+
+
+class _ShardedLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, table, idx):
+        plan = table.plan(idx)
+        ctx.table, ctx.plan = table, plan
+        return table.gather(plan)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.table.scatter_grad(g, ctx.plan)
+        return None, None, None
+
+
+def sharded_lookup(table: ShardedTable, idx: torch.Tensor, anchor: torch.Tensor) -> torch.Tensor:
+    """Differentiable lookup.  ``anchor`` is any tensor that requires grad (keeps the node in the
+    autograd graph; the table itself is updated by its owner inside backward)."""
+    return _ShardedLookup.apply(anchor, table, idx.reshape(-1).contiguous())
+
+
+class ShardedFieldFM(torch.nn.Module):
+    """26-field FM (see models.fields.FieldFM) over row-sharded feature and bias tables.  Each rank
+    feeds its own slice of the global batch; the FM interaction runs on the rows it received, with
+    the same rx_fm2 kernels (the received rows act as a batch-local table addressed by position)."""
+
+    def __init__(self, field_dims, embedding_dim, device, group=None, backend=None, full_state=None):
+        super().__init__()
+        self.field_dims = [int(x) for x in field_dims]
+        self.n_fields, self.dim = len(self.field_dims), embedding_dim
+        self.ops = backend if backend is not None else _ops()
+        n = sum(self.field_dims)
+        offs = [0]
+        for d in self.field_dims[:-1]:
+            offs.append(offs[-1] + d)
+        self.register_buffer("_offsets", torch.tensor(offs, dtype=torch.int64, device=device), persistent=False)
+        fw = full_state["feature_embedding.weight"] if full_state else None
+        bw = full_state["bias_embedding.weight"] if full_state else None
+        self.feature = ShardedTable(n, embedding_dim, device, group, backend, seed=1, full_weight=fw)
+        self.bias = ShardedTable(n, 1, device, group, backend, seed=2, full_weight=bw)
+        self._anchor = torch.nn.Parameter(torch.zeros(1, device=device))
+        self._pos = {}
+
+    def set_rule(self, kind, lr, eps=1e-10):
+        self.feature.set_rule(kind, lr, eps)
+        self.bias.set_rule(kind, lr, eps)
+
+    def _positions(self, B, device):
+        key = (B, str(device))
+        if key not in self._pos:
+            F = self.n_fields - 1
+            ex = torch.arange(B * F, device=device, dtype=torch.int64).reshape(B, F)
+            item = torch.arange(B * F, B * F + B, device=device, dtype=torch.int64).reshape(B, 1)
+            self._pos[key] = (ex, torch.zeros(F, dtype=torch.int64, device=device), item)
+        return self._pos[key]
+
+    def forward(self, inputs):
+        sparse = inputs["sparse"]
+        B, F = sparse.shape[0], self.n_fields - 1
+        glob = sparse + self._offsets[None, :]
+        # occurrence order of the FM kernels: all (b, f < F) first, then the last field's B entries
+        flat = torch.cat([glob[:, :F].reshape(-1), glob[:, F]]).contiguous()
+        rows = sharded_lookup(self.feature, flat, self._anchor)          # [B*(F+1), D]
+        bias = sharded_lookup(self.bias, flat, self._anchor)             # [B*(F+1), 1]
+        ex, base, item = self._positions(B, sparse.device)
+        return _LocalFM.apply(rows, bias, ex, base, item, self.ops)
+
+    def loss(self, inputs):
+        if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
+            return self.ops.bce_loss(self(inputs), inputs["label"])
+        from .autograd import bce_with_logits
+        return bce_with_logits(self(inputs), inputs["label"])
+
+
+class _LocalFM(torch.autograd.Function):
+    """FM over a batch-local row buffer (rows received from their owners)."""
+
+    @staticmethod
+    def forward(ctx, rows, bias, ex, base, item, ops):
+        logits, _ = ops.fm2_fwd(rows, bias.reshape(-1), ex, base, item, 0)
+        ctx.save_for_backward(rows, bias)
+        ctx.idx, ctx.ops = (ex, base, item), ops
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, bias = ctx.saved_tensors
+        ex, base, item = ctx.idx
+        occ, bias_occ = ctx.ops.fm2_bwd(g.contiguous(), None, rows, bias.reshape(-1), ex, base, item, 0)
+        return occ, bias_occ.reshape(-1, 1), None, None, None, None

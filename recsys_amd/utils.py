@@ -1,0 +1,93 @@
+"""Train / eval loop with the call contract of recsys/utils.py:61-117.
+
+``train_loop(model, data, optimizer, num_epochs, clip_norm, k=10)`` runs the reference's step order
+(zero_grad, loss, backward, global clip, step) and the same pre-training + per-epoch evaluation,
+with two differences that do not change results: the loss is accumulated on the device (one host
+sync per epoch instead of two per step, recsys/utils.py:105-106), and evaluation ranks on the
+device (rx_topk_codes) instead of numpy argsort on the host (recsys/utils.py:40-58).
+
+``optimizer`` is either a torch optimizer (dense gradients, the reference's way) or a
+``recsys_amd.optim.FusedOptimizer`` (clip handled inside its two-phase update).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .metrics import compute_metrics
+from .optim import FusedOptimizer
+
+
+def topk(scores, array=None, subset=None, k=10):
+    """Reference semantics (recsys/utils.py:40-58) for numpy arrays or GPU tensors: indices of the
+    k highest scores per row, mapped through ``array`` (or ``subset``) when given."""
+    if isinstance(scores, torch.Tensor) and scores.is_cuda:
+        if subset is not None:
+            subset = torch.as_tensor(subset, device=scores.device).long().contiguous()
+            scores = torch.gather(scores, 1, subset)
+            array = subset
+        codes = None if array is None else torch.as_tensor(array, device=scores.device).long().contiguous()
+        return ops.topk_codes(scores.float().contiguous(), codes, k)
+    scores = np.asarray(scores)
+    if subset is not None:
+        scores = np.take_along_axis(scores, subset, axis=1)
+        array = subset
+    order = np.argsort(scores, axis=1)[:, ::-1][:, :k]
+    return order if array is None else np.take_along_axis(array, order, axis=1)
+
+
+def load_model(model, device, **kwargs):
+    return model(**kwargs).to(device)
+
+
+def eval_loop(model, data, k, epoch=None, num_epochs=None, epoch_loss=None):
+    model.eval()
+    logits = []
+    with torch.no_grad():
+        for inputs in data.test_dataloader:
+            logits.append(model(inputs))
+        scores = torch.cat(logits, dim=0)
+        y_pred = topk(scores, array=data.test_codes, k=k)
+    if epoch:
+        print(f"epoch [{epoch + 1}/{num_epochs}], loss: {epoch_loss:.4f}")
+    return compute_metrics(data.test_true, y_pred)
+
+
+def train_step(model, optimizer, inputs, clip_norm):
+    """One batch of recsys/utils.py:96-103.  Returns the loss tensor (still on the device)."""
+    optimizer.zero_grad()
+    loss = model.loss(inputs)
+    loss.backward()
+    if isinstance(optimizer, FusedOptimizer):
+        optimizer.clip_norm = clip_norm
+    elif clip_norm is not None:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+    optimizer.step()
+    return loss.detach()
+
+
+def train_loop(model, data, optimizer, num_epochs, clip_norm, k=10):
+    history = []
+    data.create_test_dataloader()
+    eval_loop(model, data, k, epoch=None, num_epochs=None, epoch_loss=None)
+    on_gpu = next(model.parameters()).is_cuda
+    if on_gpu:
+        ops.set_index_check("deferred")
+    try:
+        for epoch in range(num_epochs):
+            model.train()
+            train_dl = data.create_negative_sampled_train_dataloader()
+            running = None
+            for inputs in train_dl:
+                loss = train_step(model, optimizer, inputs, clip_norm)
+                running = loss if running is None else running + loss
+            if on_gpu:
+                ops.raise_if_index_error()
+            epoch_loss = float(running.item()) / len(train_dl)
+            metrics = eval_loop(model, data, k, epoch=epoch, num_epochs=num_epochs, epoch_loss=epoch_loss)
+            history.append((epoch_loss,) + tuple(metrics))
+    finally:
+        if on_gpu:
+            ops.set_index_check("sync")
+    return history

@@ -1,0 +1,99 @@
+"""End-to-end pieces around the hot path on the GPU: the train / eval loop mirror, device-side
+ranking, the sharded table path at world size 1 with the real kernels."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_data():
+    from recsys_amd.dataset import ImplicitData, synthetic_ml1m_data
+    d = synthetic_ml1m_data(seed=3, n_users=400, n_items=300, n_occupations=7, n_train=12000, pool=60, n_test_codes=50)
+    return ImplicitData(d, device="cuda", train_batch_size=256, test_batch_size=128)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_train_loop_learns(fused, capsys):
+    """recsys/utils.py:84-117 call pattern: eval before training, then epochs of train + eval."""
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.utils import load_model, train_loop
+    torch.manual_seed(0)
+    data = _small_data()
+    model = load_model(NeuMF, "cuda", n_users=data.n_users, n_items=data.n_items, embedding_dim=16)
+    if fused:
+        opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    hist = train_loop(model, data, opt, num_epochs=4, clip_norm=1.0, k=10)
+    out = capsys.readouterr().out
+    assert out.count("metrics - ndcg@10") == 5 and "epoch [2/4], loss:" in out
+    losses = [h[0] for h in hist]
+    assert losses[-1] < losses[0] < 0.75
+    assert all(0.0 <= h[1] <= 1.0 and 0.0 <= h[2] <= 1.0 for h in hist)
+
+
+def test_eval_ranking_on_device_matches_host():
+    from recsys_amd.metrics import compute_metrics
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.utils import topk
+    torch.manual_seed(1)
+    data = _small_data()
+    data.create_test_dataloader()
+    model = VanillaMF(data.n_users, data.n_items, 32).cuda().eval()
+    with torch.no_grad():
+        scores = torch.cat([model(b) for b in data.test_dataloader])
+    assert scores.shape == (data.n_users, 50)
+    dev = topk(scores, array=data.test_codes, k=10).cpu().numpy()
+    host = topk(scores.cpu().numpy(), array=data.test_codes, k=10)
+    assert np.array_equal(dev, host)
+    a = compute_metrics(data.test_true, torch.from_numpy(dev).cuda())
+    b = compute_metrics(data.test_true, host)
+    assert a == b
+
+
+def test_epoch_loader_on_device():
+    data = _small_data()
+    dl = data.create_negative_sampled_train_dataloader()
+    n = 0
+    for b in dl:
+        assert all(v.is_cuda for v in b.values())
+        assert b["item_code"].dtype == torch.int64 and b["label"].dtype == torch.float64
+        n += b["user_code"].shape[0]
+    assert n == data.implicit_matrix.nnz and len(dl) == -(-n // 256)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", None])
+def test_sharded_fm_world1_matches_field_fm(kind):
+    """World size 1: the exchange degenerates to local permutations, all through the HIP kernels."""
+    from recsys_amd.models.fields import FieldFM
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.sharded import ShardedFieldFM
+    dims = [7, 1000, 13, 5000, 3, 211]
+    torch.manual_seed(2)
+    ref = FieldFM(dims, 16).cuda()
+    state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    sh = ShardedFieldFM(dims, 16, "cuda", full_state=state)
+    g = torch.Generator().manual_seed(4)
+    batch = {"sparse": torch.stack([torch.randint(0, d, (333,), generator=g) for d in dims], 1).cuda(),
+             "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
+    if kind:
+        opt = FusedOptimizer(ref, kind=kind, lr=0.1)
+        sh.set_rule(kind, 0.1)
+    for _ in range(2):
+        ref.zero_grad()
+        sh.feature.grad = sh.bias.grad = None
+        l1 = ref.loss(batch); l1.backward()
+        l2 = sh.loss(batch); l2.backward()
+        assert_close(l2.item(), l1.item(), rtol=1e-6, what="loss")
+        if kind:
+            opt.step()
+    if kind:
+        assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
+        assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
+    else:
+        assert_close(sh.feature.grad.cpu().numpy(), ref.feature_embedding.weight.grad.cpu().numpy(), what="grad rows")
+        assert_close(sh.bias.grad.cpu().numpy(), ref.bias_embedding.weight.grad.cpu().numpy(), what="grad bias")
