@@ -171,8 +171,10 @@ typedef struct {
 } rx_fm_args;
 #define RX_FM_NO_SECOND_ORDER 1
 
-int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, int32_t* err_flag,
-               int device, void* stream);
+/* d_tsum (may be NULL; N == 1 only) [B, dim] receives T_b = sum of all 1+F rows of sample b,
+ * the only per-sample state rx_segreduce_fm needs for the backward. */
+int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, float* d_tsum,
+               int32_t* err_flag, int device, void* stream);
 
 /* Backward given g [B,N] (and optionally d_deep [B*N,(1+F)*dim]):
  *   d_occ [(B*F + B*N), dim]: rows 0..B*F-1 = gradient of e_(b,f); then B*N item rows
@@ -244,6 +246,23 @@ int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
                  int mode, float* d_target, float* d_state, const float* d_occ2, float* d_target2,
                  float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
                  float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
+
+/* FM-fused variant for N == 1 (every sample contributes one row per field, e.g. the 26-field
+ * Criteo-shaped FM): the gradient of row r in sample b is g_b * (T_b - e_r), so
+ *   G_r = sum_b g_b T_b  -  (sum_b g_b) * e_r        and the bias gradient is sum_b g_b.
+ * Nothing per-occurrence is materialised: the reduce walks the same sorted runs but reads
+ * T [n_samples, dim] (row stride ld_T) and g [n_samples] (both cache resident), and subtracts
+ * the row's own term when it reads the row for the update.  The occurrence list behind the
+ * sort must be the rx_fm2_flat_indices order: n_samples*F entries (b, f) then n_samples item
+ * entries.  d_table: the feature table (needed to read e_r when `mode` writes a gradient
+ * buffer; ignored for the optimizer modes, which read d_target).  d_target2 / d_state2: the
+ * bias table (or its dense / compact gradient) and its Adagrad state, or NULL. */
+int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, int64_t n_samples, int32_t F,
+                    int32_t dim, const int32_t* d_sorted_pos, const int32_t* d_sorted_slot,
+                    const int64_t* d_uniq_rows, const int32_t* d_seg_off, const int32_t* d_n_uniq,
+                    int mode, float* d_target, float* d_state, const float* d_table, float* d_target2,
+                    float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
+                    float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
 
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above

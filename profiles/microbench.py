@@ -48,5 +48,13 @@ print(f"segreduce SGD+2       {timeit(lambda: ops.segreduce(occ, si, _lib.RX_SEG
 st = torch.zeros(rows, dim, device=dev)
 print(f"segreduce ADAGRAD     {timeit(lambda: ops.segreduce(occ, si, _lib.RX_SEG_ADAGRAD, table, state=st, lr=1e-3, eps=1e-10)):8.1f} us")
 print(f"row_update SGD        {timeit(lambda: ops.row_update(compact, si, _lib.RX_SEG_SGD, table, lr=1e-3)):8.1f} us")
+F = len(dims) - 1
+B = 65536
+flat_fm = torch.cat([(b["sparse"][:, :F] + offs[None, :F]).reshape(-1), b["sparse"][:, F] + offs[F]]).contiguous()
+si_fm = ops.sort_dedup(flat_fm, rows)
+T = torch.randn(B, dim, device=dev)
+gl = torch.randn(B, device=dev) / B
+print(f"segreduce_fm COMPACT+sq{timeit(lambda: ops.segreduce_fm(T, gl, F, si_fm, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2, want_sq=True)):8.1f} us")
+print(f"segreduce_fm SGD      {timeit(lambda: ops.segreduce_fm(T, gl, F, si_fm, _lib.RX_SEG_SGD, table, target2=table2, lr=1e-3)):8.1f} us")
 x = torch.empty(n * dim, device=dev)
 print(f"copy {n * dim * 4 / 1e6:.0f} MB (reference) {timeit(lambda: x.copy_(occ.view(-1))):8.1f} us")

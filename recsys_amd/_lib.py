@@ -50,7 +50,7 @@ PROTOTYPES = {
     "rx_colsum_partials": (C.c_int, [vp, i64, i32, vp, C.c_int, vp]),
     "rx_gmf_mul_fwd": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, i64, i32, vp, C.c_int, vp]),
     "rx_gmf_mul_bwd": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, i64, i32, vp, vp, C.c_int, vp]),
-    "rx_fm2_fwd": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, C.c_int, vp]),
+    "rx_fm2_fwd": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, C.c_int, vp]),
     "rx_fm2_bwd": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, C.c_int, vp]),
     "rx_fm2_flat_indices": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp]),
     "rx_bce_workspace_bytes": (sz, [i64]),
@@ -60,6 +60,7 @@ PROTOTYPES = {
     "rx_segreduce_grid": (i64, [i64, i32]),
     "rx_segreduce_workspace_bytes": (sz, [i64, i32]),
     "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
+    "rx_segreduce_fm": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
     "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),

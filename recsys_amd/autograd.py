@@ -84,21 +84,73 @@ class MFScore(Function):
 
 
 # ------------------------------------------------------------------ FM second order (+ DeepFM tower input)
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+class _AsyncSort:
+    """Index preparation for the backward (flat row ids -> sort -> dedup) depends on the batch's
+    indices only, so it is issued on a side HIP stream at forward time and overlaps the forward,
+    loss and interaction-backward kernels; the backward joins the stream before it reduces."""
+
+    def __init__(self, feat, ex_idx, ex_base, item_idx, item_base):
+        dev = feat.device
+        self.main = torch.cuda.current_stream(dev)
+        self.side = _side_stream(dev)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            flat = ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base)
+            self.si = ops.sort_dedup(flat, feat.shape[0])
+        self.flat = flat
+
+    def join(self) -> SortedIndex:
+        main = torch.cuda.current_stream(self.flat.device)
+        main.wait_stream(self.side)
+        for t in (self.si.sorted_pos, self.si.sorted_slot, self.si.uniq_rows, self.si.seg_off, self.si.n_uniq, self.flat):
+            t.record_stream(main)
+        return self.si
+
+
+def table_backward_fm(feat, bias_table, si: SortedIndex, tsum, g, n_fields_ex: int):
+    """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm)."""
+    rule = getattr(feat, "_rx_sparse", None)
+    if rule is not None:
+        rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex)
+        return None, None
+    grad = torch.zeros_like(feat)
+    grad2 = torch.zeros_like(bias_table) if bias_table is not None else None
+    ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2)
+    return grad, grad2
+
+
 class FM2(Function):
     """FM bias + second-order term over one shared table (rx_fm2_fwd / _bwd).  Returns
     ``(logits[B,N] or None, deep[B*N, deep_cols] or None)``.  ``deep`` holds the gathered rows
-    [item, field 0..F-1] in its first (1+F)*D columns; further columns (``deep_cols`` wider) start
+    [item, field 0..F-1] in its first (1+F)*D columns; further columns (``deep_cols`` wider)
     hold ``extra`` (dense features, which get no gradient)."""
 
     @staticmethod
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True,
                 deep_cols=None, want_logits=True, extra=None):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
-        logits, deep = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep,
-                                   second_order, deep_cols, want_logits, extra)
+        n_items = item_idx.shape[1] if item_idx.dim() == 2 else 1
+        # with one item per sample and no tower the backward needs only T_b = sum of the sample's rows
+        fused = n_items == 1 and second_order and want_logits and not want_deep
+        out = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep, second_order, deep_cols,
+                          want_logits, extra, want_tsum=fused)
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
         ctx.second_order = second_order
-        return logits, deep
+        ctx.tsum = out[2] if fused else None
+        ctx.sort = None
+        if ctx.needs_input_grad[4] and feat.is_cuda:
+            ctx.sort = _AsyncSort(feat, ex_idx, ex_base, item_idx, item_base)
+        return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g, g_deep):
@@ -107,16 +159,22 @@ class FM2(Function):
             g = g.contiguous()
         if g_deep is not None and g_deep.stride(-1) != 1:
             g_deep = g_deep.contiguous()
+        none_tail = (None,) * 5
+        if ctx.tsum is not None and g_deep is None and g is not None:
+            s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
+                ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])
+            gfeat, gbias = table_backward_fm(feat, bias_table, s, ctx.tsum, g.reshape(-1), ex_idx.shape[1])
+            return (None, None, None, None, gfeat, gbias) + none_tail
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         occ, bias_occ = ops.fm2_bwd(g, g_deep, feat, bias_flat, ex_idx, ex_base, item_idx, item_base,
                                     ctx.second_order)
-        flat = ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base)
-        s = ops.sort_dedup(flat, feat.shape[0])
+        s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
+            ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])
         if bias_table is not None:
             gfeat, gbias = table_backward(feat, s, occ, param2=bias_table, occ2=bias_occ)
         else:
             gfeat, gbias = table_backward(feat, s, occ), None
-        return (None, None, None, None, gfeat, gbias, None, None, None, None, None)
+        return (None, None, None, None, gfeat, gbias) + none_tail
 
 
 # ------------------------------------------------------------------ tower-input assembly

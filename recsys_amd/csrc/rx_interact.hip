@@ -367,8 +367,8 @@ extern "C" int rx_gmf_mul_bwd(const float* user_table, int64_t n_users, const fl
 // LDS with the field offsets already applied, by one coalesced sweep of all 256 lanes.
 template <int VEC, int CH>
 __global__ void __launch_bounds__(RX_BLOCK)
-fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ deep_out, int group,
-               int32_t* err_flag) {
+fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ deep_out,
+               float* __restrict__ tsum, int group, int32_t* err_flag) {
   extern __shared__ int64_t lds_idx[];  // [spb][F]
   const int spb = blockDim.x / group;
   const int64_t b0 = (int64_t)blockIdx.x * spb;
@@ -417,6 +417,11 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
     }
     acc = rx_group_sum(acc, group);
     if (deep_out) row_store<VEC, CH>(deep_out + (b * N + n) * deep_ld, v, lg, group, dim);
+    if (tsum) {  // N == 1 (checked on the host): the sum over all of the sample's rows
+      RowRegs<VEC, CH> t;
+      ROW_FOREACH(k, i) t.p[k].v[i] = S.p[k].v[i] + v.p[k].v[i];
+      row_store<VEC, CH>(tsum + b * dim, t, lg, group, dim);
+    }
     if (lg == 0 && logits) {
       float bt = bsum;
       if (a.bias && ok) bt += a.bias[row];
@@ -527,18 +532,19 @@ static int fm_launch_shape(const rx_fm_args* a, RxRowShape* sh, size_t* lds, con
   return 0;
 }
 
-extern "C" int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, int32_t* err_flag,
-                          int device, void* stream) {
+extern "C" int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, float* d_tsum,
+                          int32_t* err_flag, int device, void* stream) {
   RX_ENTER(device);
   if (fm_check(a, "rx_fm2_fwd")) return 1;
   RX_REQUIRE(d_logits || d_deep_out, "rx_fm2_fwd: neither logits nor deep_out requested");
+  RX_REQUIRE(!d_tsum || a->N == 1, "rx_fm2_fwd: the per-sample row sum is defined for N == 1 only");
   if (a->B == 0) return 0;
   RxRowShape sh;
   size_t lds;
   if (fm_launch_shape(a, &sh, &lds, "rx_fm2_fwd")) return 1;
   RX_REQUIRE(!d_deep_out || sh.vec == 1 || (rx_aligned16(d_deep_out) && a->deep_ld % 4 == 0), "rx_fm2_fwd: deep_out must be 16-byte aligned with deep_ld a multiple of 4");
   const unsigned grid = (unsigned)rx_cdiv(a->B, RX_BLOCK / sh.group);
-  RX_DISPATCH_SHAPE(sh, fm2_fwd_kernel, dim3(grid), dim3(RX_BLOCK), lds, (hipStream_t)stream, *a, d_logits, d_deep_out, sh.group, err_flag);
+  RX_DISPATCH_SHAPE(sh, fm2_fwd_kernel, dim3(grid), dim3(RX_BLOCK), lds, (hipStream_t)stream, *a, d_logits, d_deep_out, d_tsum, sh.group, err_flag);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -37,6 +37,13 @@ struct SegArgs {
   const float* occ2;
   float* target2;
   float* state2;
+  // FM-fused gradient synthesis (N = 1 factorization machine, see rx_segreduce_fm):
+  //   occurrence at list position p belongs to sample b(p) = p < fm_split ? p / fm_div : p - fm_split,
+  //   its gradient row is fm_g[b] * (occ[b, :] - table[row, :]); nothing per-occurrence is stored
+  const float* fm_g;      // [samples] dL/dlogit
+  const float* fm_table;  // table to read the old row from when `target` is a gradient buffer
+  int64_t fm_split;
+  int fm_div;
   // cross-piece workspace
   float* partials;    // [pieces][2][dim]
   float* partials2;   // [pieces][2]
@@ -62,9 +69,12 @@ __device__ __forceinline__ void apply_scalar(const SegArgs& a, float g, int64_t 
   }
 }
 
+// Writes the result for one row.  `x` is the row's current value and `st` its Adagrad state,
+// loaded by the caller ahead of time (the walk prefetches them with the occurrence rows so that
+// a flush never waits on a dependent HBM read); both are ignored by the gradient modes.
 template <int VEC, int CH, int MODE>
-__device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int64_t row, int64_t u, int lg,
-                                          float scale) {
+__device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, Acc<VEC, CH>& x, Acc<VEC, CH>& st,
+                                          int64_t row, int64_t u, int lg, float scale) {
   const int dim = a.dim, group = a.group;
   if constexpr (MODE == RX_SEG_DENSE || MODE == RX_SEG_COMPACT) {
     float* dst = a.target + (MODE == RX_SEG_DENSE ? row : u) * (int64_t)dim;
@@ -78,33 +88,18 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
   ACC_FOREACH(k, i) g.p[k].v[i] *= scale;
   float* w = a.target + row * (int64_t)dim;
   if constexpr (MODE == RX_SEG_SGD) {
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const int c = (lg + k * group) * VEC;
-      if (c < dim) {
-        RxPack<VEC> x = rx_load<VEC>(w + c);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) x.v[i] = x.v[i] - a.lr * g.p[k].v[i];
-        rx_store<VEC>(w + c, x);
-      }
-    }
+    ACC_FOREACH(k, i) x.p[k].v[i] = x.p[k].v[i] - a.lr * g.p[k].v[i];
   } else if constexpr (MODE == RX_SEG_ADAGRAD) {
-    float* st = a.state + row * (int64_t)dim;
+    ACC_FOREACH(k, i) {
+      const float gi = g.p[k].v[i];
+      st.p[k].v[i] += gi * gi;
+      x.p[k].v[i] -= a.lr * (gi / (sqrtf(st.p[k].v[i]) + a.eps));
+    }
+    float* sp = a.state + row * (int64_t)dim;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int c = (lg + k * group) * VEC;
-      if (c < dim) {
-        RxPack<VEC> x = rx_load<VEC>(w + c);
-        RxPack<VEC> s = rx_load<VEC>(st + c);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          const float gi = g.p[k].v[i];
-          s.v[i] += gi * gi;
-          x.v[i] -= a.lr * (gi / (sqrtf(s.v[i]) + a.eps));
-        }
-        rx_store<VEC>(st + c, s);
-        rx_store<VEC>(w + c, x);
-      }
+      if (c < dim) rx_store<VEC>(sp + c, st.p[k]);
     }
   } else if constexpr (MODE == RX_SEG_ROWWISE_ADAGRAD) {
     float sq = 0.f;
@@ -119,33 +114,37 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, int
     sq = rx_group_sum(sq, group);
     const float s_new = a.state[row] + sq / (float)dim;
     const float step = a.lr / (sqrtf(s_new) + a.eps);
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const int c = (lg + k * group) * VEC;
-      if (c < dim) {
-        RxPack<VEC> x = rx_load<VEC>(w + c);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) x.v[i] -= step * g.p[k].v[i];
-        rx_store<VEC>(w + c, x);
-      }
-    }
+    ACC_FOREACH(k, i) x.p[k].v[i] -= step * g.p[k].v[i];
     if (lg == 0) a.state[row] = s_new;
+  }
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = (lg + k * group) * VEC;
+    if (c < dim) rx_store<VEC>(w + c, x.p[k]);
   }
 }
 
-// Runs are cut at fixed position boundaries (SEG_CHUNK sorted positions per lane group), so a
-// row hit thousands of times (Zipf heads, tiny fields) costs no more wall time than a cold one:
-//   pass 1  one lane group per piece.  The block first stages its (slot, position) tile in LDS
-//           with one coalesced sweep; each group then walks its 32 positions in order, loading
-//           occurrence rows a batch at a time so several HBM reads are in flight.  A run that
-//           lies entirely inside the piece is finished and applied on the spot; a run that
-//           crosses a piece boundary leaves a partial sum in partials[piece][0 = entered from the
-//           left | 1 = leaves to the right], and the piece records the run that leaves it.
-//   pass 2  one wavefront per piece whose tail run continues: its 64/group lane slots add the
-//           run's partials (stride = slots, piece order inside a slot), a fixed xor tree joins
-//           the slots, and slot 0 applies the row.
-// The order of additions depends only on the sort, so results are bitwise reproducible.
-#define SEG_CHUNK 32
+// Loads the row's current value (and Adagrad state) for apply_row; columns past dim read column 0.
+template <int VEC, int CH, int MODE, bool FM>
+__device__ __forceinline__ void load_old(const SegArgs& a, int64_t row, int lg, Acc<VEC, CH>& x, Acc<VEC, CH>& st) {
+  constexpr bool OPT = MODE >= RX_SEG_SGD;
+  if constexpr (FM || OPT) {
+    const float* base = (OPT ? a.target : a.fm_table) + row * (int64_t)a.dim;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * a.group) * VEC;
+      x.p[k] = rx_load<VEC>(base + (c < a.dim ? c : 0));
+    }
+  }
+  if constexpr (MODE == RX_SEG_ADAGRAD) {
+    const float* base = a.state + row * (int64_t)a.dim;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * a.group) * VEC;
+      st.p[k] = rx_load<VEC>(base + (c < a.dim ? c : 0));
+    }
+  }
+}
 
 template <int VEC, int CH>
 __device__ __forceinline__ float acc_sq(const Acc<VEC, CH>& g, int lg, int group, int dim) {
@@ -161,6 +160,41 @@ __device__ __forceinline__ float acc_sq(const Acc<VEC, CH>& g, int lg, int group
   return sq;
 }
 
+// Everything that happens once a row's summed gradient is known.  FM: the sum so far is
+// sum_b g_b T_b; the row's own term (sum_b g_b) * e_row is subtracted here, where the old row is
+// read anyway for the update.
+template <int VEC, int CH, int MODE, bool FM>
+__device__ __forceinline__ float finish_run(const SegArgs& a, Acc<VEC, CH>& g, float g2, Acc<VEC, CH>& x,
+                                            Acc<VEC, CH>& st, int64_t row, int64_t u, int lg, float scale,
+                                            bool has2) {
+  const int dim = a.dim, group = a.group;
+  if constexpr (FM) ACC_FOREACH(k, i) g.p[k].v[i] -= g2 * x.p[k].v[i];
+  float sq = 0.f;
+  if (a.sq_part) {
+    sq = acc_sq<VEC, CH>(g, lg, group, dim);
+    if (has2 && lg == 0) sq += g2 * g2;
+  }
+  if (has2 && lg == 0) apply_scalar<MODE>(a, g2, row, u, scale);
+  apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, scale);
+  return sq;
+}
+
+// Runs are cut at fixed position boundaries (SEG_CHUNK sorted positions per lane group), so a
+// row hit thousands of times (Zipf heads, tiny fields) costs no more wall time than a cold one:
+//   pass 1  one lane group per piece.  The block first stages its (slot, position) tile in LDS
+//           with one coalesced sweep; each group then walks its 32 positions in order, loading
+//           occurrence rows a batch at a time so several HBM reads are in flight.  A run that
+//           lies entirely inside the piece is finished and applied on the spot; a run that
+//           crosses a piece boundary leaves a partial sum in partials[piece][0 = entered from the
+//           left | 1 = leaves to the right], and the piece records the run that leaves it.
+//   pass 2  one wavefront per piece whose tail run continues: its 64/group lane slots add the
+//           run's partials (stride = slots, piece order inside a slot), a fixed xor tree joins
+//           the slots, and slot 0 applies the row.
+// The order of additions depends only on the sort, so results are bitwise reproducible.
+#ifndef SEG_CHUNK
+#define SEG_CHUNK 32
+#endif
+
 __device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* sq_lds) {
   sq = rx_wave_sum(sq);
   if ((threadIdx.x & 63) == 0) sq_lds[threadIdx.x >> 6] = sq;
@@ -168,7 +202,7 @@ __device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* 
   if (threadIdx.x == 0) sq_part[blockIdx.x] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
 }
 
-template <int VEC, int CH, int MODE>
+template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_kernel(SegArgs a) {
   // LDS tile of the block's sorted positions, staged by one coalesced sweep:
@@ -185,13 +219,35 @@ segreduce_chunk_kernel(SegArgs a) {
   uint32_t* rowid = reinterpret_cast<uint32_t*>(meta + T + 2);
   const int64_t piece0 = (int64_t)blockIdx.x * gpb;
   {
+    // Eight entries per thread and round: all index loads of a round are issued before the
+    // dependent row-id gathers, and those before the LDS stores, so a round costs two memory
+    // latencies instead of two per entry.
     const int64_t base = piece0 * SEG_CHUNK;
-    for (int j = threadIdx.x; j < T + 2; j += RX_BLOCK) {
-      const int64_t p = base + j - 1;
-      int2 m = make_int2(-1, 0);
-      if (p >= 0 && p < a.n) m = make_int2(a.sorted_slot[p], a.sorted_pos[p]);
-      meta[j] = m;
-      if (j >= 1 && j <= T) rowid[j - 1] = m.x >= 0 ? (uint32_t)a.uniq_rows[m.x] : 0u;
+    for (int j0 = 0; j0 < T + 2; j0 += 8 * RX_BLOCK) {
+      int sl[8], ps[8];
+      uint32_t rw[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j = j0 + r * RX_BLOCK + threadIdx.x;
+        int64_t p = base + j - 1;
+        const bool ok = j < T + 2 && p >= 0 && p < a.n;
+        p = ok ? p : 0;
+        sl[r] = a.sorted_slot[p];
+        ps[r] = a.sorted_pos[p];
+        if (!ok) sl[r] = -1;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rw[r] = (uint32_t)a.uniq_rows[sl[r] >= 0 ? sl[r] : 0];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int j = j0 + r * RX_BLOCK + threadIdx.x;
+        if (j < T + 2) {
+          int pos = ps[r];
+          if (FM) pos = pos < a.fm_split ? pos / a.fm_div : pos - (int)a.fm_split;  // sample of the occurrence
+          meta[j] = make_int2(sl[r], sl[r] >= 0 ? pos : 0);
+          if (j >= 1 && j <= T) rowid[j - 1] = sl[r] >= 0 ? rw[r] : 0u;
+        }
+      }
     }
   }
   __syncthreads();
@@ -212,20 +268,18 @@ segreduce_chunk_kernel(SegArgs a) {
     int cur = mine[0].x;
     int run_start = 0;
     int tail = -1;
+    Acc<VEC, CH> cur_x, cur_st;                 // current value / state of the running row
+    ACC_FOREACH(k, i) { cur_x.p[k].v[i] = 0.f; cur_st.p[k].v[i] = 0.f; }
+    const bool has2 = a.target2 != nullptr;     // a companion table is updated
+    const bool keep2 = FM || has2;              // the scalar sum is needed (FM: for the row's own term)
+    const float* src2 = FM ? a.fm_g : a.occ2;
     // flush the run of slot u that covers piece positions [run_start, end)
     auto flush = [&](int u, int end) {
       const bool entered = (run_start == 0) && (left == u);
       const bool leaves = (end == len) && (right == u);
       if (!entered && !leaves) {
         const int64_t row = (int64_t)myrow[run_start];
-        if (a.sq_part) {
-          sq += acc_sq<VEC, CH>(g, lg, group, dim);
-          if (a.occ2 && lg == 0) sq += g2 * g2;
-        }
-        if (row < a.n_rows) {
-          if (a.occ2 && lg == 0) apply_scalar<MODE>(a, g2, row, u, scale);
-          apply_row<VEC, CH, MODE>(a, g, row, u, lg, scale);
-        }
+        if (row < a.n_rows) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, cur_x, cur_st, row, u, lg, scale, has2);
       } else {
         const int side = entered ? 0 : 1;
         float* dst = a.partials + (piece * 2 + side) * (int64_t)dim;
@@ -234,7 +288,7 @@ segreduce_chunk_kernel(SegArgs a) {
           const int c = (lg + k * group) * VEC;
           if (c < dim) rx_store<VEC>(dst + c, g.p[k]);
         }
-        if (a.occ2 && lg == 0) a.partials2[piece * 2 + side] = g2;
+        if (keep2 && lg == 0) a.partials2[piece * 2 + side] = g2;
         if (side == 1) tail = u;
       }
       ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
@@ -252,12 +306,11 @@ segreduce_chunk_kernel(SegArgs a) {
       col_ok[k] = c < dim;
       col[k] = col_ok[k] ? c : 0;
     }
-    const bool has2 = a.occ2 != nullptr;
 #pragma unroll 1
     for (int b0 = 0; b0 < SEG_CHUNK; b0 += BATCH) {
       if (b0 >= len) break;
       int sl[BATCH];
-      Acc<VEC, CH> rows[BATCH];
+      Acc<VEC, CH> rows[BATCH], oldx[BATCH], oldst[BATCH];
       float s2[BATCH];
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
@@ -267,7 +320,22 @@ segreduce_chunk_kernel(SegArgs a) {
         const float* src = a.occ + (int64_t)m.y * a.occ_ld;
 #pragma unroll
         for (int k = 0; k < CH; ++k) rows[j].p[k] = rx_load<VEC>(src + col[k]);
-        s2[j] = has2 ? a.occ2[m.y] : 0.f;
+        s2[j] = keep2 ? src2[m.y] : 0.f;
+        // the row's current value (and state) ride along, so that a flush has them at hand
+        const uint32_t r = myrow[jj];
+        load_old<VEC, CH, MODE, FM>(a, r < a.n_rows ? (int64_t)r : 0, lg, oldx[j], oldst[j]);
+      }
+      // Retire every load of the batch here.  vmcnt counts loads and stores in one queue, and the
+      // flushes below store under run-time branches; a load still pending behind such a store
+      // would make each later use wait for the store's round trip as well.
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        asm volatile("" ::"v"(s2[j]));
+        ACC_FOREACH(k, i) {
+          asm volatile("" ::"v"(rows[j].p[k].v[i]));
+          if constexpr (FM || MODE >= RX_SEG_SGD) asm volatile("" ::"v"(oldx[j].p[k].v[i]));
+          if constexpr (MODE == RX_SEG_ADAGRAD) asm volatile("" ::"v"(oldst[j].p[k].v[i]));
+        }
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
@@ -276,11 +344,15 @@ segreduce_chunk_kernel(SegArgs a) {
             flush(cur, b0 + j);
             cur = sl[j];
           }
+          if (b0 + j == run_start) { cur_x = oldx[j]; cur_st = oldst[j]; }
 #pragma unroll
           for (int k = 0; k < CH; ++k) {
             if (col_ok[k]) {
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) g.p[k].v[i] += rows[j].p[k].v[i];
+              for (int i = 0; i < VEC; ++i) {
+                if constexpr (FM) g.p[k].v[i] += s2[j] * rows[j].p[k].v[i];
+                else g.p[k].v[i] += rows[j].p[k].v[i];
+              }
             }
           }
           g2 += s2[j];
@@ -293,7 +365,7 @@ segreduce_chunk_kernel(SegArgs a) {
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
 }
 
-template <int VEC, int CH, int MODE>
+template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
   __shared__ float sq_lds[RX_BLOCK / 64];
@@ -308,6 +380,8 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
     const int n_parts = (int)(last - piece) + 1;
     const int slots = 64 / group;
     const int s = lane / group, lg = lane % group;
+    const bool has2 = a.target2 != nullptr;
+    const bool keep2 = FM || has2;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
@@ -323,22 +397,20 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
           for (int i = 0; i < VEC; ++i) g.p[k].v[i] += x.v[i];
         }
       }
-      if (a.occ2 && lg == 0) g2 += a.partials2[e];
+      if (keep2 && lg == 0) g2 += a.partials2[e];
     }
     for (int m = group; m < 64; m <<= 1) {
       ACC_FOREACH(k, i) g.p[k].v[i] += __shfl_xor(g.p[k].v[i], m, 64);
       g2 += __shfl_xor(g2, m, 64);
     }
+    if (FM) g2 = __shfl(g2, lane - lg, 64);  // every lane of a group needs the scalar sum
     if (s == 0) {
       const int64_t row = a.uniq_rows[u];
-      if (a.sq_part) {
-        sq = acc_sq<VEC, CH>(g, lg, group, dim);
-        if (a.occ2 && lg == 0) sq += g2 * g2;
-      }
       if (row >= 0 && row < a.n_rows) {
-        const float scale = a.scale ? a.scale[0] : 1.f;
-        if (a.occ2 && lg == 0) apply_scalar<MODE>(a, g2, row, u, scale);
-        apply_row<VEC, CH, MODE>(a, g, row, u, lg, scale);
+        Acc<VEC, CH> x, st;
+        ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
+        load_old<VEC, CH, MODE, FM>(a, row, lg, x, st);
+        sq = finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, a.scale ? a.scale[0] : 1.f, has2);
       }
     }
   }
@@ -381,30 +453,68 @@ extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
          rx_align_up(pieces * sizeof(int32_t), 256);
 }
 
-#define SEG_DISPATCH_M(M, sh, KERNEL, grid, lds, st, ...)                                          \
+#define SEG_DISPATCH_MF(M, FMV, sh, KERNEL, grid, lds, st, ...)                                    \
   do {                                                                                             \
-    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<1, 4, M>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__);       \
+    if ((sh).vec == 4 && (sh).chunks == 1) hipLaunchKernelGGL((KERNEL<4, 1, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4 && (sh).chunks == 2) hipLaunchKernelGGL((KERNEL<4, 2, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).vec == 4) hipLaunchKernelGGL((KERNEL<4, 4, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 1) hipLaunchKernelGGL((KERNEL<1, 1, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else if ((sh).chunks == 2) hipLaunchKernelGGL((KERNEL<1, 2, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<1, 4, M, FMV>), grid, dim3(RX_BLOCK), lds, st, __VA_ARGS__);  \
   } while (0)
 
-#define SEG_DISPATCH(mode, sh, KERNEL, grid, lds, st, ...)                                         \
+#define SEG_DISPATCH_F(mode, FMV, sh, KERNEL, grid, lds, st, ...)                                  \
   do {                                                                                             \
     switch (mode) {                                                                                \
-      case RX_SEG_DENSE: SEG_DISPATCH_M(RX_SEG_DENSE, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
-      case RX_SEG_COMPACT: SEG_DISPATCH_M(RX_SEG_COMPACT, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
-      case RX_SEG_SGD: SEG_DISPATCH_M(RX_SEG_SGD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break;  \
-      case RX_SEG_ADAGRAD: SEG_DISPATCH_M(RX_SEG_ADAGRAD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
-      default: SEG_DISPATCH_M(RX_SEG_ROWWISE_ADAGRAD, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_DENSE: SEG_DISPATCH_MF(RX_SEG_DENSE, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_COMPACT: SEG_DISPATCH_MF(RX_SEG_COMPACT, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_SGD: SEG_DISPATCH_MF(RX_SEG_SGD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_ADAGRAD: SEG_DISPATCH_MF(RX_SEG_ADAGRAD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      default: SEG_DISPATCH_MF(RX_SEG_ROWWISE_ADAGRAD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
     }                                                                                              \
+  } while (0)
+
+#define SEG_DISPATCH(mode, fm, sh, KERNEL, grid, lds, st, ...)                                     \
+  do {                                                                                             \
+    if (fm) SEG_DISPATCH_F(mode, true, sh, KERNEL, grid, lds, st, __VA_ARGS__);                    \
+    else SEG_DISPATCH_F(mode, false, sh, KERNEL, grid, lds, st, __VA_ARGS__);                      \
   } while (0)
 
 static int mode_check(int mode, const float* state, const char* who, bool allow_grad_modes) {
   RX_REQUIRE(mode >= (allow_grad_modes ? RX_SEG_DENSE : RX_SEG_SGD) && mode <= RX_SEG_ROWWISE_ADAGRAD, "%s: unknown mode %d", who, mode);
   RX_REQUIRE(!(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || state, "%s: Adagrad needs a state buffer", who);
+  return 0;
+}
+
+// Shared driver of rx_segreduce and rx_segreduce_fm.
+static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int64_t n = a.n;
+  const int dim = a.dim;
+  RX_REQUIRE(n >= 0 && dim >= 1 && dim <= RX_MAX_DIM && a.occ_ld >= dim, "%s: bad shape n=%lld dim=%d ld=%lld", who, (long long)n, dim, (long long)a.occ_ld);
+  if (mode_check(a.mode, a.state, who, true)) return 1;
+  RX_REQUIRE(fm || (a.occ2 == nullptr) == (a.target2 == nullptr), "%s: companion gradient and target come as a pair", who);
+  RX_REQUIRE(!a.target2 || !(a.mode == RX_SEG_ADAGRAD || a.mode == RX_SEG_ROWWISE_ADAGRAD) || a.state2, "%s: companion Adagrad state missing", who);
+  if (n == 0) return 0;
+  RX_REQUIRE(a.occ && a.sorted_pos && a.sorted_slot && a.uniq_rows && a.seg_off && a.n_uniq && a.target && ws, "%s: null argument", who);
+  RX_REQUIRE(a.n_rows >= 1, "%s: n_rows must be positive", who);
+  RX_REQUIRE(ws_bytes >= rx_segreduce_workspace_bytes(n, dim) && rx_aligned16(ws), "%s: workspace too small or unaligned", who);
+  RxRowShape sh;
+  if (seg_shape(dim, a.occ_ld, a.occ, a.target, a.mode == RX_SEG_ADAGRAD ? a.state : nullptr, &sh, who)) return 1;
+  RX_REQUIRE(!fm || sh.vec == 1 || !a.fm_table || rx_aligned16(a.fm_table), "%s: table must be 16-byte aligned", who);
+  const size_t pieces = (size_t)seg_pieces(n);
+  char* w = (char*)ws;
+  a.partials = (float*)w; w += rx_align_up(pieces * 2 * dim * sizeof(float), 256);
+  a.partials2 = (float*)w; w += rx_align_up(pieces * 2 * sizeof(float), 256);
+  a.tail_row = (int32_t*)w;
+  a.group = sh.group;
+  const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n);
+  const size_t tile = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK;
+  const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
+  SEG_DISPATCH(a.mode, fm, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
+  RX_LAUNCH_CHECK();
+  if (a.sq_part) a.sq_part = a.sq_part + g1;
+  SEG_DISPATCH(a.mode, fm, sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
+  RX_LAUNCH_CHECK();
   return 0;
 }
 
@@ -416,38 +526,40 @@ extern "C" int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32
                             float lr, float eps, const float* d_scale, float* d_sq_part, void* ws,
                             size_t ws_bytes, int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(n >= 0 && dim >= 1 && dim <= RX_MAX_DIM && occ_ld >= dim, "rx_segreduce: bad shape n=%lld dim=%d ld=%lld", (long long)n, dim, (long long)occ_ld);
-  if (mode_check(mode, d_state, "rx_segreduce", true)) return 1;
-  RX_REQUIRE((d_occ2 == nullptr) == (d_target2 == nullptr), "rx_segreduce: companion gradient and target come as a pair");
-  RX_REQUIRE(!d_occ2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || d_state2, "rx_segreduce: companion Adagrad state missing");
-  if (n == 0) return 0;
-  RX_REQUIRE(d_occ && d_sorted_pos && d_sorted_slot && d_uniq_rows && d_seg_off && d_n_uniq && d_target && ws, "rx_segreduce: null argument");
-  RX_REQUIRE(n_rows >= 1, "rx_segreduce: n_rows must be positive");
-  RX_REQUIRE(ws_bytes >= rx_segreduce_workspace_bytes(n, dim) && rx_aligned16(ws), "rx_segreduce: workspace too small or unaligned");
-  RxRowShape sh;
-  if (seg_shape(dim, occ_ld, d_occ, d_target, mode == RX_SEG_ADAGRAD ? d_state : nullptr, &sh, "rx_segreduce")) return 1;
-  const size_t pieces = (size_t)seg_pieces(n);
-  char* w = (char*)ws;
-  float* partials = (float*)w; w += rx_align_up(pieces * 2 * dim * sizeof(float), 256);
-  float* partials2 = (float*)w; w += rx_align_up(pieces * 2 * sizeof(float), 256);
-  int32_t* tail_row = (int32_t*)w;
-  SegArgs a{d_occ, occ_ld, n, dim, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, mode, d_target,
-            d_state, n_rows, lr, eps, d_scale, d_sq_part, sh.group, d_occ2, d_target2, d_state2, partials,
-            partials2, tail_row};
-  const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n);
-  const size_t tile = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK;
-  const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
-  hipStream_t st = (hipStream_t)stream;
-  SEG_DISPATCH(mode, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
-  RX_LAUNCH_CHECK();
-  if (d_sq_part) a.sq_part = d_sq_part + g1;
-  SEG_DISPATCH(mode, sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
-  RX_LAUNCH_CHECK();
-  return 0;
+  SegArgs a{};
+  a.occ = d_occ; a.occ_ld = occ_ld; a.n = n; a.dim = dim;
+  a.sorted_pos = d_sorted_pos; a.sorted_slot = d_sorted_slot; a.uniq_rows = d_uniq_rows;
+  a.seg_off = d_seg_off; a.n_uniq = d_n_uniq; a.mode = mode; a.target = d_target; a.state = d_state;
+  a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale; a.sq_part = d_sq_part;
+  a.occ2 = d_occ2; a.target2 = d_target2; a.state2 = d_state2;
+  return segreduce_run(a, false, "rx_segreduce", ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, int64_t n_samples,
+                               int32_t F, int32_t dim, const int32_t* d_sorted_pos,
+                               const int32_t* d_sorted_slot, const int64_t* d_uniq_rows,
+                               const int32_t* d_seg_off, const int32_t* d_n_uniq, int mode,
+                               float* d_target, float* d_state, const float* d_table, float* d_target2,
+                               float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
+                               float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n_samples >= 0 && F >= 1, "rx_segreduce_fm: bad shape");
+  RX_REQUIRE(d_g || n_samples == 0, "rx_segreduce_fm: null logit gradient");
+  RX_REQUIRE(n_samples * (int64_t)(F + 1) < (1ll << 31), "rx_segreduce_fm: too many occurrences");
+  const bool grad_mode = mode == RX_SEG_DENSE || mode == RX_SEG_COMPACT;
+  RX_REQUIRE(!grad_mode || d_table, "rx_segreduce_fm: gradient modes need the table to read rows from");
+  SegArgs a{};
+  a.occ = d_T; a.occ_ld = ld_T; a.n = n_samples * (int64_t)(F + 1); a.dim = dim;
+  a.sorted_pos = d_sorted_pos; a.sorted_slot = d_sorted_slot; a.uniq_rows = d_uniq_rows;
+  a.seg_off = d_seg_off; a.n_uniq = d_n_uniq; a.mode = mode; a.target = d_target; a.state = d_state;
+  a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale; a.sq_part = d_sq_part;
+  a.occ2 = nullptr; a.target2 = d_target2; a.state2 = d_state2;
+  a.fm_g = d_g; a.fm_table = d_table; a.fm_split = n_samples * (int64_t)F; a.fm_div = F;
+  return segreduce_run(a, true, "rx_segreduce_fm", ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- update from a compact gradient
-template <int VEC, int CH, int MODE>
+template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 row_update_kernel(SegArgs a) {
   const int group = a.group, dim = a.dim;
@@ -463,7 +575,10 @@ row_update_kernel(SegArgs a) {
     const int c = (lg + k * group) * VEC;
     g.p[k] = (c < dim) ? rx_load<VEC>(a.occ + u * (int64_t)dim + c) : rx_zero<VEC>();
   }
-  apply_row<VEC, CH, MODE>(a, g, row, u, lg, a.scale ? a.scale[0] : 1.f);
+  Acc<VEC, CH> x, st;
+  ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
+  load_old<VEC, CH, MODE, false>(a, row, lg, x, st);
+  apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, a.scale ? a.scale[0] : 1.f);
 }
 
 extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
@@ -477,10 +592,12 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   RX_REQUIRE(d_compact && d_uniq_rows && d_n_uniq && d_w && n_rows >= 1, "rx_row_update: null argument");
   RxRowShape sh;
   if (seg_shape(dim, dim, d_compact, d_w, mode == RX_SEG_ADAGRAD ? d_state : nullptr, &sh, "rx_row_update")) return 1;
-  SegArgs a{d_compact, dim, n_max, dim, nullptr, nullptr, d_uniq_rows, nullptr, d_n_uniq, mode, d_w, d_state,
-            n_rows, lr, eps, d_scale, nullptr, sh.group, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  SegArgs a{};
+  a.occ = d_compact; a.occ_ld = dim; a.n = n_max; a.dim = dim; a.uniq_rows = d_uniq_rows; a.n_uniq = d_n_uniq;
+  a.mode = mode; a.target = d_w; a.state = d_state; a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
+  a.group = sh.group;
   const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
-  SEG_DISPATCH(mode, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
+  SEG_DISPATCH_F(mode, false, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
   RX_LAUNCH_CHECK();
   return 0;
 }

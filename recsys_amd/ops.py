@@ -315,7 +315,7 @@ def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order
 
 def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base: int, want_deep: bool = False,
             second_order: bool = True, deep_cols: Optional[int] = None, want_logits: bool = True,
-            extra: Optional[Tensor] = None):
+            extra: Optional[Tensor] = None, want_tsum: bool = False):
     """``deep_cols`` > (1+F)*dim allocates a wider tower-input buffer whose spare columns receive
     ``extra`` (dense features, fp32 [B*N, deep_cols - (1+F)*dim]); the buffer's row stride is
     rounded up to a multiple of 4 floats."""
@@ -335,10 +335,11 @@ def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base: int, want_deep: bo
             if extra is None or tuple(extra.shape) != (B * N, cols - (1 + F) * dim) or extra.dtype != torch.float32:
                 raise ValueError("extra: expected fp32 [B*N, deep_cols - (1+F)*dim]")
             buf[:, (1 + F) * dim:cols].copy_(extra)
-    check(lib.rx_fm2_fwd(C.byref(a), _p(logits), _p(deep), _p(_err_flag(feat.device)), _dev(feat), _stream(feat)),
-          "rx_fm2_fwd")
+    tsum = torch.empty(B, dim, dtype=torch.float32, device=feat.device) if want_tsum else None
+    check(lib.rx_fm2_fwd(C.byref(a), _p(logits), _p(deep), _p(tsum), _p(_err_flag(feat.device)), _dev(feat),
+                         _stream(feat)), "rx_fm2_fwd")
     _after_index_op(feat.device)
-    return logits, deep
+    return (logits, deep, tsum) if want_tsum else (logits, deep)
 
 
 def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True):
@@ -455,6 +456,26 @@ def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state:
                            _p(si.seg_off), _p(si.n_uniq), mode, _p(target), _p(state), _p(occ2), _p(target2),
                            _p(state2), si.n_rows, lr, eps, _p(scale), _p(sq), _p(ws), ws.numel(), _dev(occ),
                            _stream(occ)), "rx_segreduce")
+    return sq
+
+
+def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mode: int, target: Tensor, *,
+                 table: Optional[Tensor] = None, state: Optional[Tensor] = None, target2: Optional[Tensor] = None,
+                 state2: Optional[Tensor] = None, lr: float = 0.0, eps: float = 0.0,
+                 scale: Optional[Tensor] = None, want_sq: bool = False) -> Optional[Tensor]:
+    """rx_segreduce_fm: N == 1 FM backward straight from T [B, D] and g [B] (no per-occurrence rows)."""
+    _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
+    B, dim = tsum.shape
+    if g.numel() != B or si.n != B * (n_fields_ex + 1):
+        raise ValueError("segreduce_fm: shapes disagree with the sorted occurrence list")
+    sq = None
+    if want_sq:
+        sq = torch.empty(max(int(lib.rx_segreduce_grid(si.n, dim)), 1), dtype=torch.float32, device=tsum.device)
+    ws = _ws(int(lib.rx_segreduce_workspace_bytes(si.n, dim)), tsum.device)
+    check(lib.rx_segreduce_fm(_p(tsum), tsum.stride(0), _p(g), B, n_fields_ex, dim, _p(si.sorted_pos),
+                              _p(si.sorted_slot), _p(si.uniq_rows), _p(si.seg_off), _p(si.n_uniq), mode, _p(target),
+                              _p(state), _p(table), _p(target2), _p(state2), si.n_rows, lr, eps, _p(scale), _p(sq),
+                              _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_segreduce_fm")
     return sq
 
 

@@ -60,6 +60,30 @@ class SparseRule:
             self.owner._pending.append((rule2, param2, compact2, si, None))
 
 
+def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex):
+    """N == 1 FM: reduce + update straight from T and g (rx_segreduce_fm)."""
+    table, state = feat.data, self._state_for(feat)
+    rule2 = getattr(bias_table, "_rx_sparse", None) if bias_table is not None else None
+    if bias_table is not None and rule2 is None:
+        raise RuntimeError("companion table must carry a sparse rule when its main table does")
+    table2 = bias_table.data if bias_table is not None else None
+    state2 = rule2._state_for(bias_table) if rule2 is not None else None
+    if self.owner.clip_norm is None:
+        ops.segreduce_fm(tsum, g, n_fields_ex, si, self.mode, table, state=state, target2=table2, state2=state2,
+                         lr=self.lr, eps=self.eps)
+        return
+    compact = torch.empty(max(si.n, 1), tsum.shape[1], dtype=torch.float32, device=table.device)
+    compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
+    sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2,
+                          want_sq=True)
+    self.owner._pending.append((self, feat, compact, si, sq))
+    if bias_table is not None:
+        self.owner._pending.append((rule2, bias_table, compact2, si, None))
+
+
+SparseRule.apply_fm = _rule_apply_fm
+
+
 class FusedOptimizer:
     """``FusedOptimizer(model, kind, lr, clip_norm=None, dense_kind=None)``.
 

@@ -330,3 +330,46 @@ def test_segreduce_companion_and_long_runs(ops, skew, mode):
         assert_close(st.cpu().numpy(), (G ** 2).numpy(), what="adagrad state")
         assert_close(w.cpu().numpy(), (w0.double() - lr * G / (G.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad rows")
         assert_close(b.cpu().numpy()[:, 0], (b0[:, 0].double() - lr * G2 / (G2.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad companion")
+
+
+@pytest.mark.parametrize("mode", ["dense", "sgd", "adagrad", "compact"])
+def test_segreduce_fm_matches_materialised_path(ops, mode):
+    """rx_segreduce_fm (gradient synthesised from T and g) against rx_fm2_bwd + rx_segreduce."""
+    from recsys_amd import _lib
+    g0 = _gen(31)
+    dims, dim, B = [4, 300, 9, 2000, 50], 16, 3000
+    F = len(dims) - 1
+    n_feat = sum(dims)
+    feat = torch.randn(n_feat, dim, generator=g0).cuda()
+    bias = torch.randn(n_feat, generator=g0).cuda()
+    sparse = torch.stack([(torch.rand(B, generator=g0) ** 3 * d).long().clamp_(0, d - 1) for d in dims], 1).cuda()
+    base = torch.tensor([0] + dims[:-1]).cumsum(0)
+    ex_base, item_base = base[:F].cuda(), int(base[F])
+    ex, item = sparse[:, :F], sparse[:, F:]
+    logits, _, tsum = ops.fm2_fwd(feat, bias, ex, ex_base, item, item_base, want_tsum=True)
+    g = torch.randn(B, 1, generator=g0).cuda() / B
+    occ, bias_occ = ops.fm2_bwd(g, None, feat, bias, ex, ex_base, item, item_base)
+    si = ops.sort_dedup(ops.fm2_flat_indices(feat, ex, ex_base, item, item_base), n_feat)
+    lr = 0.2
+    if mode == "dense":
+        a, a2 = torch.zeros_like(feat), torch.zeros(n_feat, 1).cuda()
+        b, b2 = torch.zeros_like(feat), torch.zeros(n_feat, 1).cuda()
+        ops.segreduce(occ, si, _lib.RX_SEG_DENSE, a, occ2=bias_occ, target2=a2)
+        ops.segreduce_fm(tsum, g.reshape(-1), F, si, _lib.RX_SEG_DENSE, b, table=feat, target2=b2)
+    elif mode == "compact":
+        a, a2 = torch.zeros(si.n, dim).cuda(), torch.zeros(si.n).cuda()
+        b, b2 = torch.zeros(si.n, dim).cuda(), torch.zeros(si.n).cuda()
+        sa = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, a, occ2=bias_occ, target2=a2, want_sq=True)
+        sb = ops.segreduce_fm(tsum, g.reshape(-1), F, si, _lib.RX_SEG_COMPACT, b, table=feat, target2=b2, want_sq=True)
+        assert_close(float(sb.double().sum()), float(sa.double().sum()), what="sum of squares")
+        nu = int(si.n_uniq.item())
+        a, a2, b, b2 = a[:nu], a2[:nu], b[:nu], b2[:nu]
+    else:
+        code = _lib.RX_SEG_SGD if mode == "sgd" else _lib.RX_SEG_ADAGRAD
+        a, a2, b, b2 = feat.clone(), bias.clone().reshape(-1, 1), feat.clone(), bias.clone().reshape(-1, 1)
+        st = [torch.zeros_like(x) for x in (a, a2, b, b2)] if mode == "adagrad" else [None] * 4
+        ops.segreduce(occ, si, code, a, state=st[0], lr=lr, eps=1e-10, occ2=bias_occ, target2=a2, state2=st[1])
+        ops.segreduce_fm(tsum, g.reshape(-1), F, si, code, b, state=st[2], lr=lr, eps=1e-10, target2=b2, state2=st[3])
+    rt = 1e-4 if mode == "adagrad" else 1e-5
+    assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=rt, what=f"{mode} rows", atol=1e-9)
+    assert_close(b2.cpu().numpy(), a2.cpu().numpy(), rtol=rt, what=f"{mode} bias", atol=1e-9)
