@@ -117,6 +117,17 @@ class _AsyncSort:
         return self.si
 
 
+class Presort:
+    """Index preparation done ahead of the step (see HotPathModule.prepare): the flat row-id list
+    of a batch and its sort / dedup result, in buffers that can be refreshed in place."""
+
+    def __init__(self, flat, si: SortedIndex):
+        self.flat, self.si = flat, si
+
+    def join(self) -> SortedIndex:
+        return self.si
+
+
 def table_backward_fm(feat, bias_table, si: SortedIndex, tsum, g, n_fields_ex: int):
     """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm)."""
     rule = getattr(feat, "_rx_sparse", None)
@@ -137,7 +148,7 @@ class FM2(Function):
 
     @staticmethod
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True,
-                deep_cols=None, want_logits=True, extra=None):
+                deep_cols=None, want_logits=True, extra=None, presort=None):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         n_items = item_idx.shape[1] if item_idx.dim() == 2 else 1
         # with one item per sample and no tower the backward needs only T_b = sum of the sample's rows
@@ -147,8 +158,8 @@ class FM2(Function):
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
         ctx.second_order = second_order
         ctx.tsum = out[2] if fused else None
-        ctx.sort = None
-        if ctx.needs_input_grad[4] and feat.is_cuda:
+        ctx.sort = presort
+        if presort is None and ctx.needs_input_grad[4] and feat.is_cuda:
             ctx.sort = _AsyncSort(feat, ex_idx, ex_base, item_idx, item_base)
         return out[0], out[1]
 
@@ -159,7 +170,7 @@ class FM2(Function):
             g = g.contiguous()
         if g_deep is not None and g_deep.stride(-1) != 1:
             g_deep = g_deep.contiguous()
-        none_tail = (None,) * 5
+        none_tail = (None,) * 6
         if ctx.tsum is not None and g_deep is None and g is not None:
             s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
                 ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])

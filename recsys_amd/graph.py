@@ -7,6 +7,13 @@ capturing stream) and replays it with one hipGraphLaunch.  Nothing in the step s
 the host: index errors are reported through the deferred flag (ops.raise_if_index_error), the
 loss stays on the device until asked for.
 
+With ``pipeline=True`` (and at least two resident batches) the index preparation of the NEXT batch
+(``model.prepare``: flat row ids, radix sort, dedup — work that depends on the indices only) is
+recorded on a side stream inside the graph of the CURRENT batch, so it overlaps the current step
+instead of sitting on its critical path.  Every replay still performs exactly one such preparation;
+replays must then follow the cyclic slot order 0, 1, ..., K-1, 0, ... (``copy_batch`` of slot i+1 has
+to happen before slot i is replayed).
+
 Limits: the batch tensors are captured by address, so a graph is tied to its batch object
 (``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place);
 ``dense_kind="adam"`` bakes the step count into the recording and is refused.
@@ -21,7 +28,7 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, warmup: int = 3):
+    def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False):
         if getattr(optimizer, "dense_kind", None) == "adam" and optimizer.dense:
             raise ValueError("dense Adam keeps its step count on the host and cannot be captured")
         self.model, self.opt, self.warmup = model, optimizer, warmup
@@ -29,7 +36,8 @@ class GraphedTrainStep:
         self.batches: List[Dict[str, torch.Tensor]] = []
         self.losses: List[torch.Tensor] = []
         self._pool = None
-        self._prev_check = None
+        self.pipeline = pipeline
+        self._finalized = False
 
     def _eager(self, batch):
         self.opt.zero_grad()
@@ -37,6 +45,43 @@ class GraphedTrainStep:
         loss.backward()
         self.opt.step()
         return loss
+
+    def add_batches(self, batches) -> None:
+        """Register all resident batches, then record their graphs (needed for ``pipeline=True``,
+        where the graph of slot i also prepares slot i+1)."""
+        batches = list(batches)
+        if not (self.pipeline and len(batches) >= 2):
+            for b in batches:
+                self.add_batch(b)
+            return
+        if ops._INDEX_CHECK != "deferred":
+            raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
+        dev = next(self.model.parameters()).device
+        prepared = [self.model.prepare(b) for b in batches]          # static buffers, filled eagerly once
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._eager(prepared[0])
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        K = len(prepared)
+        for i, b in enumerate(prepared):
+            g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad()
+            with torch.cuda.graph(g, pool=self._pool):
+                main = torch.cuda.current_stream(dev)
+                fork = torch.cuda.Stream(device=dev)
+                fork.wait_stream(main)
+                with torch.cuda.stream(fork):
+                    self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
+                loss = self._eager(b)
+                main.wait_stream(fork)
+            if self._pool is None:
+                self._pool = g.pool()
+            self.graphs.append(g)
+            self.batches.append(b)
+            self.losses.append(loss)
 
     def add_batch(self, batch: Dict[str, torch.Tensor]) -> int:
         """Record one graph bound to ``batch``'s tensors.  Before the first recording the step is
@@ -66,7 +111,8 @@ class GraphedTrainStep:
 
     def copy_batch(self, slot: int, new_batch: Dict[str, torch.Tensor]) -> None:
         for k, v in self.batches[slot].items():
-            v.copy_(new_batch[k])
+            if k in new_batch:
+                v.copy_(new_batch[k])
 
     def __call__(self, slot: int) -> torch.Tensor:
         self.graphs[slot].replay()

@@ -25,6 +25,13 @@ class HotPathModule(nn.Module):
             if n in named:
                 yield named[n]
 
+    def prepare(self, inputs, out=None):
+        """Index preparation that depends on the batch only (flat row ids, sort, dedup), done ahead
+        of the step — e.g. on a side stream while the previous step runs.  Returns ``inputs`` with
+        the result attached; models without such work return ``inputs`` unchanged.  ``out``: a
+        previously prepared batch whose buffers are overwritten in place."""
+        return inputs
+
     def loss(self, inputs, *args, **kwargs):
         labels = inputs["label"]
         logits = self(inputs, *args, **kwargs)

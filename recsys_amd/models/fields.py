@@ -42,6 +42,19 @@ class _FieldTable(HotPathModule):
         F = self.n_fields - 1
         return sparse[:, :F], base, sparse[:, F:], self._offsets[-1]
 
+    def prepare(self, inputs, out=None):
+        from .. import ops
+        ex, base, item, item_base = self._split(inputs)
+        feat = self.feature_embedding.weight
+        old = out.get("_rx_presort") if out is not None else None
+        flat = ops.fm2_flat_indices(feat, ex, base, item, item_base, out=old.flat if old else None)
+        si = ops.sort_dedup(flat, feat.shape[0], out=old.si if old else None)
+        if out is not None and old is not None:
+            return out
+        prepared = dict(inputs)
+        prepared["_rx_presort"] = rxa.Presort(flat, si)
+        return prepared
+
 
 class FieldFM(_FieldTable):
     """logit = sum_f bias[f] + 0.5 * sum_d[(sum_f e_f)^2 - sum_f e_f^2]."""
@@ -56,7 +69,8 @@ class FieldFM(_FieldTable):
     def forward(self, inputs):
         ex, base, item, item_base = self._split(inputs)
         logits, _ = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
-                                  self.bias_embedding.weight, False, True)
+                                  self.bias_embedding.weight, False, True, None, True, None,
+                                  inputs.get("_rx_presort"))
         return logits
 
 
@@ -88,7 +102,7 @@ class FieldDeepFM(_FieldTable):
         d_emb = self.n_fields * self.embedding_dim
         fm, x = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
                               self.bias_embedding.weight, True, True, d_emb + self.n_dense, True,
-                              _dense_input(inputs, self.n_dense, ex.shape[0]))
+                              _dense_input(inputs, self.n_dense, ex.shape[0]), inputs.get("_rx_presort"))
         return fm + run_tower(self.deep_mlp, x)
 
 
@@ -127,7 +141,8 @@ class DCNv2(_FieldTable):
         ex, base, item, item_base = self._split(inputs)
         d_emb = self.n_fields * self.embedding_dim
         _, x0 = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight, None, True, False,
-                              d_emb + self.n_dense, False, _dense_input(inputs, self.n_dense, ex.shape[0]))
+                              d_emb + self.n_dense, False, _dense_input(inputs, self.n_dense, ex.shape[0]),
+                              inputs.get("_rx_presort"))
         x = x0
         for layer in self.cross:
             x = rxa.CrossLayer.apply(x0, x, layer.weight, layer.bias, self.bf16)

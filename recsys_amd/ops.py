@@ -371,9 +371,11 @@ def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base: int, se
     return occ, bias_occ
 
 
-def fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base: int) -> Tensor:
+def fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base: int, out: Optional[Tensor] = None) -> Tensor:
     a, B, F, N = _fm_args(feat, None, ex_idx, ex_base, item_idx, item_base)
-    flat = torch.empty(B * (F + N), dtype=torch.int64, device=feat.device)
+    flat = out if out is not None else torch.empty(B * (F + N), dtype=torch.int64, device=feat.device)
+    if flat.numel() != B * (F + N) or flat.dtype != torch.int64:
+        raise ValueError("fm2_flat_indices: bad `out`")
     check(lib.rx_fm2_flat_indices(C.byref(a), _p(flat), _dev(feat), _stream(feat)), "rx_fm2_flat_indices")
     return flat
 
@@ -412,20 +414,28 @@ class SortedIndex:
     inverse: Optional[Tensor] = None
 
 
-def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False) -> SortedIndex:
+def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False, out: Optional[SortedIndex] = None) -> SortedIndex:
+    """``out``: a SortedIndex of the same length whose tensors are overwritten in place (static
+    buffers for graph capture / pipelining)."""
     _idx(idx, "indices")
     flat = idx.reshape(-1)
     n, dev = flat.numel(), idx.device
-    sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
-    sorted_slot = torch.empty(n, dtype=torch.int32, device=dev)
-    uniq = torch.empty(n, dtype=torch.int64, device=dev)
-    seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    nu = torch.empty(1, dtype=torch.int32, device=dev)
-    inv = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
+    if out is not None:
+        if out.n != n or out.n_rows != n_rows:
+            raise ValueError("sort_dedup: `out` was made for a different index list")
+        sorted_pos, sorted_slot, uniq, seg, nu, inv = (out.sorted_pos, out.sorted_slot, out.uniq_rows, out.seg_off,
+                                                        out.n_uniq, out.inverse)
+    else:
+        sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        sorted_slot = torch.empty(n, dtype=torch.int32, device=dev)
+        uniq = torch.empty(n, dtype=torch.int64, device=dev)
+        seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        nu = torch.empty(1, dtype=torch.int32, device=dev)
+        inv = torch.empty(n, dtype=torch.int32, device=dev) if want_inverse else None
     ws = _ws(int(lib.rx_sort_dedup_workspace_bytes(n)), dev)
     check(lib.rx_sort_dedup(_p(flat), n, n_rows, _p(sorted_pos), _p(sorted_slot), _p(uniq), _p(seg), _p(nu),
                             _p(inv), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)), "rx_sort_dedup")
-    return SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
+    return out if out is not None else SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
 
 
 def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state: Optional[Tensor] = None,

@@ -124,3 +124,35 @@ def test_graphed_step_matches_eager_bitwise():
     assert la == lb
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_pipelined_graph_steps_match_eager_bitwise():
+    """Graph of batch i prepares (sorts) batch i+1 on a side stream; cycling over 3 resident batches
+    gives the same weights, bit for bit, as eager steps on the same batch sequence."""
+    from recsys_amd import ops
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.optim import FusedOptimizer
+    results = []
+    for graphed in (False, True):
+        _, m, _ = _pair("FieldFM", B=512)
+        batches = [{k: v.cuda() for k, v in _batch(512, 10 + i).items()} for i in range(3)]
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True)
+                gs.add_batches(batches)            # 2 eager warm-up steps on batch 0
+                for i in range(7):
+                    loss = gs(i % 3)
+            else:
+                seq = [0, 0] + [i % 3 for i in range(7)]
+                for i in seq:
+                    opt.zero_grad(); loss = m.loss(batches[i]); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
