@@ -205,18 +205,21 @@ __device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* 
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_kernel(SegArgs a) {
-  // LDS tile of the block's sorted positions, staged by one coalesced sweep:
-  //   meta[1 + j] = (slot, position) of sorted position base + j; slot -1 past the end
-  //   meta[0], meta[1 + T] = the neighbours just outside the tile (only their slot is used)
-  //   rowid[j] = table row of that slot
-  // so the walk below never waits on a dependent global load except the rows themselves.
+  // LDS tile of the block's sorted positions, staged by one coalesced sweep.  Each piece owns
+  // PS = SEG_CHUNK + 1 consecutive entries: (slot, position) of its positions (slot -1 past the end
+  // of the list) and, in the extra entry, the slot of its right neighbour.  The odd stride puts
+  // the pieces that one wavefront reads together on different LDS banks.  meta[0] is the entry
+  // just left of the tile, and rowid[] holds each entry's table row with the same stride, so the
+  // walk below never waits on a dependent global load except the rows themselves.
   extern __shared__ int2 meta[];
   __shared__ float sq_lds[RX_BLOCK / 64];
-  constexpr int BATCH = 8 / CH;
+  constexpr int BATCH = 4 / CH;
+  constexpr int PS = SEG_CHUNK + 1;
   const int group = a.group, dim = a.dim;
   const int gpb = RX_BLOCK / group;
   const int T = gpb * SEG_CHUNK;
-  uint32_t* rowid = reinterpret_cast<uint32_t*>(meta + T + 2);
+  int2* tile = meta + 2;
+  uint32_t* rowid = reinterpret_cast<uint32_t*>(tile + gpb * PS);
   const int64_t piece0 = (int64_t)blockIdx.x * gpb;
   {
     // Eight entries per thread and round: all index loads of a round are issued before the
@@ -244,8 +247,18 @@ segreduce_chunk_kernel(SegArgs a) {
         if (j < T + 2) {
           int pos = ps[r];
           if (FM) pos = pos < a.fm_split ? pos / a.fm_div : pos - (int)a.fm_split;  // sample of the occurrence
-          meta[j] = make_int2(sl[r], sl[r] >= 0 ? pos : 0);
-          if (j >= 1 && j <= T) rowid[j - 1] = sl[r] >= 0 ? rw[r] : 0u;
+          const int2 e = make_int2(sl[r], sl[r] >= 0 ? pos : 0);
+          const int t = j - 1;
+          if (t < 0) {
+            meta[0] = e;
+          } else {
+            const int pc = t / SEG_CHUNK, off = t % SEG_CHUNK;
+            if (t < T) {
+              tile[pc * PS + off] = e;
+              rowid[pc * PS + off] = sl[r] >= 0 ? rw[r] : 0u;
+            }
+            if (off == 0 && t > 0) tile[(pc - 1) * PS + SEG_CHUNK] = e;
+          }
         }
       }
     }
@@ -257,47 +270,27 @@ segreduce_chunk_kernel(SegArgs a) {
   const int64_t lo = piece * SEG_CHUNK;
   float sq = 0.f;
   if (lo < a.n) {
+    // Positions past the end of the list carry slot -1 in the tile; they form a last "run" that is
+    // never written, so the walk needs no length test per position.
     const int len = (int)((lo + SEG_CHUNK < a.n) ? SEG_CHUNK : a.n - lo);
     const float scale = a.scale ? a.scale[0] : 1.f;
-    const int2* mine = meta + 1 + my * SEG_CHUNK;  // mine[-1] and mine[len] are the neighbours
-    const uint32_t* myrow = rowid + my * SEG_CHUNK;
-    const int left = mine[-1].x, right = mine[len].x;
+    const int2* mine = tile + my * PS;  // mine[-2] (the previous piece's last entry) and mine[SEG_CHUNK] are the neighbours
+    const uint32_t* myrow = rowid + my * PS;
+    const int left = mine[-2].x, right = mine[SEG_CHUNK].x;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
-    int cur = mine[0].x;
-    int run_start = 0;
-    int tail = -1;
-    Acc<VEC, CH> cur_x, cur_st;                 // current value / state of the running row
-    ACC_FOREACH(k, i) { cur_x.p[k].v[i] = 0.f; cur_st.p[k].v[i] = 0.f; }
     const bool has2 = a.target2 != nullptr;     // a companion table is updated
     const bool keep2 = FM || has2;              // the scalar sum is needed (FM: for the row's own term)
     const float* src2 = FM ? a.fm_g : a.occ2;
-    // flush the run of slot u that covers piece positions [run_start, end)
-    auto flush = [&](int u, int end) {
-      const bool entered = (run_start == 0) && (left == u);
-      const bool leaves = (end == len) && (right == u);
-      if (!entered && !leaves) {
-        const int64_t row = (int64_t)myrow[run_start];
-        if (row < a.n_rows) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, cur_x, cur_st, row, u, lg, scale, has2);
-      } else {
-        const int side = entered ? 0 : 1;
-        float* dst = a.partials + (piece * 2 + side) * (int64_t)dim;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          const int c = (lg + k * group) * VEC;
-          if (c < dim) rx_store<VEC>(dst + c, g.p[k]);
-        }
-        if (keep2 && lg == 0) a.partials2[piece * 2 + side] = g2;
-        if (side == 1) tail = u;
-      }
-      ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
-      g2 = 0.f;
-      run_start = end;
-    };
-    // Loads are issued unconditionally (out-of-range batch entries re-read the piece's last
-    // position, out-of-range columns re-read column 0) and masked afterwards: a load under a
-    // run-time branch would make the compiler wait for each one before issuing the next.
+    // the companion's current value rides along with the rows when the update needs it
+    constexpr bool OLD2 = MODE == RX_SEG_SGD;
+    const float* old2_src = has2 ? a.target2 : a.occ;
+    float* part0 = a.partials + piece * 2 * (int64_t)dim;   // [0] entered from the left, [1] leaves to the right
+    float* part0_2 = a.partials2 + piece * 2;
+    // Loads are issued unconditionally (out-of-range columns re-read column 0) and masked
+    // afterwards: a load under a run-time branch would make the compiler wait for each one
+    // before issuing the next.
     bool col_ok[CH];
     int col[CH];
 #pragma unroll
@@ -306,60 +299,131 @@ segreduce_chunk_kernel(SegArgs a) {
       col_ok[k] = c < dim;
       col[k] = col_ok[k] ? c : 0;
     }
-#pragma unroll 1
-    for (int b0 = 0; b0 < SEG_CHUNK; b0 += BATCH) {
-      if (b0 >= len) break;
-      int sl[BATCH];
+    // Two batches alternate: the loads of the next one are in flight while the current one is
+    // walked, so a piece pays the memory latency once instead of once per batch.
+    struct Batch {
+      int sl[BATCH + 1];
+      uint32_t rid[BATCH];
       Acc<VEC, CH> rows[BATCH], oldx[BATCH], oldst[BATCH];
-      float s2[BATCH];
+      float s2[BATCH], old2[BATCH];
+    };
+    auto load_batch = [&](int b0, Batch& t) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        const int jj = (b0 + j < len) ? b0 + j : len - 1;
-        const int2 m = mine[jj];
-        sl[j] = m.x;
+        const int2 m = mine[b0 + j];
+        t.sl[j] = m.x;
         const float* src = a.occ + (int64_t)m.y * a.occ_ld;
 #pragma unroll
-        for (int k = 0; k < CH; ++k) rows[j].p[k] = rx_load<VEC>(src + col[k]);
-        s2[j] = keep2 ? src2[m.y] : 0.f;
-        // the row's current value (and state) ride along, so that a flush has them at hand
-        const uint32_t r = myrow[jj];
-        load_old<VEC, CH, MODE, FM>(a, r < a.n_rows ? (int64_t)r : 0, lg, oldx[j], oldst[j]);
+        for (int k = 0; k < CH; ++k) t.rows[j].p[k] = rx_load<VEC>(src + col[k]);
+        t.s2[j] = keep2 ? src2[m.y] : 0.f;
+        // the row's current value (and state) ride along, so that the end of a run has them at hand
+        const uint32_t r = myrow[b0 + j];
+        t.rid[j] = r;
+        const int64_t r_safe = r < a.n_rows ? (int64_t)r : 0;
+        load_old<VEC, CH, MODE, FM>(a, r_safe, lg, t.oldx[j], t.oldst[j]);
+        t.old2[j] = OLD2 ? old2_src[has2 ? r_safe : 0] : 0.f;
       }
+      t.sl[BATCH] = mine[b0 + BATCH].x;
+    };
+    auto walk_batch = [&](int b0, Batch& t) {
       // Retire every load of the batch here.  vmcnt counts loads and stores in one queue, and the
-      // flushes below store under run-time branches; a load still pending behind such a store
+      // run ends below store under run-time predicates; a load still pending behind such a store
       // would make each later use wait for the store's round trip as well.
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        asm volatile("" ::"v"(s2[j]));
+        asm volatile("" ::"v"(t.s2[j]));
+        if constexpr (OLD2) asm volatile("" ::"v"(t.old2[j]));
         ACC_FOREACH(k, i) {
-          asm volatile("" ::"v"(rows[j].p[k].v[i]));
-          if constexpr (FM || MODE >= RX_SEG_SGD) asm volatile("" ::"v"(oldx[j].p[k].v[i]));
-          if constexpr (MODE == RX_SEG_ADAGRAD) asm volatile("" ::"v"(oldst[j].p[k].v[i]));
+          asm volatile("" ::"v"(t.rows[j].p[k].v[i]));
+          if constexpr (FM || MODE >= RX_SEG_SGD) asm volatile("" ::"v"(t.oldx[j].p[k].v[i]));
+          if constexpr (MODE == RX_SEG_ADAGRAD) asm volatile("" ::"v"(t.oldst[j].p[k].v[i]));
         }
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        if (b0 + j < len) {
-          if (sl[j] != cur) {
-            flush(cur, b0 + j);
-            cur = sl[j];
-          }
-          if (b0 + j == run_start) { cur_x = oldx[j]; cur_st = oldst[j]; }
 #pragma unroll
-          for (int k = 0; k < CH; ++k) {
-            if (col_ok[k]) {
+        for (int k = 0; k < CH; ++k) {
+          if (col_ok[k]) {
 #pragma unroll
-              for (int i = 0; i < VEC; ++i) {
-                if constexpr (FM) g.p[k].v[i] += s2[j] * rows[j].p[k].v[i];
-                else g.p[k].v[i] += rows[j].p[k].v[i];
-              }
+            for (int i = 0; i < VEC; ++i) {
+              if constexpr (FM) g.p[k].v[i] += t.s2[j] * t.rows[j].p[k].v[i];
+              else g.p[k].v[i] += t.rows[j].p[k].v[i];
             }
           }
-          g2 += s2[j];
+        }
+        g2 += t.s2[j];
+        if (t.sl[j + 1] != t.sl[j]) {
+          // The run of slot u ends here.  It is complete unless it came in from the left
+          // neighbour (a run that also leaves to the right never ends inside the piece).
+          const int u = t.sl[j];
+          const bool complete = u != left;
+          const int64_t row = (int64_t)t.rid[j];
+          const bool row_ok = row < a.n_rows;
+          if constexpr (MODE == RX_SEG_DENSE || MODE == RX_SEG_COMPACT || MODE == RX_SEG_SGD) {
+            // one store whose address and value are selected, instead of two code paths
+            Acc<VEC, CH> G = g;
+            if constexpr (FM) ACC_FOREACH(k, i) G.p[k].v[i] -= g2 * t.oldx[j].p[k].v[i];
+            if (a.sq_part) {
+              float q = acc_sq<VEC, CH>(G, lg, group, dim);
+              if (has2 && lg == 0) q += g2 * g2;
+              sq += (complete && row_ok) ? q : 0.f;
+            }
+            float v2 = g2;
+            if constexpr (MODE == RX_SEG_SGD) {
+              ACC_FOREACH(k, i) G.p[k].v[i] = t.oldx[j].p[k].v[i] - a.lr * (G.p[k].v[i] * scale);
+              v2 = t.old2[j] - a.lr * (g2 * scale);
+            }
+            const int64_t idx = MODE == RX_SEG_COMPACT ? (int64_t)u : row;
+            float* dst = complete ? a.target + idx * (int64_t)dim : part0;
+            if (complete ? row_ok : u >= 0) {
+#pragma unroll
+              for (int k = 0; k < CH; ++k) {
+                RxPack<VEC> val;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) val.v[i] = complete ? G.p[k].v[i] : g.p[k].v[i];
+                if (col_ok[k]) rx_store<VEC>(dst + (lg + k * group) * VEC, val);
+              }
+            }
+            if (keep2 && lg == 0 && (complete ? (has2 && row_ok) : u >= 0)) {
+              float* dst2 = complete ? a.target2 + idx : part0_2;
+              *dst2 = complete ? v2 : g2;
+            }
+          } else {
+            if (complete) {
+              if (row_ok) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, t.oldx[j], t.oldst[j], row, u, lg, scale, has2);
+            } else if (u >= 0) {
+#pragma unroll
+              for (int k = 0; k < CH; ++k)
+                if (col_ok[k]) rx_store<VEC>(part0 + (lg + k * group) * VEC, g.p[k]);
+              if (keep2 && lg == 0) part0_2[0] = g2;
+            }
+          }
+          ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
+          g2 = 0.f;
         }
       }
+    };
+    Batch ba, bb;
+    load_batch(0, ba);
+#pragma unroll 1
+    for (int b0 = 0; b0 < SEG_CHUNK; b0 += 2 * BATCH) {
+      if (b0 >= len) break;
+      load_batch(b0 + BATCH, bb);
+      walk_batch(b0, ba);
+      if (b0 + 2 * BATCH < SEG_CHUNK) load_batch(b0 + 2 * BATCH, ba);
+      walk_batch(b0 + BATCH, bb);
     }
-    flush(cur, len);
+    // the run that leaves the piece to the right: side 0 if it also came in from the left
+    const int last = mine[SEG_CHUNK - 1].x;
+    int tail = -1;
+    if (last >= 0 && last == right) {
+      const int side = last == left ? 0 : 1;
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        if (col_ok[k]) rx_store<VEC>(part0 + side * dim + (lg + k * group) * VEC, g.p[k]);
+      if (keep2 && lg == 0) part0_2[side] = g2;
+      if (side == 1) tail = last;
+    }
     if (lg == 0) a.tail_row[piece] = tail;
   }
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
@@ -368,33 +432,51 @@ segreduce_chunk_kernel(SegArgs a) {
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
+  // A wavefront looks after 64/group consecutive pieces.  Each lane group first fetches what its
+  // own piece's tail run needs (length, row, the row's current value), all groups at once; the
+  // wavefront then takes the tails one by one, all lane slots adding that run's partials.
   __shared__ float sq_lds[RX_BLOCK / 64];
   const int group = a.group, dim = a.dim;
   const int lane = threadIdx.x & 63;
-  const int64_t piece = (int64_t)blockIdx.x * (RX_BLOCK / 64) + (threadIdx.x >> 6);
-  float sq = 0.f;
-  const int u = piece < n_pieces ? a.tail_row[piece] : -1;  // wave-uniform
+  const int slots = 64 / group;
+  const int s = lane / group, lg = lane % group;
+  const int64_t base = ((int64_t)blockIdx.x * (RX_BLOCK / 64) + (threadIdx.x >> 6)) * slots;
+  const int64_t mine = base + s;
+  const bool has2 = a.target2 != nullptr;
+  const bool keep2 = FM || has2;
+  const float scale = a.scale ? a.scale[0] : 1.f;
+  const int u = mine < n_pieces ? a.tail_row[mine] : -1;
+  int n_parts = 0;
+  int64_t row = -1;
   if (u >= 0) {
-    const int64_t run_hi = a.seg_off[u + 1];
-    const int64_t last = (run_hi - 1) / SEG_CHUNK;
-    const int n_parts = (int)(last - piece) + 1;
-    const int slots = 64 / group;
-    const int s = lane / group, lg = lane % group;
-    const bool has2 = a.target2 != nullptr;
-    const bool keep2 = FM || has2;
+    n_parts = (int)((a.seg_off[u + 1] - 1) / SEG_CHUNK - mine) + 1;
+    row = a.uniq_rows[u];
+  }
+  const bool row_ok = row >= 0 && row < a.n_rows;
+  Acc<VEC, CH> x, st;
+  ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
+  load_old<VEC, CH, MODE, FM>(a, row_ok ? row : 0, lg, x, st);
+  float sq = 0.f;
+  unsigned long long todo = __ballot(u >= 0 && lg == 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;  // wave-uniform
+    todo &= todo - 1;
+    const int owner = leader / group;
+    const int np = __shfl(n_parts, leader, 64);
+    const int64_t piece = base + owner;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
-    for (int q = s; q < n_parts; q += slots) {
+    for (int q = s; q < np; q += slots) {
       const int64_t e = (piece + q) * 2 + (q == 0 ? 1 : 0);
       const float* src = a.partials + e * (int64_t)dim;
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int c = (lg + k * group) * VEC;
         if (c < dim) {
-          RxPack<VEC> x = rx_load<VEC>(src + c);
+          RxPack<VEC> v = rx_load<VEC>(src + c);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) g.p[k].v[i] += x.v[i];
+          for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v.v[i];
         }
       }
       if (keep2 && lg == 0) g2 += a.partials2[e];
@@ -404,15 +486,7 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
       g2 += __shfl_xor(g2, m, 64);
     }
     if (FM) g2 = __shfl(g2, lane - lg, 64);  // every lane of a group needs the scalar sum
-    if (s == 0) {
-      const int64_t row = a.uniq_rows[u];
-      if (row >= 0 && row < a.n_rows) {
-        Acc<VEC, CH> x, st;
-        ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
-        load_old<VEC, CH, MODE, FM>(a, row, lg, x, st);
-        sq = finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, a.scale ? a.scale[0] : 1.f, has2);
-      }
-    }
+    if (s == owner && row_ok) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, scale, has2);
   }
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
 }
@@ -433,17 +507,18 @@ static int seg_shape(int dim, int64_t occ_ld, const void* occ, const void* targe
 }
 
 static int seg_group(int dim) {
-  const int g = rx_row_shape(dim).group;
-  return g < 2 ? 2 : g;
+  RxRowShape sh = rx_row_shape(dim);
+  if (sh.chunks == 3) sh.chunks = 4;
+  return sh.group < 2 ? 2 : sh.group;
 }
 
 static int64_t seg_pieces(int64_t n) { return rx_cdiv(n, SEG_CHUNK); }
 static int64_t seg_grid1(int64_t n, int dim) { return rx_cdiv(seg_pieces(n) * seg_group(dim), RX_BLOCK); }
-static int64_t seg_grid2(int64_t n) { return rx_cdiv(seg_pieces(n), RX_BLOCK / 64); }
+static int64_t seg_grid2(int64_t n, int dim) { return rx_cdiv(rx_cdiv(seg_pieces(n), 64 / seg_group(dim)), RX_BLOCK / 64); }
 
 extern "C" int64_t rx_segreduce_grid(int64_t n, int32_t dim) {
   if (n <= 0 || dim < 1 || dim > RX_MAX_DIM) return 0;
-  return seg_grid1(n, dim) + seg_grid2(n);
+  return seg_grid1(n, dim) + seg_grid2(n, dim);
 }
 
 extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
@@ -507,8 +582,8 @@ static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t w
   a.partials2 = (float*)w; w += rx_align_up(pieces * 2 * sizeof(float), 256);
   a.tail_row = (int32_t*)w;
   a.group = sh.group;
-  const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n);
-  const size_t tile = (size_t)(RX_BLOCK / sh.group) * SEG_CHUNK;
+  const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n, dim);
+  const size_t tile = (size_t)(RX_BLOCK / sh.group) * (SEG_CHUNK + 1);
   const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
   SEG_DISPATCH(a.mode, fm, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
   RX_LAUNCH_CHECK();
