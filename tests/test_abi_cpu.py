@@ -50,8 +50,8 @@ def test_workspace_queries_are_pure_host_calls():
     a, b = _lib.lib.rx_sort_dedup_workspace_bytes(1000), _lib.lib.rx_sort_dedup_workspace_bytes(100000)
     assert 16 * 1000 <= a < b
     assert _lib.lib.rx_bce_workspace_bytes(10) >= 8
-    assert _lib.lib.rx_segreduce_grid(1024, 16) == 1 + 8
-    assert _lib.lib.rx_segreduce_grid(1024, 64) == 2 + 8
+    assert _lib.lib.rx_segreduce_grid(1024, 16) == 1 + 1   # 32 pieces: 4 lanes each in pass 1, 16 pieces per wavefront in pass 2
+    assert _lib.lib.rx_segreduce_grid(1024, 64) == 2 + 2
     assert _lib.lib.rx_segreduce_workspace_bytes(1024, 16) == 32 * 2 * 16 * 4 + 256 + 256
     assert _lib.lib.rx_mf_bwd_grid(1024, 64) == 64
 
