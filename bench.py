@@ -123,6 +123,7 @@ class OpTimer:
     def __init__(self, names):
         from recsys_amd import ops
         self.ops, self.names, self.events, self.saved = ops, list(names), {n: [] for n in names}, {}
+        self.last_call = {}
 
     def __enter__(self):
         for n in self.names:
@@ -135,6 +136,7 @@ class OpTimer:
                 out = __fn(*a, **k)
                 e.record()
                 self.events[__n].append((s, e))
+                self.last_call[__n] = (a, k)
                 return out
 
             setattr(self.ops, n, wrapped)
@@ -154,14 +156,53 @@ class OpTimer:
         return out
 
 
-ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", "row_update", "bce_with_logits",
+def back_to_back_ms(op_name, call, reps=30):
+    """Average duration of one launch of `op_name`, re-issued `reps` times back to back with the
+    arguments of its last call in the step, bracketed by two HIP events on the launch stream.
+    Queued launches hide the host's launch latency, so this is the kernels' own time."""
+    from recsys_amd import ops
+    fn = getattr(ops, op_name)
+    args, kwargs = call
+    for _ in range(3):
+        fn(*args, **kwargs)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn(*args, **kwargs)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps, reps
+
+
+ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", "segreduce_fm", "row_update", "bce_with_logits",
            "mf_score_fwd", "mf_score_bwd", "gather_concat", "gather_concat_bwd", "gmf_mul_fwd", "gmf_mul_bwd",
            "linear_fwd", "linear_bwd_x", "linear_bwd_w", "relu_bwd", "sumsq_accumulate", "sum_accumulate",
            "clip_scale", "reduce_sum", "cross_combine_fwd", "cross_combine_bwd"]
 
 
-def algo_bytes(desc, op):
-    """Algorithmic HBM bytes of one launch of the step's dominant kernels (fp32, 8-byte indices)."""
+# kernels behind each timed op (names as rocprofv3 prints them), for the roofline line and the PMC lookup
+OP_KERNELS = {
+    "segreduce_fm": ["segreduce_chunk_kernel<4, 1, 1, true>", "segreduce_combine_kernel<4, 1, 1, true>"],
+    "fm2_fwd": ["fm2_fwd_kernel<4, 1>"],
+    "row_update": ["row_update_kernel<4, 1, 2, false>"],
+}
+
+
+def unique_fraction(batches, dims):
+    """rho = distinct table rows / occurrences, averaged over the synthetic batches."""
+    offs = torch.tensor([0] + list(dims[:-1]), device=batches[0]["sparse"].device).cumsum(0)
+    fr = []
+    for b in batches:
+        flat = (b["sparse"] + offs[None, :]).reshape(-1)
+        fr.append(torch.unique(flat).numel() / flat.numel())
+    return sum(fr) / len(fr)
+
+
+def algo_bytes(desc, op, rho=1.0):
+    """Algorithmic HBM bytes of one launch (fp32 rows, 8-byte indices, N = 1 item per row):
+    the per-sample figures are fwd F(8 + De) + 4, bwd 4 + F De + 8F, update rho F 2 De, with
+    F fields, D columns, e = 4 bytes and rho the measured distinct-row fraction."""
     B, D = desc["batch_per_gpu"], desc["dim"]
     if desc["workload"] in ("fm_criteo", "fm_criteo_sharded", "deepfm_criteo", "dcnv2_criteo"):
         F = desc["fields"]
@@ -169,9 +210,28 @@ def algo_bytes(desc, op):
             return B * (F * (8 + 4 * D + 4) + 4)
         if op == "fm2_bwd":  # logit grad in; indices + rows re-read; per-occurrence grad rows (+bias) out
             return B * (4 + F * (8 + 4 * D) + F * (4 * D + 4))
-        if op == "segreduce":  # sorted positions + per-occurrence rows in; unique rows read+write (rho = 1 bound)
-            return B * F * (4 + 4 * D + 2 * 4 * D)
+        if op == "segreduce":  # sorted positions + per-occurrence rows in; distinct rows read + written
+            return B * F * (8 + 4 * D) + rho * B * F * 2 * 4 * D
+        if op == "segreduce_fm":  # backward + the read-modify-write of the distinct rows, in one op
+            return B * (4 + F * 4 * D + F * 8) + rho * B * F * 2 * 4 * D
+        if op == "row_update":  # compact gradient in, row in, row out
+            return rho * B * F * 3 * 4 * D
     return None
+
+
+def measured_traffic(op):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, summed
+    over the op's kernels), or None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path) or op not in OP_KERNELS:
+        return None
+    table = json.load(open(path))
+    total = 0.0
+    for k in OP_KERNELS[op]:
+        if k not in table:
+            return None
+        total += table[k]["traffic_bytes"]
+    return total
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -276,7 +336,10 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return w, el, timer.summary(), float(loss.item())
+        ops_ms = timer.summary()
+        if timed_op and timed_op in timer.last_call:
+            ops_ms[timed_op] = back_to_back_ms(timed_op, timer.last_call[timed_op])
+        return w, el, ops_ms, float(loss.item())
 
     if args.op_profile and rank == 0:
         w = build_workload(args.workload, device, rank, world, clip, use_graph=False)
@@ -289,17 +352,17 @@ def main():
             print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
         del w
 
-    dominant = {"fm_criteo": "fm2_bwd", "fm_criteo_sharded": "fm2_bwd", "deepfm_criteo": "linear_bwd_w", "dcnv2_criteo": "linear_bwd_w",
-                "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
+    dominant = {"fm_criteo": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm", "deepfm_criteo": "linear_bwd_w",
+                "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
     if world > 1 and args.workload == "fm_criteo":
         args.workload = "fm_criteo_sharded"
     if args.workload == "fm_criteo_sharded":
         use_graph = False
-        dominant = "fm2_bwd"
+        dominant = "fm2_bwd"  # the sharded step exchanges per-occurrence gradient rows, so it keeps the unfused backward
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
     if use_graph:
-        # the dominant kernel is timed with HIP events on the launch stream in a short eager pass of
+        # the dominant kernel is timed with HIP events on the launch stream after a short eager pass of
         # the same steps (events cannot bracket a single node of a replayed graph)
         _, _, ops_ms, _ = run(args.workload, min(args.steps, 30), 5, dominant, use_graph=False)
     B = w["B"]
@@ -314,12 +377,17 @@ def main():
     roof = None
     if dominant in ops_ms:
         ms, cnt = ops_ms[dominant]
-        ab = algo_bytes(w["desc"], dominant)
+        rho = 1.0
+        if "fields" in w["desc"]:
+            from recsys_amd import synthetic
+            rho = unique_fraction(w["batches"], synthetic.criteo_field_dims())
+        ab = algo_bytes(w["desc"], dominant, rho)
         if ab:
             ach = ab / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": ms * 1e3,
-                    "algorithmic_bytes_per_launch": ab}
+            roof = {"bound": "hbm", "kernel": dominant, "kernels": OP_KERNELS.get(dominant), "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": measured_traffic(dominant), "avg_us": ms * 1e3, "launches_timed": cnt,
+                    "algorithmic_bytes_per_launch": ab, "distinct_row_fraction": rho}
     out["roofline"] = roof
     del w
     torch.cuda.empty_cache()
