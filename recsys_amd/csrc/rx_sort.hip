@@ -2,10 +2,11 @@
 // sort of (row, position) pairs written for 64-lane wavefronts, then run-length compaction
 // into distinct rows + run offsets.
 //
-// Sort structure per 8-bit pass (3 launches):
+// Sort structure per pass (3 launches; digits of up to 11 bits, spread evenly over the passes):
 //   hist    each block counts the digits of its 4096-key tile (LDS integer atomics)
-//   scan    one block turns the [digit][block] counts into global start offsets
-//   scatter each wave ranks its 1024 keys stably: per key, 8 ballots give the set of lanes
+//   scan    every block scans 2048 of the [digit][block] counts in place and publishes its total
+//   scatter first folds the scan of those totals into its prologue (they are few), then
+//           each wave ranks its 1024 keys stably: per key, `bits` ballots give the set of lanes
 //           with the same digit (a 64-lane "match"), the lowest such lane advances the wave's
 //           private digit counter, and every lane's rank is counter + popcount(lanes below).
 //           Wave counters are prefixed across the block's 4 waves, so the final order is
@@ -21,35 +22,44 @@
 #define SORT_WAVE_KEYS (64 * SORT_ITEMS)
 #define SCAN_TILE (RX_BLOCK * 8)           // entries of the count array per scan block
 
-// keys: int64 rows -> uint32 (rows < 2^32), clamped into range; values: positions.
-__global__ void __launch_bounds__(RX_BLOCK)
-sort_init_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t n_rows, uint32_t* __restrict__ keys,
-                 uint32_t* __restrict__ vals, int32_t* err_flag) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int64_t r = idx[i];
-  if (r < 0 || r >= n_rows) {
-    if (err_flag) atomicOr(err_flag, RX_ERR_INDEX);
-    r = r < 0 ? 0 : n_rows - 1;
-  }
-  keys[i] = (uint32_t)r;
-  vals[i] = (uint32_t)i;
+// The first pass reads the caller's int64 rows directly (RAW): key = row clamped into range
+// (rows < 2^32), value = position.  Later passes read the uint32 pairs of the previous one.
+__device__ __forceinline__ uint32_t raw_key(const int64_t* __restrict__ idx, int64_t i, int64_t n_rows, bool* bad) {
+  const int64_t r = idx[i];
+  *bad = r < 0 || r >= n_rows;
+  return (uint32_t)(r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r));
 }
 
 // counts[digit][block] for this pass (bins = 1 << bits)
+template <bool RAW>
 __global__ void __launch_bounds__(RX_BLOCK)
-sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift, int bits, uint32_t* __restrict__ block_hist,
-                 int n_blocks) {
+sort_hist_kernel(const void* __restrict__ keys_in, int64_t n, int64_t n_rows, int shift, int bits,
+                 uint32_t* __restrict__ block_hist, int n_blocks, int32_t* err_flag) {
   extern __shared__ uint32_t h[];
   const int bins = 1 << bits;
   for (int i = threadIdx.x; i < bins; i += blockDim.x) h[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+  uint32_t key[SORT_ITEMS];
+  bool any_bad = false;
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = base + it * RX_BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (bins - 1)], 1u);
+    const int64_t ii = i < n ? i : n - 1;
+    if constexpr (RAW) {
+      bool bad;
+      key[it] = raw_key((const int64_t*)keys_in, ii, n_rows, &bad);
+      any_bad |= bad;
+    } else {
+      key[it] = ((const uint32_t*)keys_in)[ii];
+    }
   }
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const int64_t i = base + it * RX_BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&h[(key[it] >> shift) & (bins - 1)], 1u);
+  }
+  if (RAW && any_bad && err_flag) atomicOr(err_flag, RX_ERR_INDEX);
   __syncthreads();
   for (int d = threadIdx.x; d < bins; d += blockDim.x) block_hist[(int64_t)d * n_blocks + blockIdx.x] = h[d];
 }
@@ -119,17 +129,24 @@ scan_totals_kernel(uint32_t* __restrict__ sums, int64_t count) {
   }
 }
 
+// `tile_sums` are the totals published by scan_tiles_kernel.  FOLD: they are still unscanned and
+// at most SCAN_FOLD_MAX many, and every block scans them itself in LDS while its keys are in
+// flight, which saves a single-block launch per pass.  Otherwise they arrive scanned.
+#define SCAN_FOLD_MAX 1024
+
+template <bool RAW, bool FOLD>
 __global__ void __launch_bounds__(RX_BLOCK)
-sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
-                    int shift, int bits, const uint32_t* __restrict__ block_off,
-                    const uint32_t* __restrict__ tile_off, int n_blocks, uint32_t* __restrict__ keys_out,
-                    uint32_t* __restrict__ vals_out) {
+sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
+                    int64_t n_rows, int shift, int bits, const uint32_t* __restrict__ block_off,
+                    const uint32_t* __restrict__ tile_sums, int n_tiles, int n_blocks,
+                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   extern __shared__ uint32_t wave_cnt[];  // [SORT_WAVES][bins]: running counters, then wave bases
+  __shared__ uint32_t tile_lds[FOLD ? SCAN_FOLD_MAX : 1];
+  __shared__ uint32_t lds4[4];
   const int bins = 1 << bits;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < SORT_WAVES * bins; i += blockDim.x) wave_cnt[i] = 0;
-  __syncthreads();
 
   uint32_t* my_cnt = wave_cnt + wave * bins;
   const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_WAVE_KEYS;
@@ -139,9 +156,43 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = wbase + it * 64 + lane;
     const bool live = i < n;
-    key[it] = live ? keys_in[i] : 0xFFFFFFFFu;
-    val[it] = live ? vals_in[i] : 0u;
+    const int64_t ii = live ? i : n - 1;
+    if constexpr (RAW) {
+      bool bad;
+      key[it] = raw_key((const int64_t*)keys_in, ii, n_rows, &bad);
+      val[it] = (uint32_t)ii;
+    } else {
+      key[it] = ((const uint32_t*)keys_in)[ii];
+      val[it] = vals_in[ii];
+    }
+    if (!live) key[it] = 0xFFFFFFFFu;
   }
+  if constexpr (FOLD) {
+    // exclusive scan of the tile totals: four per thread, then the block scan
+    uint32_t v[SCAN_FOLD_MAX / RX_BLOCK], sum = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_FOLD_MAX / RX_BLOCK; ++e) {
+      const int t = threadIdx.x * (SCAN_FOLD_MAX / RX_BLOCK) + e;
+      v[e] = t < n_tiles ? tile_sums[t] : 0u;
+      sum += v[e];
+    }
+    const int ln = threadIdx.x & 63;
+    uint32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (ln >= off) inc += t;
+    }
+    if (ln == 63) lds4[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += lds4[w];
+#pragma unroll
+    for (int e = 0; e < SCAN_FOLD_MAX / RX_BLOCK; ++e) {
+      tile_lds[threadIdx.x * (SCAN_FOLD_MAX / RX_BLOCK) + e] = run;
+      run += v[e];
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const bool live = (wbase + it * 64 + lane) < n;
@@ -170,7 +221,7 @@ sort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __rest
   // per digit: exclusive prefix over the block's waves, plus this block's global start
   for (int d = threadIdx.x; d < bins; d += blockDim.x) {
     const int64_t e = (int64_t)d * n_blocks + blockIdx.x;
-    uint32_t run = block_off[e] + tile_off[e / SCAN_TILE];
+    uint32_t run = block_off[e] + (FOLD ? tile_lds[e / SCAN_TILE] : tile_sums[e / SCAN_TILE]);
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
       const uint32_t c = wave_cnt[w * bins + d];
@@ -300,20 +351,34 @@ static SortWs sort_ws_layout(void* ws, int64_t n) {
 
 extern "C" size_t rx_sort_dedup_workspace_bytes(int64_t n) { return sort_ws_layout(nullptr, n).bytes; }
 
-// one stable counting pass on `bits` bits starting at `shift`
-static int sort_pass(const SortWs& w, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout,
-                     int64_t n, int shift, int bits, hipStream_t st) {
+// one stable counting pass on `bits` bits starting at `shift`.  raw_idx != NULL: first pass of
+// the row sort, reading the caller's int64 rows.  fold: the scatter scans the tile totals itself;
+// callers that read w.tiles afterwards ask for the separately scanned form.
+static int sort_pass(const SortWs& w, const int64_t* raw_idx, int64_t n_rows, int32_t* err_flag, const uint32_t* kin,
+                     const uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift, int bits,
+                     bool allow_fold, hipStream_t st) {
   const int nb = (int)rx_cdiv(n, SORT_TILE);
   const int bins = 1 << bits;
   const int64_t entries = (int64_t)nb * bins;
   const int n_tiles = (int)rx_cdiv(entries, SCAN_TILE);
-  hipLaunchKernelGGL(sort_hist_kernel, dim3(nb), dim3(RX_BLOCK), bins * sizeof(uint32_t), st, kin, n, shift, bits, w.hist, nb);
+  const bool fold = allow_fold && n_tiles <= SCAN_FOLD_MAX;
+  const size_t hl = bins * sizeof(uint32_t), sl = SORT_WAVES * bins * sizeof(uint32_t);
+  if (raw_idx) hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)raw_idx, n, n_rows, shift, bits, w.hist, nb, err_flag);
+  else hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)kin, n, n_rows, shift, bits, w.hist, nb, err_flag);
   RX_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.hist, entries, w.tiles);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
-  RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sort_scatter_kernel, dim3(nb), dim3(RX_BLOCK), SORT_WAVES * bins * sizeof(uint32_t), st, kin, vin, n, shift, bits, w.hist, w.tiles, nb, kout, vout);
+  if (!fold) {
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
+    RX_LAUNCH_CHECK();
+  }
+#define SCATTER(RAWV, FOLDV, KEYS) \
+  hipLaunchKernelGGL((sort_scatter_kernel<RAWV, FOLDV>), dim3(nb), dim3(RX_BLOCK), sl, st, (const void*)(KEYS), vin, n, n_rows, shift, bits, w.hist, w.tiles, n_tiles, nb, kout, vout)
+  if (raw_idx && fold) SCATTER(true, true, raw_idx);
+  else if (raw_idx) SCATTER(true, false, raw_idx);
+  else if (fold) SCATTER(false, true, kin);
+  else SCATTER(false, false, kin);
+#undef SCATTER
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -338,22 +403,24 @@ extern "C" int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, in
   int passes, bits;
   sort_plan(n_rows, &passes, &bits);
 
-  hipLaunchKernelGGL(sort_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, n_rows, w.ka, w.va, err_flag);
-  RX_LAUNCH_CHECK();
   uint32_t *kin = w.ka, *kout = w.kb, *vin = w.va, *vout = w.vb;
   for (int p = 0; p < passes; ++p) {
-    if (sort_pass(w, kin, vin, kout, vout, n, p * bits, bits, st)) return 1;
+    if (sort_pass(w, p == 0 ? d_idx : nullptr, n_rows, err_flag, kin, vin, kout, vout, n, p * bits, bits, true, st)) return 1;
     uint32_t* t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }
   const int ndb = (int)rx_cdiv(n, DEDUP_TILE);
-  const int n_tiles = (int)rx_cdiv(ndb, SCAN_TILE);
   hipLaunchKernelGGL(dedup_count_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, n, w.counts);
   RX_LAUNCH_CHECK();
-  // exclusive scan of the block counts: tiles in place + totals, then fold the totals back in
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
-  RX_LAUNCH_CHECK();
-  if (n_tiles > 1) {
+  if (ndb <= (1 << 18)) {
+    // few enough block counts for one block to scan in place
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.counts, (int64_t)ndb);
+    RX_LAUNCH_CHECK();
+  } else {
+    // tiles in place + totals, then fold the totals back in
+    const int n_tiles = (int)rx_cdiv(ndb, SCAN_TILE);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
+    RX_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
     RX_LAUNCH_CHECK();
     hipLaunchKernelGGL(add_tile_offsets_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
@@ -428,7 +495,7 @@ extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G,
   while ((1 << bits) < G + 1) ++bits;  // one spare bin so that bin G marks the end of bin G-1
   hipLaunchKernelGGL(owner_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, G, n_rows_global, w.ka, w.va, err_flag);
   RX_LAUNCH_CHECK();
-  if (sort_pass(w, w.ka, w.va, w.kb, w.vb, n, 0, bits, st)) return 1;
+  if (sort_pass(w, nullptr, n_rows_global, err_flag, w.ka, w.va, w.kb, w.vb, n, 0, bits, false, st)) return 1;
   const int64_t work = n > G ? n : G;
   hipLaunchKernelGGL(owner_finish_kernel, dim3((unsigned)rx_cdiv(work, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, w.vb, n, G, n_rows_global, w.hist, w.tiles, nb, d_counts, d_send_local, d_perm);
   RX_LAUNCH_CHECK();
