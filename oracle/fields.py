@@ -34,10 +34,13 @@ def field_fm_logits(P, inputs, field_dims, **_):
     return bias + fm_second_order(e[:, :-1], e[:, -1:])
 
 
-def _tower_input(e, dense):
-    # [last field, field 0..n-2, dense]
+def _tower_input(e, dense, width=None):
+    # [last field, field 0..n-2, dense, zero columns up to the first layer's input width]
     x = torch.cat([e[:, -1], e[:, :-1].reshape(e.shape[0], -1)], 1)
-    return torch.cat([x, dense], 1) if dense is not None and dense.shape[1] else x
+    x = torch.cat([x, dense], 1) if dense is not None and dense.shape[1] else x
+    if width is not None and width > x.shape[1]:
+        x = F.pad(x, (0, width - x.shape[1]))
+    return x
 
 
 def field_deepfm_logits(P, inputs, field_dims, train=False, dropout=0.0, buffers_out=None, **_):
@@ -45,13 +48,13 @@ def field_deepfm_logits(P, inputs, field_dims, train=False, dropout=0.0, buffers
     e, idx = _rows(P, "feature_embedding.weight", inputs["sparse"], field_dims)
     bias = P["bias_embedding.weight"][:, 0][idx].sum(1, keepdim=True)
     fm = fm_second_order(e[:, :-1], e[:, -1:])
-    x = _tower_input(e, inputs.get("dense"))
+    x = _tower_input(e, inputs.get("dense"), P["deep_mlp.0.weight"].shape[1])
     return bias + fm + _bn_tower(P, "deep_mlp", x, train, buffers_out, dropout)
 
 
 def dcnv2_logits(P, inputs, field_dims, **_):
     e, _ = _rows(P, "feature_embedding.weight", inputs["sparse"], field_dims)
-    x0 = _tower_input(e, inputs.get("dense"))
+    x0 = _tower_input(e, inputs.get("dense"), P["cross.0.weight"].shape[1])
     x = x0
     l = 0
     while f"cross.{l}.weight" in P:

@@ -304,6 +304,205 @@ gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------- bf16 operands, pipelined
+// The kernel the aligned shapes take (16-byte aligned operands, leading dimensions and
+// contiguous extents that are multiples of 4, K-contiguous reduction lengths multiples of 8).
+//   * 128x128 tile, 2x2 waves, each wave 2x2 MFMA tiles of v_mfma_f32_32x32x16_bf16
+//   * the next K-step's global loads are issued before the current step's MFMAs and land in
+//     registers; they are rounded to bf16 (v_cvt_pk_bf16_f32) and written to the other LDS buffer
+//     after the MFMAs: one barrier per K-step, global latency behind matrix work
+//   * an operand that is contiguous along K is kept [row][32 + 8] and read 16 bytes per lane;
+//     an operand that is contiguous along M/N (dY and X of the weight gradient, W of the input
+//     gradient) is kept as loaded, [k][128 + 32], and read through ds_read_b64_tr_b16, the
+//     transposing LDS read: no transposing stores, no second copy of the activations.
+//     Row strides of 80 and 320 bytes keep both kinds of read off shared banks.
+//   * workgroups that share an A panel are placed on one XCD so the panel stays in that L2.
+#define G2_BK 32
+#define G2_LDK (G2_BK + 8)
+#define G2_T 128
+#define G2_LDR (G2_T + 32)
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  f32x2_t v = {a, b};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&r);
+}
+
+// One operand tile in flight: 16 floats per thread.
+struct G2Regs { float4 v[4]; };
+
+// K-contiguous operand: tile rows r0.., 32 k from k0; thread = (row tid/4 [+64], 8 k at (tid%4)*8)
+__device__ __forceinline__ void g2_load_kc(const float* __restrict__ P, int64_t rs, int64_t r0, int64_t r_lim,
+                                           int64_t k0, int64_t k_end, int tid, G2Regs& t) {
+  const int64_t k = k0 + (tid & 3) * 8;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int64_t row = r0 + (tid >> 2) + 64 * p;
+    const bool ok = row < r_lim && k < k_end;
+    const float* src = P + (ok ? row : 0) * rs + (ok ? k : 0);
+    float4 a = *reinterpret_cast<const float4*>(src);
+    float4 b = *reinterpret_cast<const float4*>(src + 4);
+    if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    t.v[2 * p] = a;
+    t.v[2 * p + 1] = b;
+  }
+}
+
+__device__ __forceinline__ void g2_store_kc(uint16_t* lds, int tid, const G2Regs& t) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    uint4 o;
+    o.x = pack_bf16(t.v[2 * p].x, t.v[2 * p].y);
+    o.y = pack_bf16(t.v[2 * p].z, t.v[2 * p].w);
+    o.z = pack_bf16(t.v[2 * p + 1].x, t.v[2 * p + 1].y);
+    o.w = pack_bf16(t.v[2 * p + 1].z, t.v[2 * p + 1].w);
+    *reinterpret_cast<uint4*>(&lds[((tid >> 2) + 64 * p) * G2_LDK + (tid & 3) * 8]) = o;
+  }
+}
+
+// M/N-contiguous operand: 32 k-rows of 128 contiguous elements from c0; thread = (k-row tid/32 [+8],
+// 4 elements at (tid%32)*4)
+__device__ __forceinline__ void g2_load_mc(const float* __restrict__ P, int64_t ks, int64_t c0, int64_t c_lim,
+                                           int64_t k0, int64_t k_end, int tid, G2Regs& t) {
+  const int64_t c = c0 + (tid & 31) * 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t k = k0 + (tid >> 5) + 8 * p;
+    const bool ok = k < k_end && c < c_lim;
+    float4 a = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
+    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    t.v[p] = a;
+  }
+}
+
+__device__ __forceinline__ void g2_store_mc(uint16_t* lds, int tid, const G2Regs& t) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    uint2 o;
+    o.x = pack_bf16(t.v[p].x, t.v[p].y);
+    o.y = pack_bf16(t.v[p].z, t.v[p].w);
+    *reinterpret_cast<uint2*>(&lds[((tid >> 5) + 8 * p) * G2_LDR + (tid & 31) * 4]) = o;
+  }
+}
+
+// MFMA operand (32 rows from `base`, k = ks + 8*(lane>>5) .. +7) out of either LDS image.
+template <bool KC>
+__device__ __forceinline__ bf16x8 g2_frag(const uint16_t* lds, int base, int ks, int lane) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const bf16x8*>(&lds[(base + (lane & 31)) * G2_LDK + ks + 8 * (lane >> 5)]);
+  } else {
+    // per 16-lane group the transposing read takes a 4(k) x 16(column) block: lane 4q+p supplies
+    // the address of k-row q, columns 4p..4p+3, and receives column (lane & 15), k-rows 0..3
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const uint16_t* a0 = &lds[(ks + 8 * (lane >> 5) + q) * G2_LDR + base + 16 * ((lane >> 4) & 1) + 4 * pp];
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * G2_LDR));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool A_KC, bool B_KC, bool ACCUM>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemm_bf16_pipe_kernel(GemmArgs g, int swizzle) {
+  constexpr int A_SZ = A_KC ? G2_T * G2_LDK : G2_BK * G2_LDR;
+  constexpr int B_SZ = B_KC ? G2_T * G2_LDK : G2_BK * G2_LDR;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][A_SZ + B_SZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs;
+  // give each XCD a contiguous run of logical tiles (which share A panels)
+  int64_t bid = blockIdx.x;
+  if (swizzle) bid = (bid % 8) * (gridDim.x / 8) + bid / 8;
+  const int64_t tile_m = bid / g.tiles_n;
+  const int tile_n = (int)(bid % g.tiles_n);
+  const int64_t m0 = tile_m * G2_T;
+  const int64_t n0 = (int64_t)tile_n * G2_T;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
+  const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  G2Regs ra, rb;
+  auto fetch = [&](int64_t k0) {
+    if constexpr (A_KC) g2_load_kc(g.A, g.a_rs, m0, g.M, k0, k_end, tid, ra);
+    else g2_load_mc(g.A, g.a_cs, m0, g.M, k0, k_end, tid, ra);
+    if constexpr (B_KC) g2_load_kc(g.B, g.b_cs, n0, g.N, k0, k_end, tid, rb);
+    else g2_load_mc(g.B, g.b_rs, n0, g.N, k0, k_end, tid, rb);
+  };
+  auto stash = [&](int buf) {
+    if constexpr (A_KC) g2_store_kc(lds[buf], tid, ra);
+    else g2_store_mc(lds[buf], tid, ra);
+    if constexpr (B_KC) g2_store_kc(lds[buf] + A_SZ, tid, rb);
+    else g2_store_mc(lds[buf] + A_SZ, tid, rb);
+  };
+
+  fetch(k_begin);
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += G2_BK) {
+    const bool more = k0 + G2_BK < k_end;
+    if (more) fetch(k0 + G2_BK);
+    const uint16_t* As = lds[cur];
+    const uint16_t* Bs = lds[cur] + A_SZ;
+#pragma unroll
+    for (int ks = 0; ks < G2_BK; ks += 16) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = g2_frag<A_KC>(As, (wave_m * 2 + i) * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = g2_frag<B_KC>(Bs, (wave_n * 2 + j) * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cb = g.C + (int64_t)blockIdx.z * g.c_slab_stride;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + (wave_n * 2 + j) * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == 1) v = v > 0.f ? v : 0.f;
+          float* dst = Cb + row * g.c_rs + col;
+          *dst = ACCUM ? (*dst + v) : v;
+        }
+      }
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s][i] in slab order
 __global__ void __launch_bounds__(RX_BLOCK)
 slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, float* __restrict__ out) {
@@ -331,9 +530,33 @@ colsum_slab_kernel(const float* __restrict__ dY, int64_t ldd, int64_t M, int N, 
   if (q == 0 && j < N) partial[(int64_t)blockIdx.z * N + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Shapes the pipelined bf16 kernel takes: 16-byte loads must be legal wherever it issues them.
+template <bool A_KC, bool B_KC>
+static bool pipe_ok(const GemmArgs& g) {
+  if (!g.a_vec || !g.b_vec) return false;
+  // K-contiguous operands are read 8 k at a time (every slab starts at a multiple of 32);
+  // M/N-contiguous ones 4 elements at a time along M/N
+  if ((A_KC || B_KC) && (g.K % 8 != 0)) return false;
+  if (!A_KC && (g.M % 4 != 0)) return false;
+  if (!B_KC && (g.N % 4 != 0)) return false;
+  if (g.k_per_slab % G2_BK != 0 && g.k_per_slab < g.K) return false;
+  return true;
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
   const int64_t tiles_m = rx_cdiv(g.M, 128);
+  if (bf16 && g.N > 64 && pipe_ok<A_KC, B_KC>(g)) {
+    g.tiles_n = (int)rx_cdiv(g.N, G2_T);
+    const int64_t blocks = tiles_m * g.tiles_n;
+    RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");
+    dim3 grid((unsigned)blocks, 1, (unsigned)n_slabs);
+    const int swz = (blocks % 8 == 0) ? 1 : 0;
+    if (g.accumulate) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<A_KC, B_KC, true>), grid, dim3(RX_BLOCK), 0, st, g, swz);
+    else hipLaunchKernelGGL((gemm_bf16_pipe_kernel<A_KC, B_KC, false>), grid, dim3(RX_BLOCK), 0, st, g, swz);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
 #define RX_GEMM_GO(BN_, WM_, WN_)                                                                       \
   do {                                                                                                  \
     g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \

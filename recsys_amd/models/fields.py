@@ -95,24 +95,35 @@ class FieldDeepFM(_FieldTable):
         self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
         self.bias_embedding = nn.Embedding(self.n_features, 1)
         d_in = self.n_fields * embedding_dim + n_dense
+        self.pad = _tower_pad(d_in, n_dense)
+        d_in += self.pad
         self.deep_mlp = _bn_stack(d_in, [d_in, d_in // 2, d_in // 4], dropout)
 
     def forward(self, inputs):
         ex, base, item, item_base = self._split(inputs)
         d_emb = self.n_fields * self.embedding_dim
         fm, x = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
-                              self.bias_embedding.weight, True, True, d_emb + self.n_dense, True,
-                              _dense_input(inputs, self.n_dense, ex.shape[0]), inputs.get("_rx_presort"))
+                              self.bias_embedding.weight, True, True, d_emb + self.n_dense + self.pad, True,
+                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
         return fm + run_tower(self.deep_mlp, x)
 
 
-def _dense_input(inputs, n_dense, rows):
+def _dense_input(inputs, n_dense, rows, pad=0):
+    """The dense features, followed by ``pad`` zero columns (see ``_tower_pad``)."""
     if not n_dense:
         return None
     dense = inputs["dense"]
     if dense.dtype != torch.float32 or tuple(dense.shape) != (rows, n_dense):
         raise ValueError(f"dense: expected fp32 [{rows}, {n_dense}]")
-    return dense
+    return torch.nn.functional.pad(dense, (0, pad)) if pad else dense
+
+
+def _tower_pad(width, n_dense):
+    """Zero columns appended to the tower input so that its width is a multiple of 16: rows of
+    the activations and of the first weights are then whole 16-byte vectors and whole MFMA k-steps
+    (Criteo shape: 26 * 16 + 13 = 429 -> 432).  The padding is inert: it multiplies weight columns
+    that therefore receive zero gradient, and a DCN-v2 cross layer keeps a zero coordinate zero."""
+    return (-width) % 16 if n_dense else 0
 
 
 class DCNv2(_FieldTable):
@@ -127,6 +138,8 @@ class DCNv2(_FieldTable):
         self.n_dense, self.bf16 = n_dense, bf16
         self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
         d = self.n_fields * embedding_dim + n_dense
+        self.pad = _tower_pad(d, n_dense)
+        d += self.pad
         self.input_dim = d
         self.cross = nn.ModuleList([nn.Linear(d, d) for _ in range(n_cross)])
         layers, i = [], d
@@ -141,8 +154,8 @@ class DCNv2(_FieldTable):
         ex, base, item, item_base = self._split(inputs)
         d_emb = self.n_fields * self.embedding_dim
         _, x0 = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight, None, True, False,
-                              d_emb + self.n_dense, False, _dense_input(inputs, self.n_dense, ex.shape[0]),
-                              inputs.get("_rx_presort"))
+                              d_emb + self.n_dense + self.pad, False,
+                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
         x = x0
         for layer in self.cross:
             x = rxa.CrossLayer.apply(x0, x, layer.weight, layer.bias, self.bf16)

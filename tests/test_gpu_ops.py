@@ -236,6 +236,25 @@ def test_linear_bf16_within_1e2(ops, M, N, K):
     assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=1e-2, what="bf16 bwd w")
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 200, 136), (260, 132, 40), (4096, 1024, 432), (8192, 96, 72), (128, 128, 32)])
+def test_linear_bf16_exact_on_rounded_operands(ops, M, N, K):
+    """With operands that are already bf16 values the bf16-operand kernels (pipelined path:
+    N > 64, aligned shapes) must match an fp32-accumulating reference to rounding: catches any
+    tile, transposing-read or edge-masking mistake that a 1e-2 tolerance would hide."""
+    g = _gen(M + N + K)
+    r = lambda *sh: torch.randn(*sh, generator=g).bfloat16().float()
+    x, w, b, dy = r(M, K), r(N, K) / 8, r(N), r(M, N)
+    w = w.bfloat16().float()
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), 1, bf16=True).cpu()
+    exp = torch.nn.functional.linear(x.double(), w.double(), b.double()).relu()
+    assert_close(y.numpy(), exp.numpy(), rtol=2e-6, what="bf16 fwd on rounded operands")
+    dx = ops.linear_bwd_x(dy.cuda(), w.cuda(), bf16=True).cpu()
+    assert_close(dx.numpy(), (dy.double() @ w.double()).numpy(), rtol=2e-6, what="bf16 bwd x on rounded operands")
+    dw, db = ops.linear_bwd_w(dy.cuda(), x.cuda(), bf16=True)
+    assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=2e-5, what="bf16 bwd w on rounded operands")
+    assert_close(db.cpu().numpy(), dy.double().sum(0).numpy(), rtol=2e-5, what="bf16 bwd b")
+
+
 def test_linear_on_column_block(ops):
     g = _gen(2)
     wide = torch.randn(200, 96, generator=g).cuda()
