@@ -513,21 +513,192 @@ slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, floa
   out[i] = s;
 }
 
-// partial[z][j] = sum over the slab's rows of dY[row, j]
+// ---------------------------------------------------------------- fp32 operands, pipelined
+// Same pipeline as above on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation in k
+// order): 128x128 tile, 16 k per step, LDS tiles k-major [16][128 + 4] so that the operand read
+// (one float per lane, 32 consecutive rows per half-wave) is conflict free.
+#define G3_BK 16
+#define G3_LD (G2_T + 4)
+
+struct G3Regs { float4 v[2]; };
+
+// K-contiguous: thread = (row tid/4 [+64], 4 k at (tid%4)*4); M/N-contiguous: (k-row tid/32 [+8], 4 at (tid%32)*4)
+__device__ __forceinline__ void g3_load_kc(const float* __restrict__ P, int64_t rs, int64_t r0, int64_t r_lim,
+                                           int64_t k0, int64_t k_end, int tid, G3Regs& t) {
+  const int64_t k = k0 + (tid & 3) * 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int64_t row = r0 + (tid >> 2) + 64 * p;
+    const bool ok = row < r_lim && k < k_end;
+    float4 a = *reinterpret_cast<const float4*>(P + (ok ? row : 0) * rs + (ok ? k : 0));
+    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    t.v[p] = a;
+  }
+}
+
+__device__ __forceinline__ void g3_store_kc(float* lds, int tid, const G3Regs& t) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float* dst = lds + ((tid & 3) * 4) * G3_LD + (tid >> 2) + 64 * p;
+    dst[0] = t.v[p].x; dst[G3_LD] = t.v[p].y; dst[2 * G3_LD] = t.v[p].z; dst[3 * G3_LD] = t.v[p].w;
+  }
+}
+
+__device__ __forceinline__ void g3_load_mc(const float* __restrict__ P, int64_t ks, int64_t c0, int64_t c_lim,
+                                           int64_t k0, int64_t k_end, int tid, G3Regs& t) {
+  const int64_t c = c0 + (tid & 31) * 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int64_t k = k0 + (tid >> 5) + 8 * p;
+    const bool ok = k < k_end && c < c_lim;
+    float4 a = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
+    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    t.v[p] = a;
+  }
+}
+
+__device__ __forceinline__ void g3_store_mc(float* lds, int tid, const G3Regs& t) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+    *reinterpret_cast<float4*>(lds + ((tid >> 5) + 8 * p) * G3_LD + (tid & 31) * 4) = t.v[p];
+}
+
+template <bool A_KC, bool B_KC, bool ACCUM>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemm_f32_pipe_kernel(GemmArgs g, int swizzle) {
+  constexpr int T_SZ = G3_BK * G3_LD;
+  __shared__ __attribute__((aligned(16))) float lds[2][2 * T_SZ];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  int64_t bid = blockIdx.x;
+  if (swizzle) bid = (bid % 8) * (gridDim.x / 8) + bid / 8;
+  const int64_t tile_m = bid / g.tiles_n;
+  const int tile_n = (int)(bid % g.tiles_n);
+  const int64_t m0 = tile_m * G2_T;
+  const int64_t n0 = (int64_t)tile_n * G2_T;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
+  const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  G3Regs ra, rb;
+  auto fetch = [&](int64_t k0) {
+    if constexpr (A_KC) g3_load_kc(g.A, g.a_rs, m0, g.M, k0, k_end, tid, ra);
+    else g3_load_mc(g.A, g.a_cs, m0, g.M, k0, k_end, tid, ra);
+    if constexpr (B_KC) g3_load_kc(g.B, g.b_cs, n0, g.N, k0, k_end, tid, rb);
+    else g3_load_mc(g.B, g.b_rs, n0, g.N, k0, k_end, tid, rb);
+  };
+  auto stash = [&](int buf) {
+    if constexpr (A_KC) g3_store_kc(lds[buf], tid, ra);
+    else g3_store_mc(lds[buf], tid, ra);
+    if constexpr (B_KC) g3_store_kc(lds[buf] + T_SZ, tid, rb);
+    else g3_store_mc(lds[buf] + T_SZ, tid, rb);
+  };
+
+  fetch(k_begin);
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  const int h = lane >> 5, l31 = lane & 31;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += G3_BK) {
+    const bool more = k0 + G3_BK < k_end;
+    if (more) fetch(k0 + G3_BK);
+    const float* As = lds[cur];
+    const float* Bs = lds[cur] + T_SZ;
+#pragma unroll
+    for (int kk = 0; kk < G3_BK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[(kk + h) * G3_LD + (wave_m * 2 + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + h) * G3_LD + (wave_n * 2 + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* Cb = g.C + (int64_t)blockIdx.z * g.c_slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + (wave_n * 2 + j) * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M) {
+          float v = acc[i][j][r] + bv;
+          if (g.act == 1) v = v > 0.f ? v : 0.f;
+          float* dst = Cb + row * g.c_rs + col;
+          *dst = ACCUM ? (*dst + v) : v;
+        }
+      }
+    }
+  }
+}
+
+// partial[z][j] = sum over the slab's rows of dY[row, j].  A block covers 64 columns with
+// 16 row lanes of 16-byte loads (four rows in flight per thread); VEC = false is the scalar
+// form for unaligned dY.
+#define COLSUM_SLABS 64
+template <bool VEC>
 __global__ void __launch_bounds__(RX_BLOCK)
 colsum_slab_kernel(const float* __restrict__ dY, int64_t ldd, int64_t M, int N, int64_t rows_per_slab,
                    float* __restrict__ partial) {
-  __shared__ float red[4][64];
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int q = threadIdx.x >> 6;  // 4 row-lanes
+  __shared__ float red[16][64 + 1];
+  const int cq = threadIdx.x & 15;   // column quad
+  const int rl = threadIdx.x >> 4;   // row lane
+  const int j0 = blockIdx.x * 64 + cq * 4;
   const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
   const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
-  float s = 0.f;
-  if (j < N)
-    for (int64_t r = lo + q; r < hi; r += 4) s += dY[r * ldd + j];
-  red[q][threadIdx.x & 63] = s;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (j0 < N) {  // N % 4 == 0 on this path
+      int64_t r = lo + rl;
+      for (; r + 48 < hi; r += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(dY + (r + 16 * u) * ldd + j0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+      }
+      for (; r < hi; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(dY + r * ldd + j0);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      }
+    }
+  } else {
+    for (int64_t r = lo + rl; r < hi; r += 16)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j0 + e < N) s[e] += dY[r * ldd + j0 + e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
   __syncthreads();
-  if (q == 0 && j < N) partial[(int64_t)blockIdx.z * N + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 64) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    if (j < N) partial[(int64_t)blockIdx.z * N + j] = t;
+  }
 }
 
 // Shapes the pipelined bf16 kernel takes: 16-byte loads must be legal wherever it issues them.
@@ -544,6 +715,16 @@ static bool pipe_ok(const GemmArgs& g) {
 }
 
 template <bool A_KC, bool B_KC>
+static bool pipe_ok_f32(const GemmArgs& g) {
+  if (!g.a_vec || !g.b_vec) return false;
+  if ((A_KC || B_KC) && (g.K % 4 != 0)) return false;
+  if (!A_KC && (g.M % 4 != 0)) return false;
+  if (!B_KC && (g.N % 4 != 0)) return false;
+  if (g.k_per_slab % G3_BK != 0 && g.k_per_slab < g.K) return false;
+  return true;
+}
+
+template <bool A_KC, bool B_KC>
 static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
   const int64_t tiles_m = rx_cdiv(g.M, 128);
   if (bf16 && g.N > 64 && pipe_ok<A_KC, B_KC>(g)) {
@@ -554,6 +735,17 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
     const int swz = (blocks % 8 == 0) ? 1 : 0;
     if (g.accumulate) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<A_KC, B_KC, true>), grid, dim3(RX_BLOCK), 0, st, g, swz);
     else hipLaunchKernelGGL((gemm_bf16_pipe_kernel<A_KC, B_KC, false>), grid, dim3(RX_BLOCK), 0, st, g, swz);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (!bf16 && g.N > 64 && pipe_ok_f32<A_KC, B_KC>(g)) {
+    g.tiles_n = (int)rx_cdiv(g.N, G2_T);
+    const int64_t blocks = tiles_m * g.tiles_n;
+    RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");
+    dim3 grid((unsigned)blocks, 1, (unsigned)n_slabs);
+    const int swz = (blocks % 8 == 0) ? 1 : 0;
+    if (g.accumulate) hipLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC, true>), grid, dim3(RX_BLOCK), 0, st, g, swz);
+    else hipLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC, false>), grid, dim3(RX_BLOCK), 0, st, g, swz);
     RX_LAUNCH_CHECK();
     return 0;
   }
@@ -614,9 +806,9 @@ extern "C" int rx_linear_bwd_x(const float* dY, int64_t ldd, const float* W, flo
 }
 
 static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
-  // enough slabs to put >= ~512 blocks on the chip, each slab a multiple of the k-step
+  // enough slabs to put >= ~768 blocks (three per CU) on the chip, each slab a multiple of the k-step
   const int64_t tiles = rx_cdiv(N, 128) * rx_cdiv(K, (K <= 32 ? 32 : (K <= 64 ? 64 : 128)));
-  int64_t want = rx_cdiv(512, tiles);
+  int64_t want = rx_cdiv(768, tiles);
   int64_t max_by_rows = rx_cdiv(M, 256);
   if (want > max_by_rows) want = max_by_rows;
   if (want < 1) want = 1;
@@ -627,7 +819,7 @@ static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
 extern "C" size_t rx_linear_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   if (M <= 0 || N < 1 || K < 1) return 256;
   const int s = bwd_w_slabs(M, N, K);
-  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up((size_t)s * N * sizeof(float), 256);
+  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up((size_t)COLSUM_SLABS * N * sizeof(float), 256);
 }
 
 extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, float* dW,
@@ -656,9 +848,15 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, RX_BLOCK)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW);
   RX_LAUNCH_CHECK();
   if (db) {
-    hipLaunchKernelGGL(colsum_slab_kernel, dim3((unsigned)rx_cdiv(N, 64), 1, (unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY, ldd, M, N, rows_per_slab, bpart);
+    // the bias gradient has its own, finer slabs: the column sums are a pure streaming read
+    int64_t cs_rows = rx_cdiv(M, COLSUM_SLABS);
+    cs_rows = rx_cdiv(cs_rows, 16) * 16;
+    const int cs = (int)rx_cdiv(M, cs_rows);
+    const dim3 cgrid((unsigned)rx_cdiv(N, 64), 1, (unsigned)cs);
+    if (vec_ok(dY, ldd) && N % 4 == 0) hipLaunchKernelGGL(colsum_slab_kernel<true>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
+    else hipLaunchKernelGGL(colsum_slab_kernel<false>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
     RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, RX_BLOCK)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, n_slabs, db);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, RX_BLOCK)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, cs, db);
     RX_LAUNCH_CHECK();
   }
   return 0;
