@@ -111,7 +111,11 @@ def one_step(w, i):
     batch = w["batches"][i % len(w["batches"])]
     w["opt"].zero_grad()
     loss = w["model"].loss(batch)
-    (loss * w["loss_scale"] if w.get("loss_scale") else loss).backward()
+    if w.get("loss_scale"):
+        (loss * w["loss_scale"]).backward()
+    else:
+        from recsys_amd.autograd import backward_from_loss
+        backward_from_loss(loss)
     w["opt"].step()
     return loss
 

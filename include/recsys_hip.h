@@ -266,11 +266,12 @@ int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, int64_t n_
 
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above
- * (SGD / ADAGRAD / ROWWISE_ADAGRAD). */
+ * (SGD / ADAGRAD / ROWWISE_ADAGRAD).  d_compact2 [*n_uniq] / d_w2 / d_state2: compact gradient,
+ * table and Adagrad state of the companion scalar table updated in the same launch, or NULL. */
 int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
                   const int32_t* d_n_uniq, int64_t n_max, int mode, float* d_w, float* d_state,
-                  int64_t n_rows, float lr, float eps, const float* d_scale, int device,
-                  void* stream);
+                  const float* d_compact2, float* d_w2, float* d_state2, int64_t n_rows, float lr,
+                  float eps, const float* d_scale, int device, void* stream);
 
 /* Dense full-table optimizers for MovieLens-sized tables and tower weights, one launch per
  * tensor: torch.optim.Adam(lr, betas, eps) exactly as recsys/pipelines/ build it
@@ -294,6 +295,10 @@ int rx_sum_accumulate(const float* d_x, int64_t n, double* d_acc, void* ws, size
                       int device, void* stream);
 int rx_clip_scale(const double* d_acc, float max_norm, float* d_scale, float* d_total_norm,
                   int device, void* stream);
+/* The same factor from per-block partial sums of squares (the d_sq_part of rx_segreduce /
+ * rx_segreduce_fm) in one launch: total = (d_acc ? *d_acc : 0) + sum(d_parts[0..n_parts)). */
+int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_acc, float max_norm,
+                        float* d_scale, float* d_total_norm, int device, void* stream);
 /* out[0] = sum(x) (fp64 accumulate, fixed order): gradient of a scalar bias that is added to
  * every logit (bias_mf.py:12,17; the Linear(D,1) bias of gmf.py:20). Same workspace size. */
 int rx_reduce_sum(const float* d_x, int64_t n, float* d_out, void* ws, size_t ws_bytes, int device,

@@ -61,7 +61,7 @@ PROTOTYPES = {
     "rx_segreduce_workspace_bytes": (sz, [i64, i32]),
     "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
     "rx_segreduce_fm": (C.c_int, [vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
-    "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
     "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),
     "rx_dense_adagrad": (C.c_int, [vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
@@ -69,6 +69,7 @@ PROTOTYPES = {
     "rx_sumsq_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_sum_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_clip_scale": (C.c_int, [vp, f32, vp, vp, C.c_int, vp]),
+    "rx_clip_scale_parts": (C.c_int, [vp, i64, vp, f32, vp, vp, C.c_int, vp]),
     "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_linear_bwd_x": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

@@ -291,6 +291,29 @@ class CrossLayer(Function):
 
 
 # ------------------------------------------------------------------ loss
+_UNIT_LOSS_GRAD = False
+_ONES = {}
+
+
+def backward_from_loss(loss: Tensor) -> None:
+    """``loss.backward()`` for a loss that is the direct output of ``bce_with_logits``: the root
+    gradient is a cached device 1 and the loss function hands on its saved dL/dlogit unscaled, which
+    removes three tiny launches (fill, cast, multiply) from the step's critical path."""
+    global _UNIT_LOSS_GRAD
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ == "BCEWithLogitsBackward"):
+        loss.backward(gradient=one)
+        return
+    _UNIT_LOSS_GRAD = True
+    try:
+        loss.backward(gradient=one)
+    finally:
+        _UNIT_LOSS_GRAD = False
+
+
 class BCEWithLogits(Function):
     """Mean BCE-with-logits; fp64 loss when the labels are fp64, like the reference."""
 
@@ -304,6 +327,8 @@ class BCEWithLogits(Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
+        if _UNIT_LOSS_GRAD:  # set by backward_from_loss: g is exactly 1
+            return dl.reshape(ctx.shape), None
         return (dl * g.to(torch.float32)).reshape(ctx.shape), None
 
 

@@ -653,16 +653,22 @@ row_update_kernel(SegArgs a) {
   Acc<VEC, CH> x, st;
   ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
   load_old<VEC, CH, MODE, false>(a, row, lg, x, st);
-  apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, a.scale ? a.scale[0] : 1.f);
+  const float scale = a.scale ? a.scale[0] : 1.f;
+  apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, scale);
+  // companion scalar table addressed by the same rows
+  if (a.target2 && lg == 0) apply_scalar<MODE>(a, a.occ2[u], row, u, scale);
 }
 
 extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
                              const int32_t* d_n_uniq, int64_t n_max, int mode, float* d_w,
-                             float* d_state, int64_t n_rows, float lr, float eps,
-                             const float* d_scale, int device, void* stream) {
+                             float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                             int64_t n_rows, float lr, float eps, const float* d_scale, int device,
+                             void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n_max >= 0 && dim >= 1 && dim <= RX_MAX_DIM, "rx_row_update: bad shape");
   if (mode_check(mode, d_state, "rx_row_update", false)) return 1;
+  RX_REQUIRE((d_compact2 == nullptr) == (d_w2 == nullptr), "rx_row_update: companion gradient and table come as a pair");
+  RX_REQUIRE(!d_w2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || d_state2, "rx_row_update: companion Adagrad state missing");
   if (n_max == 0) return 0;
   RX_REQUIRE(d_compact && d_uniq_rows && d_n_uniq && d_w && n_rows >= 1, "rx_row_update: null argument");
   RxRowShape sh;
@@ -670,6 +676,7 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   SegArgs a{};
   a.occ = d_compact; a.occ_ld = dim; a.n = n_max; a.dim = dim; a.uniq_rows = d_uniq_rows; a.n_uniq = d_n_uniq;
   a.mode = mode; a.target = d_w; a.state = d_state; a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
+  a.occ2 = d_compact2; a.target2 = d_w2; a.state2 = d_state2;
   a.group = sh.group;
   const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
   SEG_DISPATCH_F(mode, false, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
@@ -841,6 +848,34 @@ __global__ void clip_scale_kernel(const double* __restrict__ acc, float max_norm
   const float coef = max_norm / (tn + 1e-6f);
   scale[0] = coef < 1.f ? coef : 1.f;
   if (total_norm) total_norm[0] = tn;
+}
+
+// One block: thread t adds parts[t], parts[t + 256], ... in order (fp64), fixed xor trees and a
+// fixed order over the four waves join them; then the clip factor.
+__global__ void __launch_bounds__(RX_BLOCK)
+clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double* __restrict__ acc, float max_norm,
+                        float* __restrict__ scale, float* __restrict__ total_norm) {
+  __shared__ double wsum[RX_BLOCK / 64];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += RX_BLOCK) s += (double)parts[i];
+  s = rx_wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double total = (acc ? acc[0] : 0.0) + ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+  const float tn = (float)sqrt(total);
+  const float coef = max_norm / (tn + 1e-6f);
+  scale[0] = coef < 1.f ? coef : 1.f;
+  if (total_norm) total_norm[0] = tn;
+}
+
+extern "C" int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_acc, float max_norm,
+                                   float* d_scale, float* d_total_norm, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n_parts >= 0 && (d_parts || n_parts == 0) && d_scale, "rx_clip_scale_parts: bad arguments");
+  hipLaunchKernelGGL(clip_scale_parts_kernel, dim3(1), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_parts, n_parts, d_acc, max_norm, d_scale, d_total_norm);
+  RX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int rx_clip_scale(const double* d_acc, float max_norm, float* d_scale, float* d_total_norm,

@@ -25,6 +25,7 @@ from typing import Dict, List
 import torch
 
 from . import ops
+from .autograd import backward_from_loss
 
 
 class GraphedTrainStep:
@@ -42,7 +43,7 @@ class GraphedTrainStep:
     def _eager(self, batch):
         self.opt.zero_grad()
         loss = self.model.loss(batch)
-        loss.backward()
+        backward_from_loss(loss)
         self.opt.step()
         return loss
 

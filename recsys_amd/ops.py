@@ -490,10 +490,12 @@ def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mod
 
 
 def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
-               scale=None) -> None:
+               scale=None, compact2=None, table2=None, state2=None) -> None:
+    """``compact2`` [n] / ``table2`` / ``state2``: the companion scalar table, updated in the same launch."""
     dim = compact.shape[1] if compact.dim() == 2 else 1
     check(lib.rx_row_update(_p(compact), dim, _p(si.uniq_rows), _p(si.n_uniq), si.n, mode, _p(table), _p(state),
-                            si.n_rows, lr, eps, _p(scale), _dev(table), _stream(table)), "rx_row_update")
+                            _p(compact2), _p(table2), _p(state2), si.n_rows, lr, eps, _p(scale), _dev(table),
+                            _stream(table)), "rx_row_update")
 
 
 # ------------------------------------------------------------------ dense optimizers / reductions
@@ -529,6 +531,16 @@ def clip_scale(acc: Tensor, max_norm: float):
     scale = torch.empty(1, dtype=torch.float32, device=acc.device)
     total = torch.empty(1, dtype=torch.float32, device=acc.device)
     check(lib.rx_clip_scale(_p(acc), max_norm, _p(scale), _p(total), _dev(acc), _stream(acc)), "rx_clip_scale")
+    return scale, total
+
+
+def clip_scale_parts(parts: Tensor, acc: Optional[Tensor], max_norm: float):
+    """Clip factor from per-block partial sums of squares (plus ``acc``, a device double, if given)."""
+    _req(parts, torch.float32, "parts")
+    scale = torch.empty(1, dtype=torch.float32, device=parts.device)
+    total = torch.empty(1, dtype=torch.float32, device=parts.device)
+    check(lib.rx_clip_scale_parts(_p(parts), parts.numel(), _p(acc), max_norm, _p(scale), _p(total), _dev(parts),
+                                  _stream(parts)), "rx_clip_scale_parts")
     return scale, total
 
 

@@ -55,9 +55,7 @@ class SparseRule:
         compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if param2 is not None else None
         sq = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, compact, dim=dim, occ_ld=occ_ld, want_sq=True,
                            occ2=occ2, target2=compact2)
-        self.owner._pending.append((self, param, compact, si, sq))
-        if param2 is not None:
-            self.owner._pending.append((rule2, param2, compact2, si, None))
+        self.owner._pending.append((self, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
 
 
 def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex):
@@ -76,9 +74,7 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex):
     compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
     sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2,
                           want_sq=True)
-    self.owner._pending.append((self, feat, compact, si, sq))
-    if bias_table is not None:
-        self.owner._pending.append((rule2, bias_table, compact2, si, None))
+    self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
 
 
 SparseRule.apply_fm = _rule_apply_fm
@@ -149,18 +145,31 @@ class FusedOptimizer:
         self._step += 1
         scale = None
         if self.clip_norm is not None:
-            dev = (self.dense[0] if self.dense else self.sparse[0]).device
-            acc = torch.zeros(1, dtype=torch.float64, device=dev)
-            for p in self.dense:
-                if p.grad is not None:
-                    ops.sumsq_accumulate(p.grad.contiguous().reshape(-1), acc)
-            for (_, _, _, _, sq) in self._pending:
-                if sq is not None:
+            # global norm: dense gradients go through a device double; the per-block partials of the
+            # last table reduce ride in the launch that forms the clip factor
+            acc = None
+            grads = [p.grad for p in self.dense if p.grad is not None]
+            parts = [e[4] for e in self._pending if e[4] is not None]
+            if grads or len(parts) != 1:
+                dev = (self.dense[0] if self.dense else self.sparse[0]).device
+                acc = torch.zeros(1, dtype=torch.float64, device=dev)
+                for g in grads:
+                    ops.sumsq_accumulate(g.contiguous().reshape(-1), acc)
+                for sq in parts[:-1]:
                     ops.sum_accumulate(sq, acc)
-            scale, self.last_total_norm = ops.clip_scale(acc, float(self.clip_norm))
-            for (rule, param, compact, si, _) in self._pending:
-                ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                               eps=rule.eps, scale=scale)
+            if parts:
+                scale, self.last_total_norm = ops.clip_scale_parts(parts[-1], acc, float(self.clip_norm))
+            else:
+                scale, self.last_total_norm = ops.clip_scale(acc, float(self.clip_norm))
+            for (rule, param, compact, si, _, comp) in self._pending:
+                if comp is not None:
+                    rule2, param2, compact2 = comp
+                    ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                                   eps=rule.eps, scale=scale, compact2=compact2, table2=param2.data,
+                                   state2=rule2._state_for(param2))
+                else:
+                    ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                                   eps=rule.eps, scale=scale)
             self._pending.clear()
         for p in self.dense:
             self._dense_update(p, scale)

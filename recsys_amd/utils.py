@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .autograd import backward_from_loss
 from .metrics import compute_metrics
 from .optim import FusedOptimizer
 
@@ -58,7 +59,7 @@ def train_step(model, optimizer, inputs, clip_norm):
     """One batch of recsys/utils.py:96-103.  Returns the loss tensor (still on the device)."""
     optimizer.zero_grad()
     loss = model.loss(inputs)
-    loss.backward()
+    backward_from_loss(loss)
     if isinstance(optimizer, FusedOptimizer):
         optimizer.clip_norm = clip_norm
     elif clip_norm is not None:

@@ -191,6 +191,44 @@ def test_two_phase_clip_update(ops):
     assert_close(w.cpu().numpy(), wr.detach().numpy(), what="clipped sgd")
 
 
+@pytest.mark.parametrize("mode", ["sgd", "adagrad"])
+def test_two_phase_clip_update_with_companion(ops, mode):
+    """Compact gradients of a table and of its [rows, 1] companion, clip factor formed in one launch
+    from the per-block partials plus a dense-gradient accumulator, both tables updated by one launch."""
+    from recsys_amd import _lib
+    g = _gen(6)
+    n, rows, dim, lr = 3000, 150, 16, 0.5
+    w0, b0 = torch.randn(rows, dim, generator=g), torch.randn(rows, 1, generator=g)
+    idx = torch.randint(0, rows, (n,), generator=g)
+    occ, occ2 = torch.randn(n, dim, generator=g), torch.randn(n, generator=g)
+    dense_g = torch.randn(37, generator=g)
+    si = ops.sort_dedup(idx.cuda(), rows)
+    compact, compact2 = torch.empty(n, dim).cuda(), torch.empty(n).cuda()
+    sq = ops.segreduce(occ.cuda(), si, _lib.RX_SEG_COMPACT, compact, want_sq=True, occ2=occ2.cuda(), target2=compact2)
+    acc = torch.zeros(1, dtype=torch.float64).cuda()
+    ops.sumsq_accumulate(dense_g.cuda(), acc)
+    scale, total = ops.clip_scale_parts(sq, acc, 1.0)
+    w, b = w0.clone().cuda(), b0.clone().cuda()
+    kind = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD}[mode]
+    st = torch.zeros(rows, dim).cuda() if mode == "adagrad" else None
+    st2 = torch.zeros(rows, 1).cuda() if mode == "adagrad" else None
+    ops.row_update(compact, si, kind, w, state=st, lr=lr, eps=1e-10, scale=scale, compact2=compact2, table2=b, state2=st2)
+    wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    dr = torch.zeros(37, requires_grad=True)
+    wr.grad = torch.zeros(rows, dim).index_add_(0, idx, occ)
+    br.grad = torch.zeros(rows, 1).index_add_(0, idx, occ2[:, None])
+    dr.grad = dense_g.clone()
+    tn = torch.nn.utils.clip_grad_norm_([wr, br, dr], 1.0)
+    assert_close(total.item(), tn.item(), what="total norm")
+    opt = torch.optim.SGD([wr, br], lr=lr) if mode == "sgd" else torch.optim.Adagrad([wr, br], lr=lr, eps=1e-10)
+    opt.step()
+    touched = torch.zeros(rows, dtype=torch.bool)
+    touched[idx] = True
+    assert_close(w.cpu().numpy()[touched], wr.detach().numpy()[touched], what=f"{mode} table")
+    assert_close(b.cpu().numpy()[touched], br.detach().numpy()[touched], what=f"{mode} companion")
+    assert torch.equal(w.cpu()[~touched], w0[~touched]) and torch.equal(b.cpu()[~touched], b0[~touched])
+
+
 # ------------------------------------------------------------------ dense layers
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 3, 5), (130, 32, 64), (257, 64, 128), (1000, 1, 32),
                                    (513, 107, 214), (300, 214, 429), (2048, 128, 256)])
