@@ -140,16 +140,22 @@ sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict
                     int64_t n_rows, int shift, int bits, const uint32_t* __restrict__ block_off,
                     const uint32_t* __restrict__ tile_sums, int n_tiles, int n_blocks,
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-  extern __shared__ uint32_t wave_cnt[];  // [SORT_WAVES][bins]: running counters, then wave bases
+  // dynamic LDS: [bins] global start per digit | [bins] tile-local start per digit |
+  //              max([SORT_WAVES][bins] wave counters, [2][SORT_TILE] staged (key, value) pairs)
+  extern __shared__ uint32_t dyn[];
   __shared__ uint32_t tile_lds[FOLD ? SCAN_FOLD_MAX : 1];
   __shared__ uint32_t lds4[4];
   const int bins = 1 << bits;
+  uint32_t* gstart = dyn;
+  uint32_t* texcl = dyn + bins;
+  uint32_t* wave_cnt = dyn + 2 * bins;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < SORT_WAVES * bins; i += blockDim.x) wave_cnt[i] = 0;
 
   uint32_t* my_cnt = wave_cnt + wave * bins;
-  const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * SORT_WAVE_KEYS;
+  const int64_t tbase = (int64_t)blockIdx.x * SORT_TILE;
+  const int64_t wbase = tbase + (int64_t)wave * SORT_WAVE_KEYS;
   uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -176,16 +182,8 @@ sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict
       v[e] = t < n_tiles ? tile_sums[t] : 0u;
       sum += v[e];
     }
-    const int ln = threadIdx.x & 63;
-    uint32_t inc = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (ln >= off) inc += t;
-    }
-    if (ln == 63) lds4[wave] = inc;
-    __syncthreads();
-    uint32_t run = inc - sum;
-    for (int w = 0; w < wave; ++w) run += lds4[w];
+    const uint32_t run0 = block_exclusive_scan(sum, lds4, nullptr);
+    uint32_t run = run0;
 #pragma unroll
     for (int e = 0; e < SCAN_FOLD_MAX / RX_BLOCK; ++e) {
       tile_lds[threadIdx.x * (SCAN_FOLD_MAX / RX_BLOCK) + e] = run;
@@ -218,26 +216,70 @@ sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict
     }
   }
   __syncthreads();
-  // per digit: exclusive prefix over the block's waves, plus this block's global start
+  // per digit: exclusive prefix over the block's waves (tile-local), the tile's count, and the
+  // digit's global start for this tile
   for (int d = threadIdx.x; d < bins; d += blockDim.x) {
     const int64_t e = (int64_t)d * n_blocks + blockIdx.x;
-    uint32_t run = block_off[e] + (FOLD ? tile_lds[e / SCAN_TILE] : tile_sums[e / SCAN_TILE]);
+    gstart[d] = block_off[e] + (FOLD ? tile_lds[e / SCAN_TILE] : tile_sums[e / SCAN_TILE]);
+    uint32_t run = 0;
 #pragma unroll
     for (int w = 0; w < SORT_WAVES; ++w) {
       const uint32_t c = wave_cnt[w * bins + d];
       wave_cnt[w * bins + d] = run;
       run += c;
     }
+    texcl[d] = run;
   }
   __syncthreads();
+  {
+    // exclusive scan of the tile's digit counts (bins / 256 consecutive digits per thread)
+    const int per = (bins + RX_BLOCK - 1) / RX_BLOCK;
+    uint32_t v[SORT_MAX_BINS / RX_BLOCK], sum = 0;
+#pragma unroll
+    for (int e = 0; e < SORT_MAX_BINS / RX_BLOCK; ++e) {
+      const int d = threadIdx.x * per + e;
+      v[e] = (e < per && d < bins) ? texcl[d] : 0u;
+      sum += v[e];
+    }
+    uint32_t run = block_exclusive_scan(sum, lds4, nullptr);
+#pragma unroll
+    for (int e = 0; e < SORT_MAX_BINS / RX_BLOCK; ++e) {
+      const int d = threadIdx.x * per + e;
+      if (e < per && d < bins) texcl[d] = run;
+      run += v[e];
+    }
+  }
+  __syncthreads();
+  // position of every key inside the sorted tile
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
-    const int64_t i = wbase + it * 64 + lane;
-    if (i < n) {
-      const uint32_t d = (key[it] >> shift) & (bins - 1);
-      const uint32_t dst = my_cnt[d] + rank[it];
-      keys_out[dst] = key[it];
-      vals_out[dst] = val[it];
+    const uint32_t d = (key[it] >> shift) & (bins - 1);
+    rank[it] += texcl[d] + my_cnt[d];
+  }
+  __syncthreads();
+  // The wave counters are dead: their space stages the tile in sorted order, so that the
+  // write-out below sends neighbouring lanes to neighbouring addresses (runs of equal digits are
+  // contiguous in the output) instead of one 4-byte store per key and destination.
+  uint32_t* sk = wave_cnt;
+  uint32_t* sv = wave_cnt + SORT_TILE;
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    if (wbase + it * 64 + lane < n) {
+      sk[rank[it]] = key[it];
+      sv[rank[it]] = val[it];
+    }
+  }
+  __syncthreads();
+  const int tile_n = (int)((tbase + SORT_TILE <= n) ? SORT_TILE : n - tbase);
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const int j = it * RX_BLOCK + threadIdx.x;
+    if (j < tile_n) {
+      const uint32_t k = sk[j];
+      const uint32_t d = (k >> shift) & (bins - 1);
+      const uint32_t dst = gstart[d] + ((uint32_t)j - texcl[d]);
+      keys_out[dst] = k;
+      vals_out[dst] = sv[j];
     }
   }
 }
@@ -362,7 +404,9 @@ static int sort_pass(const SortWs& w, const int64_t* raw_idx, int64_t n_rows, in
   const int64_t entries = (int64_t)nb * bins;
   const int n_tiles = (int)rx_cdiv(entries, SCAN_TILE);
   const bool fold = allow_fold && n_tiles <= SCAN_FOLD_MAX;
-  const size_t hl = bins * sizeof(uint32_t), sl = SORT_WAVES * bins * sizeof(uint32_t);
+  const size_t hl = bins * sizeof(uint32_t);
+  const size_t stage = (size_t)(SORT_WAVES * bins > 2 * SORT_TILE ? SORT_WAVES * bins : 2 * SORT_TILE);
+  const size_t sl = (2 * (size_t)bins + stage) * sizeof(uint32_t);
   if (raw_idx) hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)raw_idx, n, n_rows, shift, bits, w.hist, nb, err_flag);
   else hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)kin, n, n_rows, shift, bits, w.hist, nb, err_flag);
   RX_LAUNCH_CHECK();
