@@ -326,6 +326,33 @@ int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, f
                     size_t ws_bytes, int device, void* stream);
 int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int device, void* stream);
 
+/* ---- BatchNorm1d of the reference's BN towers, fused with the ReLU and Dropout that follow it
+ * (widendeep.py:6-24 and deep_factorization_machine.py:6-24: Linear, BatchNorm1d, ReLU,
+ * Dropout per hidden layer).  x [M, C] row-major, statistics per column over the M rows.
+ *   rx_bn_stats   mean[C], rstd[C] = 1/sqrt(biased var + eps); when the running buffers are given:
+ *                 running = (1 - momentum) running + momentum (mean | unbiased var), as
+ *                 torch.nn.BatchNorm1d does in training mode
+ *   rx_bn_apply   out = keep * keep_scale * act(gamma (x - mean) rstd + beta); relu: act = ReLU;
+ *                 d_keep (uint8 [M, C], may be NULL) is the dropout keep mask, keep_scale = 1/(1-p).
+ *                 Evaluation mode passes the running mean and 1/sqrt(running var + eps).
+ *   rx_bn_bwd     dz = gate ? dout * keep_scale * (out != 0) : dout;  dbeta = sum dz;
+ *                 dgamma = sum dz xhat;  dx = gamma rstd (dz - dbeta/M - xhat dgamma/M) with batch
+ *                 statistics, gamma rstd dz with fixed ones.  gate = relu or dropout was applied.
+ * Sums are fp64 in a fixed order (slabs of rows, then slab order).  ws: rx_bn_workspace_bytes. */
+size_t rx_bn_workspace_bytes(int64_t M, int32_t C);
+int rx_bn_stats(const float* d_x, int64_t ldx, int64_t M, int32_t C, float eps, float momentum,
+                float* d_mean, float* d_rstd, float* d_running_mean, float* d_running_var, void* ws,
+                size_t ws_bytes, int device, void* stream);
+int rx_bn_apply(const float* d_x, int64_t ldx, int64_t M, int32_t C, const float* d_mean,
+                const float* d_rstd, const float* d_gamma, const float* d_beta, int relu,
+                const uint8_t* d_keep, float keep_scale, float* d_out, int64_t ldo, int device,
+                void* stream);
+int rx_bn_bwd(const float* d_dout, int64_t ldd, const float* d_x, int64_t ldx, const float* d_out,
+              int64_t ldo, int64_t M, int32_t C, const float* d_mean, const float* d_rstd,
+              const float* d_gamma, int gate, float keep_scale, int batch_stats, float* d_dx,
+              int64_t lddx, float* d_dgamma, float* d_dbeta, void* ws, size_t ws_bytes, int device,
+              void* stream);
+
 /* ------------------------------------------------------------------ DCN-v2 cross layer
  * No counterpart in the reference.  x_{l+1} = x0 * (x_l W^T + b) + x_l, W [d,d].
  * fwd: U = rx_linear_fwd(x_l, W, b) then xn = x0 * U + x_l; bwd elementwise part, given dXn:

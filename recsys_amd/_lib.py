@@ -69,6 +69,11 @@ PROTOTYPES = {
     "rx_sumsq_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_sum_accumulate": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_clip_scale": (C.c_int, [vp, f32, vp, vp, C.c_int, vp]),
+    "rx_bn_workspace_bytes": (C.c_size_t, [i64, i32]),
+    "rx_bn_stats": (C.c_int, [vp, i64, i64, i32, f32, f32, vp, vp, vp, vp, vp, C.c_size_t, C.c_int, vp]),
+    "rx_bn_apply": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, f32, vp, i64, C.c_int, vp]),
+    "rx_bn_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, C.c_int, f32, C.c_int, vp, i64, vp, vp,
+                            vp, C.c_size_t, C.c_int, vp]),
     "rx_clip_scale_parts": (C.c_int, [vp, i64, vp, f32, vp, vp, C.c_int, vp]),
     "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

@@ -291,6 +291,54 @@ class CrossLayer(Function):
 
 
 # ------------------------------------------------------------------ loss
+class BatchNormAct(Function):
+    """BatchNorm1d (+ ReLU) (+ Dropout) of the reference's BN towers in three launches forward
+    (statistics, their join, apply) and three backward.  Training mode normalises with the batch
+    statistics and updates the running buffers like torch.nn.BatchNorm1d; evaluation mode uses
+    the running buffers.  The dropout keep mask is drawn by torch (its generator, graph-safe)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, p):
+        batch_stats = training or running_mean is None
+        if batch_stats:
+            if x.shape[0] < 2 and training:
+                raise ValueError("Expected more than 1 value per channel when training")
+            mean, rstd = ops.bn_stats(x, eps, momentum if training else 0.0,
+                                      running_mean if training else None, running_var if training else None)
+        else:
+            mean, rstd = running_mean, torch.rsqrt(running_var + eps)
+        keep, keep_scale = None, 1.0
+        if training and p > 0.0:
+            keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - p)
+            keep_scale = 1.0 / (1.0 - p)
+        out = ops.bn_apply(x, mean, rstd, gamma, beta, relu, keep, keep_scale)
+        ctx.gate = bool(relu or keep is not None)
+        ctx.keep_scale, ctx.batch_stats = keep_scale, batch_stats
+        ctx.save_for_backward(x, out if ctx.gate else None, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, mean, rstd, gamma = ctx.saved_tensors
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        dx, dgamma, dbeta = ops.bn_bwd(dout, x, out, mean, rstd, gamma, ctx.gate, ctx.keep_scale, ctx.batch_stats)
+        return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None, None, None, None, None, None
+
+
+def batch_norm_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool, p: float) -> Tensor:
+    """``Dropout(p)(ReLU(bn(x)))`` (either may be absent) with torch.nn.BatchNorm1d's state handling."""
+    training = bn.training
+    momentum = 0.0
+    if training and bn.track_running_stats:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return BatchNormAct.apply(x, bn.weight, bn.bias, rm, rv, training, momentum, bn.eps, relu, p if training else 0.0)
+
+
 _UNIT_LOSS_GRAD = False
 _ONES = {}
 

@@ -1,0 +1,312 @@
+// BatchNorm1d over the batch dimension of the tower activations, fused with the ReLU and the
+// dropout mask that follow it in the reference's towers (gfx950).
+//
+// x is [M, C] row-major (C = features), statistics are per column.  Every pass is a streaming read
+// of whole rows: a block covers 64 columns with 16 row lanes of 16-byte loads and leaves fixed-order
+// fp64 partials per slab of rows; a second, tiny kernel joins the slabs in slab order.  No atomics.
+#include "rx_common.h"
+
+#define BN_SLABS 64
+#define BN_COLS 64
+
+__device__ __forceinline__ float4 bn_ld4(const float* p, bool vec, int valid) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) r.x = p[0];
+  if (valid > 1) r.y = p[1];
+  if (valid > 2) r.z = p[2];
+  if (valid > 3) r.w = p[3];
+  return r;
+}
+
+// partial[z][c][0..1] = (sum x, sum x^2) over the slab's rows
+template <bool VEC>
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, int64_t rows_per_slab,
+                double* __restrict__ partial) {
+  __shared__ double red[16][BN_COLS + 1][2];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int j0 = blockIdx.x * BN_COLS + cq * 4;
+  const int valid = C - j0;
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (valid > 0) {
+    int64_t r = lo + rl;
+    for (; r + 48 < hi; r += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = bn_ld4(x + (r + 16 * u) * ldx + j0, VEC, valid);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const double d = (double)e[i]; s[i] += d; q[i] += d * d; }
+      }
+    }
+    for (; r < hi; r += 16) {
+      const float4 v = bn_ld4(x + r * ldx + j0, VEC, valid);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const double d = (double)e[i]; s[i] += d; q[i] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[rl][cq * 4 + i][0] = s[i]; red[rl][cq * 4 + i][1] = q[i]; }
+  __syncthreads();
+  if (threadIdx.x < BN_COLS) {
+    const int j = blockIdx.x * BN_COLS + threadIdx.x;
+    double a = 0, b = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { a += red[t][threadIdx.x][0]; b += red[t][threadIdx.x][1]; }
+    if (j < C) {
+      partial[((int64_t)blockIdx.z * C + j) * 2] = a;
+      partial[((int64_t)blockIdx.z * C + j) * 2 + 1] = b;
+    }
+  }
+}
+
+// mean, 1/sqrt(var + eps) with the biased variance; running estimates with the unbiased one
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_stats_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M, int C, float eps, float momentum,
+                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                      float* __restrict__ running_var) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  double a = 0, b = 0;
+  for (int z = 0; z < n_slabs; ++z) { a += partial[((int64_t)z * C + j) * 2]; b += partial[((int64_t)z * C + j) * 2 + 1]; }
+  const double mu = a / (double)M;
+  double var = b / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[j] = (float)mu;
+  rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[j] = (1.f - momentum) * running_mean[j] + momentum * (float)mu;
+  if (running_var) {
+    const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+    running_var[j] = (1.f - momentum) * running_var[j] + momentum * (float)unbiased;
+  }
+}
+
+// out = keep * keep_scale * act(gamma * (x - mean) * rstd + beta)
+template <bool VEC>
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, const float* __restrict__ mean,
+                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                int relu, const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ out, int64_t ldo) {
+  const int quads = (C + 3) / 4;
+  const int64_t total = M * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / quads;
+    const int j0 = (int)(i - r * quads) * 4;
+    const int valid = C - j0;
+    const float4 v = bn_ld4(x + r * ldx + j0, VEC, valid);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + (t < valid ? t : 0);
+      const float g = gamma ? gamma[j] : 1.f, b = beta ? beta[j] : 0.f;
+      float y = (e[t] - mean[j]) * rstd[j] * g + b;
+      if (relu) y = y > 0.f ? y : 0.f;
+      if (keep) y = keep[r * (int64_t)C + j] ? y * keep_scale : 0.f;
+      o[t] = y;
+    }
+    float* dst = out + r * ldo + j0;
+    if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+  }
+}
+
+// dz = gate ? dout * keep_scale * (out != 0) : dout ;  partial sums of (dz, dz * xhat)
+template <bool VEC>
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_bwd_sums_kernel(const float* __restrict__ dout, int64_t ldd, const float* __restrict__ x, int64_t ldx,
+                   const float* __restrict__ out, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, int gate, float keep_scale, int64_t rows_per_slab,
+                   double* __restrict__ partial) {
+  __shared__ double red[16][BN_COLS + 1][2];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int j0 = blockIdx.x * BN_COLS + cq * 4;
+  const int valid = C - j0;
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (valid > 0) {
+    float mu[4], rs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int j = j0 + (t < valid ? t : 0); mu[t] = mean[j]; rs[t] = rstd[j]; }
+    for (int64_t r = lo + rl; r < hi; r += 32) {
+      float4 vd[2], vx[2], vo[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t rr = (r + 16 * u < hi) ? r + 16 * u : r;
+        vd[u] = bn_ld4(dout + rr * ldd + j0, VEC, valid);
+        vx[u] = bn_ld4(x + rr * ldx + j0, VEC, valid);
+        vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (r + 16 * u >= hi) continue;
+        const float d[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+        const float xe[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+        const float oe[4] = {vo[u].x, vo[u].y, vo[u].z, vo[u].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float dz = gate ? (oe[t] != 0.f ? d[t] * keep_scale : 0.f) : d[t];
+          const float xh = (xe[t] - mu[t]) * rs[t];
+          s[t] += (double)dz;
+          q[t] += (double)dz * (double)xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[rl][cq * 4 + i][0] = s[i]; red[rl][cq * 4 + i][1] = q[i]; }
+  __syncthreads();
+  if (threadIdx.x < BN_COLS) {
+    const int j = blockIdx.x * BN_COLS + threadIdx.x;
+    double a = 0, b = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { a += red[t][threadIdx.x][0]; b += red[t][threadIdx.x][1]; }
+    if (j < C) {
+      partial[((int64_t)blockIdx.z * C + j) * 2] = a;
+      partial[((int64_t)blockIdx.z * C + j) * 2 + 1] = b;
+    }
+  }
+}
+
+// dbeta = sum dz, dgamma = sum dz xhat; coef[c] = (dbeta / M, dgamma / M) for the second pass
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_bwd_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M, int C, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  double a = 0, b = 0;
+  for (int z = 0; z < n_slabs; ++z) { a += partial[((int64_t)z * C + j) * 2]; b += partial[((int64_t)z * C + j) * 2 + 1]; }
+  if (dbeta) dbeta[j] = (float)a;
+  if (dgamma) dgamma[j] = (float)b;
+  coef[2 * j] = (float)(a / (double)M);
+  coef[2 * j + 1] = (float)(b / (double)M);
+}
+
+// batch statistics: dx = gamma rstd (dz - mean(dz) - xhat mean(dz xhat)); fixed statistics: gamma rstd dz
+template <bool VEC>
+__global__ void __launch_bounds__(RX_BLOCK)
+bn_bwd_dx_kernel(const float* __restrict__ dout, int64_t ldd, const float* __restrict__ x, int64_t ldx,
+                 const float* __restrict__ out, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ coef,
+                 int gate, float keep_scale, int batch_stats, float* __restrict__ dx, int64_t lddx) {
+  const int quads = (C + 3) / 4;
+  const int64_t total = M * quads;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / quads;
+    const int j0 = (int)(i - r * quads) * 4;
+    const int valid = C - j0;
+    const float4 vd = bn_ld4(dout + r * ldd + j0, VEC, valid);
+    const float4 vx = bn_ld4(x + r * ldx + j0, VEC, valid);
+    const float4 vo = gate ? bn_ld4(out + r * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float d[4] = {vd.x, vd.y, vd.z, vd.w};
+    const float xe[4] = {vx.x, vx.y, vx.z, vx.w};
+    const float oe[4] = {vo.x, vo.y, vo.z, vo.w};
+    float o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = j0 + (t < valid ? t : 0);
+      const float dz = gate ? (oe[t] != 0.f ? d[t] * keep_scale : 0.f) : d[t];
+      const float g = (gamma ? gamma[j] : 1.f) * rstd[j];
+      if (batch_stats) {
+        const float xh = (xe[t] - mean[j]) * rstd[j];
+        o[t] = g * (dz - coef[2 * j] - xh * coef[2 * j + 1]);
+      } else {
+        o[t] = g * dz;
+      }
+    }
+    float* dst = dx + r * lddx + j0;
+    if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    else
+      for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+  }
+}
+
+static inline bool bn_vec(const void* p, int64_t ld, int C) { return (ld % 4 == 0) && (C % 4 == 0) && rx_aligned16(p); }
+
+static int bn_slabs(int64_t M, int64_t* rows_per_slab) {
+  int64_t rows = rx_cdiv(M, BN_SLABS);
+  rows = rx_cdiv(rows, 32) * 32;
+  *rows_per_slab = rows;
+  return (int)rx_cdiv(M, rows);
+}
+
+extern "C" size_t rx_bn_workspace_bytes(int64_t M, int32_t C) {
+  (void)M;
+  if (C < 1) return 256;
+  return rx_align_up((size_t)BN_SLABS * C * 2 * sizeof(double), 256) + rx_align_up((size_t)C * 2 * sizeof(float), 256);
+}
+
+extern "C" int rx_bn_stats(const float* d_x, int64_t ldx, int64_t M, int32_t C, float eps, float momentum,
+                           float* d_mean, float* d_rstd, float* d_running_mean, float* d_running_var, void* ws,
+                           size_t ws_bytes, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 1 && C >= 1 && ldx >= C, "rx_bn_stats: bad shape M=%lld C=%d", (long long)M, C);
+  RX_REQUIRE(d_x && d_mean && d_rstd && ws && ws_bytes >= rx_bn_workspace_bytes(M, C), "rx_bn_stats: null argument or small workspace");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rows;
+  const int slabs = bn_slabs(M, &rows);
+  const dim3 grid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)slabs);
+  if (bn_vec(d_x, ldx, C)) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, rows, (double*)ws);
+  else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, rows, (double*)ws);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)rx_cdiv(C, RX_BLOCK)), dim3(RX_BLOCK), 0, st, (const double*)ws, slabs, M, C, eps, momentum, d_mean, d_rstd, d_running_mean, d_running_var);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+static unsigned bn_ew_grid(int64_t M, int C) {
+  int64_t g = rx_cdiv(M * ((C + 3) / 4), RX_BLOCK);
+  return (unsigned)(g < 16384 ? (g < 1 ? 1 : g) : 16384);
+}
+
+extern "C" int rx_bn_apply(const float* d_x, int64_t ldx, int64_t M, int32_t C, const float* d_mean,
+                           const float* d_rstd, const float* d_gamma, const float* d_beta, int relu,
+                           const uint8_t* d_keep, float keep_scale, float* d_out, int64_t ldo, int device,
+                           void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && C >= 1 && ldx >= C && ldo >= C, "rx_bn_apply: bad shape");
+  if (M == 0) return 0;
+  RX_REQUIRE(d_x && d_mean && d_rstd && d_out, "rx_bn_apply: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (bn_vec(d_x, ldx, C) && bn_vec(d_out, ldo, C))
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_bn_bwd(const float* d_dout, int64_t ldd, const float* d_x, int64_t ldx, const float* d_out,
+                         int64_t ldo, int64_t M, int32_t C, const float* d_mean, const float* d_rstd,
+                         const float* d_gamma, int gate, float keep_scale, int batch_stats, float* d_dx,
+                         int64_t lddx, float* d_dgamma, float* d_dbeta, void* ws, size_t ws_bytes, int device,
+                         void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 1 && C >= 1 && ldd >= C && ldx >= C && lddx >= C && (!gate || ldo >= C), "rx_bn_bwd: bad shape");
+  RX_REQUIRE(d_dout && d_x && d_mean && d_rstd && d_dx && ws && (!gate || d_out), "rx_bn_bwd: null argument");
+  RX_REQUIRE(ws_bytes >= rx_bn_workspace_bytes(M, C), "rx_bn_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rows;
+  const int slabs = bn_slabs(M, &rows);
+  double* partial = (double*)ws;
+  float* coef = (float*)((char*)ws + rx_align_up((size_t)BN_SLABS * C * 2 * sizeof(double), 256));
+  const bool vec = bn_vec(d_dout, ldd, C) && bn_vec(d_x, ldx, C) && bn_vec(d_dx, lddx, C) && (!gate || bn_vec(d_out, ldo, C));
+  const dim3 grid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)slabs);
+  if (vec) hipLaunchKernelGGL(bn_bwd_sums_kernel<true>, grid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, gate, keep_scale, rows, partial);
+  else hipLaunchKernelGGL(bn_bwd_sums_kernel<false>, grid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, gate, keep_scale, rows, partial);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)rx_cdiv(C, RX_BLOCK)), dim3(RX_BLOCK), 0, st, (const double*)partial, slabs, M, C, d_dgamma, d_dbeta, coef);
+  RX_LAUNCH_CHECK();
+  if (vec) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx);
+  else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

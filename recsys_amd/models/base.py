@@ -48,8 +48,8 @@ def as_index(t: Tensor, name: str) -> Tensor:
 
 def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False) -> Tensor:
     """Evaluate a Linear/(BatchNorm1d)/ReLU/Dropout stack.  Linear (+ a directly following ReLU)
-    goes through the MFMA GEMM with the ReLU fused into its epilogue; BatchNorm1d and Dropout
-    keep torch's own modules (their batch statistics / RNG semantics are torch's)."""
+    goes through the MFMA GEMM with the ReLU fused into its epilogue; BatchNorm1d with the ReLU and
+    Dropout behind it is one fused normalisation (rx_bn_*); anything else runs as the torch module."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -58,6 +58,16 @@ def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False) -> Tensor:
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16)
             i += 2 if fuse else 1
+        elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2 and m.affine:
+            j = i + 1
+            relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+            j += 1 if relu else 0
+            p = 0.0
+            if j < len(mods) and isinstance(mods[j], nn.Dropout):
+                p = float(mods[j].p)
+                j += 1
+            x = rxa.batch_norm_act(x, m, relu, p)
+            i = j
         else:
             x = m(x)
             i += 1

@@ -617,6 +617,51 @@ def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
     return dz
 
 
+# ------------------------------------------------------------------ BatchNorm1d (+ ReLU + dropout)
+def bn_stats(x: Tensor, eps: float, momentum: float = 0.0, running_mean: Optional[Tensor] = None,
+             running_var: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Per-column mean and 1/sqrt(biased var + eps) of x [M, C]; updates the running buffers in place."""
+    x, ldx = _mat(x, "x")
+    M, C = x.shape
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _ws(int(lib.rx_bn_workspace_bytes(M, C)), x.device)
+    check(lib.rx_bn_stats(_p(x), ldx, M, C, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var),
+                          _p(ws), ws.numel(), _dev(x), _stream(x)), "rx_bn_stats")
+    return mean, rstd
+
+
+def bn_apply(x: Tensor, mean: Tensor, rstd: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], relu: bool,
+             keep: Optional[Tensor] = None, keep_scale: float = 1.0) -> Tensor:
+    x, ldx = _mat(x, "x")
+    M, C = x.shape
+    if keep is not None and not (keep.dtype == torch.uint8 and keep.is_contiguous() and tuple(keep.shape) == (M, C)):
+        raise ValueError("keep: expected a contiguous uint8 [M, C] mask")
+    out = _padded(M, C, x.device)
+    check(lib.rx_bn_apply(_p(x), ldx, M, C, _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(keep), keep_scale,
+                          _p(out), out.stride(0) if M > 1 else max(C, out.stride(0)), _dev(x), _stream(x)), "rx_bn_apply")
+    return out
+
+
+def bn_bwd(dout: Tensor, x: Tensor, out: Optional[Tensor], mean: Tensor, rstd: Tensor, gamma: Optional[Tensor],
+           gate: bool, keep_scale: float, batch_stats: bool):
+    """Returns (dx, dgamma, dbeta)."""
+    dout, ldd = _mat(dout, "dout")
+    x, ldx = _mat(x, "x")
+    M, C = x.shape
+    ldo = 0
+    if gate:
+        out, ldo = _mat(out, "out")
+    dx = _padded(M, C, x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _ws(int(lib.rx_bn_workspace_bytes(M, C)), x.device)
+    check(lib.rx_bn_bwd(_p(dout), ldd, _p(x), ldx, _p(out) if gate else None, ldo, M, C, _p(mean), _p(rstd), _p(gamma),
+                        int(gate), keep_scale, int(batch_stats), _p(dx), dx.stride(0) if M > 1 else max(C, dx.stride(0)),
+                        _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _dev(x), _stream(x)), "rx_bn_bwd")
+    return dx, dgamma, dbeta
+
+
 def _padded(rows: int, cols: int, device) -> Tensor:
     """fp32 [rows, cols] whose row stride is a multiple of 4 floats."""
     cp = (cols + 3) // 4 * 4

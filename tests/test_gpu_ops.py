@@ -229,6 +229,63 @@ def test_two_phase_clip_update_with_companion(ops, mode):
     assert torch.equal(w.cpu()[~touched], w0[~touched]) and torch.equal(b.cpu()[~touched], b0[~touched])
 
 
+# ------------------------------------------------------------------ BatchNorm1d + ReLU + dropout
+@pytest.mark.parametrize("M,C", [(300, 70), (1024, 64), (4096, 216), (2, 5)])
+@pytest.mark.parametrize("relu,drop", [(False, False), (True, False), (True, True)])
+def test_batch_norm_act_matches_torch(ops, M, C, relu, drop):
+    g = _gen(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    keep = (torch.rand(M, C, generator=g) < 0.9).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    dout = torch.randn(M, C, generator=g)
+    eps, mom = 1e-5, 0.1
+    # torch reference in fp64
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y = torch.nn.functional.batch_norm(xr, rm_ref, rv_ref, gr, br, training=True, momentum=mom, eps=eps)
+    if relu:
+        y = y.relu()
+    if drop:
+        y = y * keep.double() * scale
+    y.backward(dout.double())
+    # device
+    xd = x.cuda()
+    rmd, rvd = rm.clone().cuda(), rv.clone().cuda()
+    mean, rstd = ops.bn_stats(xd, eps, mom, rmd, rvd)
+    out = ops.bn_apply(xd, mean, rstd, gamma.cuda(), beta.cuda(), relu, keep.cuda() if drop else None, scale)
+    assert_close(out.cpu().numpy(), y.detach().numpy(), what="bn out")
+    assert_close(rmd.cpu().numpy(), rm_ref.numpy(), what="running mean")
+    assert_close(rvd.cpu().numpy(), rv_ref.numpy(), what="running var")
+    dx, dgamma, dbeta = ops.bn_bwd(dout.cuda(), xd, out, mean, rstd, gamma.cuda(), relu or drop, scale, True)
+    # dx is a difference of O(1) terms; with two rows it cancels to ~1e-4, so allow fp32 rounding of the terms
+    assert_close(dx.cpu().numpy(), xr.grad.numpy(), what="bn dx", atol=5e-6)
+    assert_close(dgamma.cpu().numpy(), gr.grad.numpy(), what="bn dgamma")
+    assert_close(dbeta.cpu().numpy(), br.grad.numpy(), what="bn dbeta")
+
+
+def test_batch_norm_act_module_eval_and_train(ops):
+    """The tower helper against torch modules: training statistics / buffers, then evaluation mode."""
+    from recsys_amd import autograd as rxa
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(48).cuda()
+    ref = torch.nn.BatchNorm1d(48).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    ref.load_state_dict(bn.state_dict())
+    x = torch.randn(512, 48, device="cuda")
+    for _ in range(2):
+        a = rxa.batch_norm_act(x, bn, True, 0.0)
+        b = ref(x).relu()
+        assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), what="train fwd")
+    assert int(bn.num_batches_tracked) == 2
+    assert_close(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), what="running var")
+    bn.eval(); ref.eval()
+    assert_close(rxa.batch_norm_act(x, bn, False, 0.3).detach().cpu().numpy(), ref(x).detach().cpu().numpy(), what="eval fwd")
+
+
 # ------------------------------------------------------------------ dense layers
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 3, 5), (130, 32, 64), (257, 64, 128), (1000, 1, 32),
                                    (513, 107, 214), (300, 214, 429), (2048, 128, 256)])
