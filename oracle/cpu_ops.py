@@ -95,7 +95,23 @@ def segreduce(occ, si, mode, target, *, state=None, lr=0.0, eps=0.0, scale=None,
     else:
         state[rows] += ((sc * G) ** 2).mean(1)
         t[rows] -= lr * sc * G / (state[rows].sqrt()[:, None] + eps)
-    return (G ** 2).sum().reshape(1) if want_sq else None
+    sq = (G ** 2).sum()
+    if target2 is not None:
+        # companion scalar table addressed by the same rows
+        G2 = torch.zeros(nu).index_add_(0, si.sorted_slot.long(), occ2.reshape(-1)[si.sorted_pos.long()])
+        t2 = target2.reshape(-1)
+        if mode == _lib.RX_SEG_DENSE:
+            t2[rows] = G2
+        elif mode == _lib.RX_SEG_COMPACT:
+            t2[:nu] = G2
+        elif mode == _lib.RX_SEG_SGD:
+            t2[rows] -= lr * sc * G2
+        else:
+            s2 = state2.reshape(-1)
+            s2[rows] += (sc * G2) ** 2
+            t2[rows] -= lr * sc * G2 / (s2[rows].sqrt() + eps)
+        sq = sq + (G2 ** 2).sum()
+    return sq.reshape(1) if want_sq else None
 
 
 def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base, want_deep=False, second_order=True, deep_cols=None,

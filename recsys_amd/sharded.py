@@ -96,22 +96,36 @@ class ShardedTable:
         back = self._from_owners(mine, plan)
         return self.ops.unpermute_rows(back, plan["perm"])
 
-    def scatter_grad(self, occ: torch.Tensor, plan):
-        """Send per-occurrence gradient rows (list order) to the owners and reduce / update there."""
+    def scatter_grad(self, occ: torch.Tensor, plan, companion: Optional["ShardedTable"] = None,
+                     occ2: Optional[torch.Tensor] = None):
+        """Send per-occurrence gradient rows (list order) to the owners and reduce / update there.
+        ``companion`` / ``occ2`` [n]: a second table addressed by the same rows (the [rows, 1] bias
+        table) and its per-occurrence gradients; they share this list's plan, sort and reduce."""
         sent = self.ops.permute_rows(occ.contiguous(), plan["perm"])
         got = self._to_owners(sent, plan)
+        got2 = None
+        if companion is not None:
+            sent2 = self.ops.permute_rows(occ2.reshape(-1, 1).contiguous(), plan["perm"])
+            got2 = self._to_owners(sent2, plan).reshape(-1)
         if got.shape[0] == 0:
             return
         si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
         if self.rule is None:
-            if self.grad is None:
-                self.grad = torch.zeros_like(self.weight)
             g = torch.zeros_like(self.weight)
-            self.ops.segreduce(got, si, _lib.RX_SEG_DENSE, g, dim=self.dim)
-            self.grad += g
+            g2 = torch.zeros_like(companion.weight) if companion is not None else None
+            self.ops.segreduce(got, si, _lib.RX_SEG_DENSE, g, dim=self.dim, occ2=got2, target2=g2)
+            self.grad = g if self.grad is None else self.grad + g
+            if companion is not None:
+                companion.grad = g2 if companion.grad is None else companion.grad + g2
         else:
             mode, lr, eps, state = self.rule
-            self.ops.segreduce(got, si, mode, self.weight, state=state, lr=lr, eps=eps, dim=self.dim)
+            w2 = st2 = None
+            if companion is not None:
+                if companion.rule is None or companion.rule[0] != mode:
+                    raise RuntimeError("a companion table must carry the same update rule as its main table")
+                w2, st2 = companion.weight, companion.rule[3]
+            self.ops.segreduce(got, si, mode, self.weight, state=state, lr=lr, eps=eps, dim=self.dim,
+                               occ2=got2, target2=w2, state2=st2)
 
 
 class _ShardedLookup(torch.autograd.Function):
@@ -131,6 +145,27 @@ def sharded_lookup(table: ShardedTable, idx: torch.Tensor, anchor: torch.Tensor)
     """Differentiable lookup.  ``anchor`` is any tensor that requires grad (keeps the node in the
     autograd graph; the table itself is updated by its owner inside backward)."""
     return _ShardedLookup.apply(anchor, table, idx.reshape(-1).contiguous())
+
+
+class _ShardedLookupPair(torch.autograd.Function):
+    """Rows of a table and of its companion for one index list: one plan, one sort, one reduce."""
+
+    @staticmethod
+    def forward(ctx, anchor, table, companion, idx):
+        plan = table.plan(idx)
+        ctx.table, ctx.companion, ctx.plan = table, companion, plan
+        return table.gather(plan), companion.gather(plan)
+
+    @staticmethod
+    def backward(ctx, g, g2):
+        ctx.table.scatter_grad(g, ctx.plan, ctx.companion, g2)
+        return None, None, None, None
+
+
+def sharded_lookup_pair(table: ShardedTable, companion: ShardedTable, idx: torch.Tensor, anchor: torch.Tensor):
+    if companion.n_rows != table.n_rows or companion.G != table.G:
+        raise ValueError("companion table must be sharded like its main table")
+    return _ShardedLookupPair.apply(anchor, table, companion, idx.reshape(-1).contiguous())
 
 
 class ShardedFieldFM(torch.nn.Module):
@@ -174,8 +209,7 @@ class ShardedFieldFM(torch.nn.Module):
         glob = sparse + self._offsets[None, :]
         # occurrence order of the FM kernels: all (b, f < F) first, then the last field's B entries
         flat = torch.cat([glob[:, :F].reshape(-1), glob[:, F]]).contiguous()
-        rows = sharded_lookup(self.feature, flat, self._anchor)          # [B*(F+1), D]
-        bias = sharded_lookup(self.bias, flat, self._anchor)             # [B*(F+1), 1]
+        rows, bias = sharded_lookup_pair(self.feature, self.bias, flat, self._anchor)   # [B*(F+1), D], [B*(F+1), 1]
         ex, base, item = self._positions(B, sparse.device)
         return _LocalFM.apply(rows, bias, ex, base, item, self.ops)
 
