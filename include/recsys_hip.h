@@ -296,9 +296,31 @@ int rx_sum_accumulate(const float* d_x, int64_t n, double* d_acc, void* ws, size
 int rx_clip_scale(const double* d_acc, float max_norm, float* d_scale, float* d_total_norm,
                   int device, void* stream);
 /* The same factor from per-block partial sums of squares (the d_sq_part of rx_segreduce /
- * rx_segreduce_fm) in one launch: total = (d_acc ? *d_acc : 0) + sum(d_parts[0..n_parts)). */
-int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_acc, float max_norm,
-                        float* d_scale, float* d_total_norm, int device, void* stream);
+ * rx_segreduce_fm) in one launch: total = (d_acc ? *d_acc : 0) + sum(d_parts[0..n_parts)) +
+ * sum(d_parts64[0..n_parts64)), the latter fp64 partials as rx_multi_sumsq writes them. */
+int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_parts64,
+                        int64_t n_parts64, const double* d_acc, float max_norm, float* d_scale,
+                        float* d_total_norm, int device, void* stream);
+
+/* Up to RX_MULTI_MAX small dense tensors (the towers' weights and biases) in one launch each:
+ *   rx_multi_sumsq         d_partial[k * 32 + b] (fp64) = partial sums of squares of g[k]; the
+ *                          buffer holds rx_multi_sumsq_partials(count) doubles and is consumed as
+ *                          d_parts64 by rx_clip_scale_parts (clip_grad_norm_ over all parameters,
+ *                          recsys/utils.py:101)
+ *   rx_multi_dense_update  SGD (RX_SEG_SGD) or Adagrad (RX_SEG_ADAGRAD, state[k]) step of w[k] with
+ *                          gradient g[k] * scale, as rx_dense_sgd / rx_dense_adagrad do per tensor */
+#define RX_MULTI_MAX 24
+typedef struct rx_tensor_list {
+  float* w[RX_MULTI_MAX];
+  const float* g[RX_MULTI_MAX];
+  float* state[RX_MULTI_MAX];
+  int64_t n[RX_MULTI_MAX];
+  int32_t count;
+} rx_tensor_list;
+size_t rx_multi_sumsq_partials(int32_t count);
+int rx_multi_sumsq(const rx_tensor_list* list, double* d_partial, int device, void* stream);
+int rx_multi_dense_update(const rx_tensor_list* list, int mode, float lr, float eps,
+                          const float* d_scale, int device, void* stream);
 /* out[0] = sum(x) (fp64 accumulate, fixed order): gradient of a scalar bias that is added to
  * every logit (bias_mf.py:12,17; the Linear(D,1) bias of gmf.py:20). Same workspace size. */
 int rx_reduce_sum(const float* d_x, int64_t n, float* d_out, void* ws, size_t ws_bytes, int device,

@@ -37,6 +37,13 @@ class FMArgs(C.Structure):
 
 
 RX_FM_NO_SECOND_ORDER = 1
+RX_MULTI_MAX = 24
+
+
+class TensorList(C.Structure):
+    _fields_ = [("w", vp * RX_MULTI_MAX), ("g", vp * RX_MULTI_MAX), ("state", vp * RX_MULTI_MAX),
+                ("n", i64 * RX_MULTI_MAX), ("count", i32)]
+
 
 # name -> (restype, argtypes); must list every symbol of include/recsys_hip.h
 PROTOTYPES = {
@@ -74,7 +81,10 @@ PROTOTYPES = {
     "rx_bn_apply": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, f32, vp, i64, C.c_int, vp]),
     "rx_bn_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, C.c_int, f32, C.c_int, vp, i64, vp, vp,
                             vp, C.c_size_t, C.c_int, vp]),
-    "rx_clip_scale_parts": (C.c_int, [vp, i64, vp, f32, vp, vp, C.c_int, vp]),
+    "rx_clip_scale_parts": (C.c_int, [vp, i64, vp, i64, vp, f32, vp, vp, C.c_int, vp]),
+    "rx_multi_sumsq_partials": (C.c_size_t, [i32]),
+    "rx_multi_sumsq": (C.c_int, [C.POINTER(TensorList), vp, C.c_int, vp]),
+    "rx_multi_dense_update": (C.c_int, [C.POINTER(TensorList), C.c_int, f32, f32, vp, C.c_int, vp]),
     "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_linear_bwd_x": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

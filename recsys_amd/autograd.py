@@ -22,6 +22,27 @@ from .ops import Segment, SortedIndex
 Tensor = torch.Tensor
 
 
+_SORT_CACHE: list = []
+
+
+def sorted_index(idx: Tensor, n_rows: int):
+    """``ops.sort_dedup`` with a small memo: NeuMF-style models look the same index tensor up in
+    several tables of equal height (GMF and MLP embeddings), and one sort serves them all.  An
+    entry is keyed by storage address, length and version counter and keeps its index tensor
+    alive, so a hit can only be the same, unmodified data."""
+    flat = idx.reshape(-1)
+    key = (flat.data_ptr(), flat.numel(), flat._version, int(n_rows), flat.device)
+    for k, _, si in _SORT_CACHE:
+        if k == key:
+            return si
+    si = ops.sort_dedup(flat.contiguous() if not flat.is_contiguous() else flat, n_rows)
+    if flat.is_contiguous():
+        _SORT_CACHE.append((key, flat, si))
+        if len(_SORT_CACHE) > 8:
+            _SORT_CACHE.pop(0)
+    return si
+
+
 def table_backward(param: Optional[Tensor], si: SortedIndex, occ: Tensor, dim: Optional[int] = None,
                    occ_ld: Optional[int] = None, param2: Optional[Tensor] = None,
                    occ2: Optional[Tensor] = None):
@@ -60,16 +81,16 @@ class MFScore(Function):
         kw = ctx.kw
         g = g.contiguous()
         user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, **kw)
-        su = ops.sort_dedup(users, U.shape[0])
-        si = ops.sort_dedup(items, V.shape[0])
+        su = sorted_index(users, U.shape[0])
+        si = sorted_index(items, V.shape[0])
         gU = table_backward(U, su, user_occ)
         gV = table_backward(V, si, item_occ)
         gO = gUT = gT = gub = gib = gb = glw = glb = None
         if kw["O"] is not None:
-            gO = table_backward(kw["O"], ops.sort_dedup(kw["occs"], kw["O"].shape[0]), user_occ)
+            gO = table_backward(kw["O"], sorted_index(kw["occs"], kw["O"].shape[0]), user_occ)
         if kw["UT"] is not None:
             gUT = table_backward(kw["UT"], su, utemp_occ)
-            gT = table_backward(kw["T"], ops.sort_dedup(kw["temps"], kw["T"].shape[0]), temp_occ)
+            gT = table_backward(kw["T"], sorted_index(kw["temps"], kw["T"].shape[0]), temp_occ)
         if kw["user_bias"] is not None:
             gub = table_backward(kw["user_bias"], su, gsum, dim=1)
         if kw["item_bias"] is not None:
@@ -218,7 +239,7 @@ class GatherConcat(Function):
                 used = idx.reshape(-1, stride)[:n, k] if stride > 1 else idx.reshape(-1)[:n]
                 idx_parts.append(used + base if base else used)
             flat = idx_parts[0] if len(idx_parts) == 1 else torch.cat(idx_parts)
-            si = ops.sort_dedup(flat.contiguous(), table.shape[0])
+            si = sorted_index(flat, table.shape[0])
             grads.append(table_backward(table, si, occ))
         return (None, None, None, *grads)
 
@@ -234,8 +255,8 @@ class GMFMul(Function):
     def backward(ctx, dout):
         users, items, U, V = ctx.args
         user_occ, item_occ = ops.gmf_mul_bwd(dout.contiguous(), U, V, users, items)
-        gU = table_backward(U, ops.sort_dedup(users, U.shape[0]), user_occ)
-        gV = table_backward(V, ops.sort_dedup(items, V.shape[0]), item_occ)
+        gU = table_backward(U, sorted_index(users, U.shape[0]), user_occ)
+        gV = table_backward(V, sorted_index(items, V.shape[0]), item_occ)
         return None, None, gU, gV
 
 

@@ -503,14 +503,27 @@ gemm_bf16_pipe_kernel(GemmArgs g, int swizzle) {
   }
 }
 
-// out[i] = sum_s slabs[s][i] in slab order
+// out[i] = sum over the slabs of slabs[s][i], in a fixed order: four slab lanes per output
+// element (lane q adds slabs q, q+4, ... in increasing order), joined as (l0 + l1) + (l2 + l3).
+// Small weight matrices are cut into many slabs, so the lanes matter more than the columns.
 __global__ void __launch_bounds__(RX_BLOCK)
 slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int q = 0; q < n_slabs; ++q) s += slabs[(int64_t)q * n + i];
-  out[i] = s;
+  if (i < n) {
+    int z = q;
+    for (; z + 12 < n_slabs; z += 16) {
+      const float a = slabs[(int64_t)z * n + i], b = slabs[(int64_t)(z + 4) * n + i];
+      const float c = slabs[(int64_t)(z + 8) * n + i], d = slabs[(int64_t)(z + 12) * n + i];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; z < n_slabs; z += 4) s += slabs[(int64_t)z * n + i];
+  }
+  part[q][e] = s;
+  __syncthreads();
+  if (q == 0 && i < n) out[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 // ---------------------------------------------------------------- fp32 operands, pipelined
@@ -845,7 +858,7 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(X, ldx);
   if (gemm_launch<false, false>(g, n_slabs, bf16, st)) return 1;
   const int64_t nk = (int64_t)N * K;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, RX_BLOCK)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, 64)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW);
   RX_LAUNCH_CHECK();
   if (db) {
     // the bias gradient has its own, finer slabs: the column sums are a pure streaming read
@@ -856,7 +869,7 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
     if (vec_ok(dY, ldd) && N % 4 == 0) hipLaunchKernelGGL(colsum_slab_kernel<true>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
     else hipLaunchKernelGGL(colsum_slab_kernel<false>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
     RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, RX_BLOCK)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, cs, db);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, 64)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, cs, db);
     RX_LAUNCH_CHECK();
   }
   return 0;

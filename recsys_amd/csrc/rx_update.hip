@@ -850,14 +850,89 @@ __global__ void clip_scale_kernel(const double* __restrict__ acc, float max_norm
   if (total_norm) total_norm[0] = tn;
 }
 
+// ---------------------------------------------------------------- many small dense tensors at once
+// The towers have a dozen weight / bias tensors of a few KB each; one launch per tensor and
+// reduction would cost more in launch latency than in work.  blockIdx.y selects the tensor.
+#define RX_MULTI_BLOCKS 32
+
+__global__ void __launch_bounds__(RX_BLOCK)
+multi_sumsq_kernel(rx_tensor_list t, double* __restrict__ partial) {
+  __shared__ double wsum[RX_BLOCK / 64];
+  const int k = blockIdx.y;
+  const float* __restrict__ x = t.g[k];
+  const int64_t n = t.n[k];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)x[i];
+    acc += v * v;
+  }
+  acc = rx_wave_sum_f64(acc);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)k * RX_MULTI_BLOCKS + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RX_BLOCK)
+multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __restrict__ scale) {
+  const int k = blockIdx.y;
+  float* __restrict__ w = t.w[k];
+  const float* __restrict__ g = t.g[k];
+  float* __restrict__ s = t.state[k];
+  const int64_t n = t.n[k];
+  const float sc = scale ? scale[0] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * sc;
+    if (MODE == RX_SEG_SGD) {
+      w[i] = w[i] - lr * gi;
+    } else {
+      const float si = s[i] + gi * gi;
+      s[i] = si;
+      w[i] = w[i] - lr * (gi / (sqrtf(si) + eps));
+    }
+  }
+}
+
+extern "C" size_t rx_multi_sumsq_partials(int32_t count) {
+  return (size_t)(count > 0 ? count : 0) * RX_MULTI_BLOCKS;
+}
+
+extern "C" int rx_multi_sumsq(const rx_tensor_list* list, double* d_partial, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(list && list->count >= 0 && list->count <= RX_MULTI_MAX, "rx_multi_sumsq: bad tensor list");
+  if (list->count == 0) return 0;
+  RX_REQUIRE(d_partial, "rx_multi_sumsq: null partial buffer");
+  for (int k = 0; k < list->count; ++k) RX_REQUIRE(list->n[k] >= 0 && (list->g[k] || list->n[k] == 0), "rx_multi_sumsq: bad tensor %d", k);
+  hipLaunchKernelGGL(multi_sumsq_kernel, dim3(RX_MULTI_BLOCKS, list->count), dim3(RX_BLOCK), 0, (hipStream_t)stream, *list, d_partial);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_multi_dense_update(const rx_tensor_list* list, int mode, float lr, float eps, const float* d_scale,
+                                     int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(list && list->count >= 0 && list->count <= RX_MULTI_MAX, "rx_multi_dense_update: bad tensor list");
+  RX_REQUIRE(mode == RX_SEG_SGD || mode == RX_SEG_ADAGRAD, "rx_multi_dense_update: mode must be SGD or ADAGRAD");
+  if (list->count == 0) return 0;
+  for (int k = 0; k < list->count; ++k)
+    RX_REQUIRE(list->n[k] >= 0 && ((list->w[k] && list->g[k] && (mode == RX_SEG_SGD || list->state[k])) || list->n[k] == 0), "rx_multi_dense_update: bad tensor %d", k);
+  const dim3 grid(RX_MULTI_BLOCKS, list->count);
+  if (mode == RX_SEG_SGD) hipLaunchKernelGGL(multi_dense_update_kernel<RX_SEG_SGD>, grid, dim3(RX_BLOCK), 0, (hipStream_t)stream, *list, lr, eps, d_scale);
+  else hipLaunchKernelGGL(multi_dense_update_kernel<RX_SEG_ADAGRAD>, grid, dim3(RX_BLOCK), 0, (hipStream_t)stream, *list, lr, eps, d_scale);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 // One block: thread t adds parts[t], parts[t + 256], ... in order (fp64), fixed xor trees and a
 // fixed order over the four waves join them; then the clip factor.
 __global__ void __launch_bounds__(RX_BLOCK)
-clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double* __restrict__ acc, float max_norm,
-                        float* __restrict__ scale, float* __restrict__ total_norm) {
+clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double* __restrict__ parts64, int64_t n64,
+                        const double* __restrict__ acc, float max_norm, float* __restrict__ scale,
+                        float* __restrict__ total_norm) {
   __shared__ double wsum[RX_BLOCK / 64];
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += RX_BLOCK) s += (double)parts[i];
+  for (int64_t i = threadIdx.x; i < n64; i += RX_BLOCK) s += parts64[i];
   s = rx_wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -869,11 +944,12 @@ clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double
   if (total_norm) total_norm[0] = tn;
 }
 
-extern "C" int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_acc, float max_norm,
-                                   float* d_scale, float* d_total_norm, int device, void* stream) {
+extern "C" int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_parts64, int64_t n_parts64,
+                                   const double* d_acc, float max_norm, float* d_scale, float* d_total_norm,
+                                   int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(n_parts >= 0 && (d_parts || n_parts == 0) && d_scale, "rx_clip_scale_parts: bad arguments");
-  hipLaunchKernelGGL(clip_scale_parts_kernel, dim3(1), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_parts, n_parts, d_acc, max_norm, d_scale, d_total_norm);
+  RX_REQUIRE(n_parts >= 0 && (d_parts || n_parts == 0) && n_parts64 >= 0 && (d_parts64 || n_parts64 == 0) && d_scale, "rx_clip_scale_parts: bad arguments");
+  hipLaunchKernelGGL(clip_scale_parts_kernel, dim3(1), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_parts, n_parts, d_parts64, n_parts64, d_acc, max_norm, d_scale, d_total_norm);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -534,14 +534,55 @@ def clip_scale(acc: Tensor, max_norm: float):
     return scale, total
 
 
-def clip_scale_parts(parts: Tensor, acc: Optional[Tensor], max_norm: float):
-    """Clip factor from per-block partial sums of squares (plus ``acc``, a device double, if given)."""
-    _req(parts, torch.float32, "parts")
-    scale = torch.empty(1, dtype=torch.float32, device=parts.device)
-    total = torch.empty(1, dtype=torch.float32, device=parts.device)
-    check(lib.rx_clip_scale_parts(_p(parts), parts.numel(), _p(acc), max_norm, _p(scale), _p(total), _dev(parts),
-                                  _stream(parts)), "rx_clip_scale_parts")
+def clip_scale_parts(parts: Optional[Tensor], acc: Optional[Tensor], max_norm: float, parts64: Optional[Tensor] = None):
+    """Clip factor from per-block partial sums of squares: fp32 ``parts`` (segmented reduce),
+    fp64 ``parts64`` (multi_sumsq_partials), plus ``acc``, a device double, if given."""
+    ref = parts if parts is not None else parts64
+    if parts is not None:
+        _req(parts, torch.float32, "parts")
+    if parts64 is not None:
+        _req(parts64, torch.float64, "parts64")
+    scale = torch.empty(1, dtype=torch.float32, device=ref.device)
+    total = torch.empty(1, dtype=torch.float32, device=ref.device)
+    check(lib.rx_clip_scale_parts(_p(parts), parts.numel() if parts is not None else 0, _p(parts64),
+                                  parts64.numel() if parts64 is not None else 0, _p(acc), max_norm, _p(scale),
+                                  _p(total), _dev(ref), _stream(ref)), "rx_clip_scale_parts")
     return scale, total
+
+
+def _tensor_list(ws, gs, states):
+    from ._lib import TensorList, RX_MULTI_MAX
+    if len(gs) > RX_MULTI_MAX:
+        raise ValueError(f"at most {RX_MULTI_MAX} tensors per launch")
+    t = TensorList()
+    t.count = len(gs)
+    for k, g in enumerate(gs):
+        _req(g, torch.float32, "g")
+        t.g[k] = g.data_ptr()
+        t.n[k] = g.numel()
+        if ws is not None:
+            w = ws[k]
+            if not (w.is_contiguous() and w.numel() == g.numel() and w.dtype == torch.float32):
+                raise ValueError("weight / gradient mismatch")
+            t.w[k] = w.data_ptr()
+        if states is not None:
+            t.state[k] = states[k].data_ptr()
+    return t
+
+
+def multi_sumsq_partials(gs) -> Tensor:
+    """fp64 partial sums of squares of up to 24 contiguous fp32 tensors, one launch."""
+    t = _tensor_list(None, gs, None)
+    out = torch.empty(int(lib.rx_multi_sumsq_partials(len(gs))), dtype=torch.float64, device=gs[0].device)
+    check(lib.rx_multi_sumsq(C.byref(t), _p(out), _dev(gs[0]), _stream(gs[0])), "rx_multi_sumsq")
+    return out
+
+
+def multi_dense_update(ws, gs, mode: int, lr: float, eps: float = 0.0, scale=None, states=None) -> None:
+    """SGD / Adagrad step of up to 24 small dense tensors in one launch."""
+    t = _tensor_list(ws, gs, states)
+    check(lib.rx_multi_dense_update(C.byref(t), mode, lr, eps, _p(scale), _dev(ws[0]), _stream(ws[0])),
+          "rx_multi_dense_update")
 
 
 def reduce_sum(x: Tensor) -> Tensor:

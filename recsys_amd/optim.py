@@ -141,26 +141,55 @@ class FusedOptimizer:
                 st = self._dense_state[id(p)] = (torch.zeros_like(w), torch.zeros_like(w))
             ops.dense_adam(w, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.adam_eps, self._step, scale)
 
+    def _dense_step_all(self, scale):
+        """All dense parameters: SGD / Adagrad in launches of up to 24 tensors; Adam per tensor."""
+        live = [(p, p.grad.contiguous()) for p in self.dense if p.grad is not None]
+        if not live:
+            return
+        if self.dense_kind == "adam" or any(not p.data.is_contiguous() for p, _ in live):
+            for p, _ in live:
+                self._dense_update(p, scale)
+            return
+        mode = _lib.RX_SEG_SGD if self.dense_kind == "sgd" else _lib.RX_SEG_ADAGRAD
+        for i in range(0, len(live), _lib.RX_MULTI_MAX):
+            chunk = live[i:i + _lib.RX_MULTI_MAX]
+            states = None
+            if mode == _lib.RX_SEG_ADAGRAD:
+                states = []
+                for p, _ in chunk:
+                    st = self._dense_state.get(id(p))
+                    if st is None:
+                        st = self._dense_state[id(p)] = torch.zeros_like(p.data)
+                    states.append(st)
+            ops.multi_dense_update([p.data for p, _ in chunk], [g for _, g in chunk], mode, self.lr, self.eps,
+                                   scale=scale, states=states)
+
     def step(self):
         self._step += 1
         scale = None
         if self.clip_norm is not None:
-            # global norm: dense gradients go through a device double; the per-block partials of the
-            # last table reduce ride in the launch that forms the clip factor
+            # Global norm.  Dense gradients: one launch leaves fp64 partials for up to 24 tensors;
+            # they and the per-block partials of the last table reduce ride in the launch that forms
+            # the clip factor.  Anything beyond that goes through a device double first.
             acc = None
-            grads = [p.grad for p in self.dense if p.grad is not None]
+            grads = [p.grad.contiguous().reshape(-1) for p in self.dense if p.grad is not None]
             parts = [e[4] for e in self._pending if e[4] is not None]
-            if grads or len(parts) != 1:
+            parts64 = ops.multi_sumsq_partials(grads[:_lib.RX_MULTI_MAX]) if grads else None
+            rest = grads[_lib.RX_MULTI_MAX:]
+            if rest or len(parts) > 1:
                 dev = (self.dense[0] if self.dense else self.sparse[0]).device
                 acc = torch.zeros(1, dtype=torch.float64, device=dev)
-                for g in grads:
-                    ops.sumsq_accumulate(g.contiguous().reshape(-1), acc)
+                for g in rest:
+                    ops.sumsq_accumulate(g, acc)
                 for sq in parts[:-1]:
                     ops.sum_accumulate(sq, acc)
-            if parts:
-                scale, self.last_total_norm = ops.clip_scale_parts(parts[-1], acc, float(self.clip_norm))
+            if parts or parts64 is not None:
+                scale, self.last_total_norm = ops.clip_scale_parts(parts[-1] if parts else None, acc,
+                                                                   float(self.clip_norm), parts64)
             else:
-                scale, self.last_total_norm = ops.clip_scale(acc, float(self.clip_norm))
+                dev = (self.dense[0] if self.dense else self.sparse[0]).device
+                scale, self.last_total_norm = ops.clip_scale(torch.zeros(1, dtype=torch.float64, device=dev),
+                                                             float(self.clip_norm))
             for (rule, param, compact, si, _, comp) in self._pending:
                 if comp is not None:
                     rule2, param2, compact2 = comp
@@ -171,5 +200,4 @@ class FusedOptimizer:
                     ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
                                    eps=rule.eps, scale=scale)
             self._pending.clear()
-        for p in self.dense:
-            self._dense_update(p, scale)
+        self._dense_step_all(scale)

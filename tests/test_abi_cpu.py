@@ -34,13 +34,14 @@ def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "recsys_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rx_gather_seg), sizeof(rx_mf_args), sizeof(rx_fm_args),'
-        ' offsetof(rx_gather_seg, dim), offsetof(rx_mf_args, B), offsetof(rx_fm_args, flags));return 0;}\n')
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rx_gather_seg), sizeof(rx_mf_args), sizeof(rx_fm_args),'
+        ' offsetof(rx_gather_seg, dim), offsetof(rx_mf_args, B), offsetof(rx_fm_args, flags),'
+        ' sizeof(rx_tensor_list), offsetof(rx_tensor_list, count));return 0;}\n')
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     exp = [C.sizeof(_lib.GatherSeg), C.sizeof(_lib.MFArgs), C.sizeof(_lib.FMArgs), _lib.GatherSeg.dim.offset,
-           _lib.MFArgs.B.offset, _lib.FMArgs.flags.offset]
+           _lib.MFArgs.B.offset, _lib.FMArgs.flags.offset, C.sizeof(_lib.TensorList), _lib.TensorList.count.offset]
     assert got == exp
 
 

@@ -229,6 +229,31 @@ def test_two_phase_clip_update_with_companion(ops, mode):
     assert torch.equal(w.cpu()[~touched], w0[~touched]) and torch.equal(b.cpu()[~touched], b0[~touched])
 
 
+@pytest.mark.parametrize("mode", ["sgd", "adagrad"])
+def test_multi_tensor_norm_and_update(ops, mode):
+    """Sum of squares and optimizer step of many small dense tensors, one launch each."""
+    from recsys_amd import _lib
+    g = _gen(11)
+    shapes = [(64, 128), (64,), (1, 32), (1,), (300, 7), (5000,)]
+    ws = [torch.randn(*sh, generator=g) for sh in shapes]
+    gs = [torch.randn(*sh, generator=g) for sh in shapes]
+    wd, gd = [w.clone().cuda() for w in ws], [x.clone().cuda() for x in gs]
+    parts64 = ops.multi_sumsq_partials([x.reshape(-1) for x in gd])
+    scale, total = ops.clip_scale_parts(None, None, 1.0, parts64)
+    ref = [w.clone().requires_grad_(True) for w in ws]
+    for r, x in zip(ref, gs):
+        r.grad = x.clone()
+    tn = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+    assert_close(total.item(), tn.item(), what="total norm")
+    opt = torch.optim.SGD(ref, lr=0.3) if mode == "sgd" else torch.optim.Adagrad(ref, lr=0.3, eps=1e-10)
+    opt.step()
+    states = [torch.zeros_like(w) for w in wd] if mode == "adagrad" else None
+    kind = _lib.RX_SEG_SGD if mode == "sgd" else _lib.RX_SEG_ADAGRAD
+    ops.multi_dense_update(wd, gd, kind, 0.3, 1e-10, scale=scale, states=states)
+    for a, b in zip(wd, ref):
+        assert_close(a.cpu().numpy(), b.detach().numpy(), what=f"{mode} dense step")
+
+
 # ------------------------------------------------------------------ BatchNorm1d + ReLU + dropout
 @pytest.mark.parametrize("M,C", [(300, 70), (1024, 64), (4096, 216), (2, 5)])
 @pytest.mark.parametrize("relu,drop", [(False, False), (True, False), (True, True)])
