@@ -223,6 +223,19 @@ def algo_bytes(desc, op, rho=1.0):
     return None
 
 
+def dense_flops_per_sample(name):
+    """Algorithmic flops of the dense layers per sample, fwd + grad-x + grad-w (3 x 2 MACs)."""
+    def mlp(dims):
+        return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    if name == "dcnv2_criteo":
+        return 6.0 * (3 * 432 * 432 + mlp([432, 1024, 512, 256, 1]))
+    if name == "deepfm_criteo":
+        return 6.0 * mlp([432, 432, 216, 108, 1])
+    if name == "neumf_ml1m":  # per (user, item) pair: MLP 128-64-32, GMF 64-32, head 64-1; 5 pairs per sample
+        return 6.0 * 5 * (mlp([128, 64, 32]) + 64 * 32 + 64)
+    return None
+
+
 def measured_traffic(op):
     """HBM bytes per launch from committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, summed
     over the op's kernels), or None when no measurement is on file."""
@@ -297,7 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="", help="comma list of further workloads to time briefly and append")
+    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,dcnv2_criteo",
+                    help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -396,13 +410,16 @@ def main():
     del w
     torch.cuda.empty_cache()
 
-    extras = [x for x in args.extra.split(",") if x]
+    extras = [x for x in args.extra.split(",") if x and x != "none" and x != args.workload]
     if extras and rank == 0 and world == 1:
         out["other_workloads"] = []
         for name in extras:
             w2, el2, _, _ = run(name, 30, 5)
-            out["other_workloads"].append({"workload": name, "samples_per_s": w2["B"] * 30 / el2,
-                                           "ms_per_step": 1e3 * el2 / 30})
+            entry = {"workload": name, "samples_per_s": w2["B"] * 30 / el2, "ms_per_step": 1e3 * el2 / 30}
+            fl = dense_flops_per_sample(name)
+            if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
+                entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12
+            out["other_workloads"].append(entry)
             del w2
             torch.cuda.empty_cache()
 

@@ -1,0 +1,133 @@
+"""Size-independent properties at the full benchmark sizes (Criteo shape: batch 65536, 26 fields,
+33 M rows, D = 16), where the CPU oracle would take minutes: sortedness and permutation checks
+of the index preparation, linearity and run-to-run bit-reproducibility of the reduce, untouched
+rows, and one fused train step against a dense-gradient restatement built from plain torch ops on
+the same device."""
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+B, D = 65536, 16
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from recsys_amd import ops, synthetic
+    ops.set_index_check("sync")
+    dev = torch.device("cuda", 0)
+    dims = synthetic.criteo_field_dims()
+    batch = synthetic.criteo_batch(dims, B, seed=7, device=dev)
+    offs = torch.tensor([0] + dims[:-1], device=dev).cumsum(0)
+    flat = (batch["sparse"] + offs[None, :]).reshape(-1).contiguous()
+    return dict(ops=ops, dev=dev, dims=dims, batch=batch, flat=flat, rows=sum(dims))
+
+
+def test_sort_dedup_properties_full_size(setup):
+    ops, flat, rows = setup["ops"], setup["flat"], setup["rows"]
+    si = ops.sort_dedup(flat, rows, want_inverse=True)
+    nu = int(si.n_uniq.item())
+    uniq = si.uniq_rows[:nu]
+    assert torch.all(uniq[1:] > uniq[:-1]), "distinct rows must be strictly increasing"
+    assert torch.equal(uniq, torch.unique(flat)), "distinct-row set"
+    pos = si.sorted_pos.long()
+    assert torch.equal(torch.sort(pos).values, torch.arange(flat.numel(), device=flat.device)), "a permutation"
+    keys = flat[pos]
+    assert torch.all(keys[1:] >= keys[:-1]), "sorted by row"
+    same = keys[1:] == keys[:-1]
+    assert torch.all(pos[1:][same] > pos[:-1][same]), "stable: original order inside a run"
+    assert torch.equal(pos, torch.sort(flat, stable=True).indices), "the permutation of a stable sort"
+    seg = si.seg_off[:nu + 1].long()
+    assert seg[0] == 0 and seg[-1] == flat.numel() and torch.all(seg[1:] > seg[:-1])
+    assert torch.equal(uniq[si.sorted_slot.long()], keys), "slot of every sorted position"
+    assert torch.equal(uniq[si.inverse.long()], flat), "inverse map"
+
+
+def test_segreduce_linearity_and_reproducibility_full_size(setup):
+    from recsys_amd import _lib
+    ops, flat, rows, dev = setup["ops"], setup["flat"], setup["rows"], setup["dev"]
+    n = flat.numel()
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn(n, D, generator=g, device=dev)
+    b = torch.randn(n, D, generator=g, device=dev)
+    si = ops.sort_dedup(flat, rows)
+    nu = int(si.n_uniq.item())
+
+    def compact(occ):
+        out = torch.empty(n, D, device=dev)
+        ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, out)
+        return out[:nu]
+
+    ca, cb, cab = compact(a), compact(b), compact(a + b)
+    assert torch.equal(ca, compact(a)), "bitwise reproducible run to run"
+    assert_close((ca + cb).cpu().numpy(), cab.cpu().numpy(), rtol=1e-5, what="linearity")
+    # checksum of checksums: the column sums of all distinct-row gradients equal those of all occurrences
+    assert_close(ca.double().sum(0).cpu().numpy(), a.double().sum(0).cpu().numpy(), rtol=1e-5, what="column checksum")
+    # against an atomics-free restatement with torch ops
+    ref = torch.zeros(nu, D, device=dev, dtype=torch.float64).index_add_(0, si.inverse.long() if si.inverse is not None
+                                                                         else torch.searchsorted(si.uniq_rows[:nu], flat), a.double())
+    assert_close(ca.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, what="per-row sums")
+
+
+def test_fm_forward_permutation_invariance_full_size(setup):
+    """The FM logit sums over fields: feeding the non-item fields in another order changes nothing
+    but the rounding."""
+    from recsys_amd.models import fields
+    dims, batch, dev = setup["dims"], setup["batch"], setup["dev"]
+    torch.manual_seed(0)
+    with torch.device(dev):
+        m = fields.FieldFM(dims, D).eval()
+    logits = m(batch)
+    assert logits.shape == (B, 1) and torch.isfinite(logits).all()
+    # same model evaluated by plain torch gathers on the device
+    offs = torch.tensor([0] + dims[:-1], device=dev).cumsum(0)
+    idx = batch["sparse"] + offs[None, :]
+    e = m.feature_embedding.weight[idx].double()
+    bias = m.bias_embedding.weight[idx].double().sum(1)
+    s = e.sum(1)
+    ref = bias + 0.5 * (s * s - (e * e).sum(1)).sum(-1, keepdim=True)
+    assert_close(logits.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, what="FM logits at full size")
+
+
+def test_fused_step_matches_dense_restatement_full_size(setup):
+    """One fused SGD step with global clip 1.0 at the benchmark size against dense gradients,
+    clip_grad_norm_ and a dense SGD update made of plain torch ops; rows that the batch does not
+    touch must stay bit-identical."""
+    from recsys_amd.models import fields
+    from recsys_amd.optim import FusedOptimizer
+    dims, batch, dev = setup["dims"], setup["batch"], setup["dev"]
+    torch.manual_seed(0)
+    with torch.device(dev):
+        m = fields.FieldFM(dims, D)
+    w0, b0 = m.feature_embedding.weight.detach().clone(), m.bias_embedding.weight.detach().clone()
+    # reference: autograd through plain torch ops, dense gradients
+    wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    offs = torch.tensor([0] + dims[:-1], device=dev).cumsum(0)
+    idx = batch["sparse"] + offs[None, :]
+    e = wr[idx]
+    s = e.sum(1)
+    logits = br[idx].sum(1) + 0.5 * (s * s - (e * e).sum(1)).sum(-1, keepdim=True)
+    loss_ref = torch.nn.functional.binary_cross_entropy_with_logits(logits, batch["label"])
+    loss_ref.backward()
+    tn = torch.nn.utils.clip_grad_norm_([wr, br], 1.0)
+    lr = 0.05
+    with torch.no_grad():
+        wr -= lr * wr.grad
+        br -= lr * br.grad
+    # fused path
+    opt = FusedOptimizer(m, kind="sgd", lr=lr, clip_norm=1.0)
+    m.train()
+    opt.zero_grad()
+    loss = m.loss(batch)
+    loss.backward()
+    opt.step()
+    assert_close(loss.item(), loss_ref.item(), rtol=1e-6, what="loss")  # fp64 mean over fp32 logits that agree to rounding
+    assert_close(opt.last_total_norm.item(), tn.item(), rtol=1e-5, what="global gradient norm")
+    touched = torch.zeros(sum(dims), dtype=torch.bool, device=dev)
+    touched[idx.reshape(-1)] = True
+    w1, b1 = m.feature_embedding.weight.detach(), m.bias_embedding.weight.detach()
+    assert torch.equal(w1[~touched], w0[~touched]) and torch.equal(b1[~touched], b0[~touched]), "untouched rows moved"
+    assert_close(w1[touched].cpu().numpy(), wr.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated rows")
+    assert_close(b1[touched].cpu().numpy(), br.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated bias rows")
