@@ -66,15 +66,31 @@ bn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, int6
   }
 }
 
+// Joins the slab partials of 64 columns per block: four slab lanes per column (lane q adds slabs
+// q, q+4, ... in order), joined as (l0 + l1) + (l2 + l3).
+__device__ __forceinline__ void bn_join(const double* __restrict__ partial, int n_slabs, int C, int j, int q,
+                                        double (*lds)[64][2], double* a_out, double* b_out) {
+  double a = 0, b = 0;
+  if (j < C)
+    for (int z = q; z < n_slabs; z += 4) { a += partial[((int64_t)z * C + j) * 2]; b += partial[((int64_t)z * C + j) * 2 + 1]; }
+  lds[q][threadIdx.x & 63][0] = a;
+  lds[q][threadIdx.x & 63][1] = b;
+  __syncthreads();
+  const int e = threadIdx.x & 63;
+  *a_out = (lds[0][e][0] + lds[1][e][0]) + (lds[2][e][0] + lds[3][e][0]);
+  *b_out = (lds[0][e][1] + lds[1][e][1]) + (lds[2][e][1] + lds[3][e][1]);
+}
+
 // mean, 1/sqrt(var + eps) with the biased variance; running estimates with the unbiased one
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_stats_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M, int C, float eps, float momentum,
                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                       float* __restrict__ running_var) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= C) return;
-  double a = 0, b = 0;
-  for (int z = 0; z < n_slabs; ++z) { a += partial[((int64_t)z * C + j) * 2]; b += partial[((int64_t)z * C + j) * 2 + 1]; }
+  __shared__ double lds[4][64][2];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double a, b;
+  bn_join(partial, n_slabs, C, j, q, lds, &a, &b);
+  if (q != 0 || j >= C) return;
   const double mu = a / (double)M;
   double var = b / (double)M - mu * mu;
   if (var < 0) var = 0;
@@ -87,34 +103,64 @@ bn_stats_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M
   }
 }
 
-// out = keep * keep_scale * act(gamma * (x - mean) * rstd + beta)
+// out = keep * keep_scale * act(gamma * (x - mean) * rstd + beta).  Same geometry as the statistics
+// pass (64 columns x 16 row lanes per block, a slab of rows per blockIdx.z): the per-column
+// constants are read once per thread and no index arithmetic is left in the row loop.
 template <bool VEC>
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, const float* __restrict__ mean,
                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                int relu, const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ out, int64_t ldo) {
-  const int quads = (C + 3) / 4;
-  const int64_t total = M * quads;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / quads;
-    const int j0 = (int)(i - r * quads) * 4;
-    const int valid = C - j0;
-    const float4 v = bn_ld4(x + r * ldx + j0, VEC, valid);
-    const float e[4] = {v.x, v.y, v.z, v.w};
-    float o[4];
+                int relu, const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ out, int64_t ldo,
+                int64_t rows_per_slab) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int j0 = blockIdx.x * BN_COLS + cq * 4;
+  const int valid = C - j0;
+  if (valid <= 0) return;
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float sc[4], sh[4], gm[4], bt[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = j0 + (t < valid ? t : 0);
-      const float g = gamma ? gamma[j] : 1.f, b = beta ? beta[j] : 0.f;
-      float y = (e[t] - mean[j]) * rstd[j] * g + b;
-      if (relu) y = y > 0.f ? y : 0.f;
-      if (keep) y = keep[r * (int64_t)C + j] ? y * keep_scale : 0.f;
-      o[t] = y;
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + (t < valid ? t : 0);
+    sc[t] = rstd[j];
+    sh[t] = mean[j];
+    gm[t] = gamma ? gamma[j] : 1.f;
+    bt[t] = beta ? beta[j] : 0.f;
+  }
+  for (int64_t r = lo + rl; r < hi; r += 32) {
+    float4 v[2];
+    uint32_t kp[2] = {0x01010101u, 0x01010101u};
+    const bool second = r + 16 < hi;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t rr = (u == 0 || second) ? r + 16 * u : r;
+      v[u] = bn_ld4(x + rr * ldx + j0, VEC, valid);
+      if (keep) {
+        const uint8_t* kptr = keep + rr * (int64_t)C + j0;
+        if (VEC) kp[u] = *reinterpret_cast<const uint32_t*>(kptr);
+        else {
+          kp[u] = 0;
+          for (int t = 0; t < 4 && t < valid; ++t) kp[u] |= (uint32_t)kptr[t] << (8 * t);
+        }
+      }
     }
-    float* dst = out + r * ldo + j0;
-    if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    else
-      for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !second) continue;
+      const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      float o[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float y = (e[t] - sh[t]) * sc[t] * gm[t] + bt[t];
+        if (relu) y = y > 0.f ? y : 0.f;
+        if (keep) y = ((kp[u] >> (8 * t)) & 0xffu) ? y * keep_scale : 0.f;
+        o[t] = y;
+      }
+      float* dst = out + (r + 16 * u) * ldo + j0;
+      if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      else
+        for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+    }
   }
 }
 
@@ -180,10 +226,11 @@ bn_bwd_sums_kernel(const float* __restrict__ dout, int64_t ldd, const float* __r
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_bwd_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M, int C, float* __restrict__ dgamma,
                     float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= C) return;
-  double a = 0, b = 0;
-  for (int z = 0; z < n_slabs; ++z) { a += partial[((int64_t)z * C + j) * 2]; b += partial[((int64_t)z * C + j) * 2 + 1]; }
+  __shared__ double lds[4][64][2];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  double a, b;
+  bn_join(partial, n_slabs, C, j, q, lds, &a, &b);
+  if (q != 0 || j >= C) return;
   if (dbeta) dbeta[j] = (float)a;
   if (dgamma) dgamma[j] = (float)b;
   coef[2 * j] = (float)(a / (double)M);
@@ -196,36 +243,51 @@ __global__ void __launch_bounds__(RX_BLOCK)
 bn_bwd_dx_kernel(const float* __restrict__ dout, int64_t ldd, const float* __restrict__ x, int64_t ldx,
                  const float* __restrict__ out, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ coef,
-                 int gate, float keep_scale, int batch_stats, float* __restrict__ dx, int64_t lddx) {
-  const int quads = (C + 3) / 4;
-  const int64_t total = M * quads;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / quads;
-    const int j0 = (int)(i - r * quads) * 4;
-    const int valid = C - j0;
-    const float4 vd = bn_ld4(dout + r * ldd + j0, VEC, valid);
-    const float4 vx = bn_ld4(x + r * ldx + j0, VEC, valid);
-    const float4 vo = gate ? bn_ld4(out + r * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float d[4] = {vd.x, vd.y, vd.z, vd.w};
-    const float xe[4] = {vx.x, vx.y, vx.z, vx.w};
-    const float oe[4] = {vo.x, vo.y, vo.z, vo.w};
-    float o[4];
+                 int gate, float keep_scale, int batch_stats, float* __restrict__ dx, int64_t lddx,
+                 int64_t rows_per_slab) {
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int j0 = blockIdx.x * BN_COLS + cq * 4;
+  const int valid = C - j0;
+  if (valid <= 0) return;
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float mu[4], rs[4], gg[4], c0[4], c1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int j = j0 + (t < valid ? t : 0);
-      const float dz = gate ? (oe[t] != 0.f ? d[t] * keep_scale : 0.f) : d[t];
-      const float g = (gamma ? gamma[j] : 1.f) * rstd[j];
-      if (batch_stats) {
-        const float xh = (xe[t] - mean[j]) * rstd[j];
-        o[t] = g * (dz - coef[2 * j] - xh * coef[2 * j + 1]);
-      } else {
-        o[t] = g * dz;
-      }
+  for (int t = 0; t < 4; ++t) {
+    const int j = j0 + (t < valid ? t : 0);
+    mu[t] = mean[j]; rs[t] = rstd[j];
+    gg[t] = (gamma ? gamma[j] : 1.f) * rstd[j];
+    c0[t] = batch_stats ? coef[2 * j] : 0.f;
+    c1[t] = batch_stats ? coef[2 * j + 1] : 0.f;
+  }
+  for (int64_t r = lo + rl; r < hi; r += 32) {
+    float4 vd[2], vx[2], vo[2];
+    const bool second = r + 16 < hi;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t rr = (u == 0 || second) ? r + 16 * u : r;
+      vd[u] = bn_ld4(dout + rr * ldd + j0, VEC, valid);
+      vx[u] = bn_ld4(x + rr * ldx + j0, VEC, valid);
+      vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
-    float* dst = dx + r * lddx + j0;
-    if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    else
-      for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !second) continue;
+      const float d[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+      const float xe[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w};
+      const float oe[4] = {vo[u].x, vo[u].y, vo[u].z, vo[u].w};
+      float o[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float dz = gate ? (oe[t] != 0.f ? d[t] * keep_scale : 0.f) : d[t];
+        const float xh = (xe[t] - mu[t]) * rs[t];
+        o[t] = gg[t] * (dz - c0[t] - xh * c1[t]);
+      }
+      float* dst = dx + (r + 16 * u) * lddx + j0;
+      if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      else
+        for (int t = 0; t < 4 && t < valid; ++t) dst[t] = o[t];
+    }
   }
 }
 
@@ -257,14 +319,19 @@ extern "C" int rx_bn_stats(const float* d_x, int64_t ldx, int64_t M, int32_t C, 
   if (bn_vec(d_x, ldx, C)) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, rows, (double*)ws);
   else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, rows, (double*)ws);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)rx_cdiv(C, RX_BLOCK)), dim3(RX_BLOCK), 0, st, (const double*)ws, slabs, M, C, eps, momentum, d_mean, d_rstd, d_running_mean, d_running_var);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)rx_cdiv(C, 64)), dim3(RX_BLOCK), 0, st, (const double*)ws, slabs, M, C, eps, momentum, d_mean, d_rstd, d_running_mean, d_running_var);
   RX_LAUNCH_CHECK();
   return 0;
 }
 
-static unsigned bn_ew_grid(int64_t M, int C) {
-  int64_t g = rx_cdiv(M * ((C + 3) / 4), RX_BLOCK);
-  return (unsigned)(g < 16384 ? (g < 1 ? 1 : g) : 16384);
+// streaming passes: enough slabs of rows to fill the chip at any width
+static int bn_ew_slabs(int64_t M, int C, int64_t* rows_per_slab) {
+  const int64_t col_blocks = rx_cdiv(C, BN_COLS);
+  int64_t want = rx_cdiv(2048, col_blocks);
+  int64_t rows = rx_cdiv(M, want);
+  rows = rx_cdiv(rows, 32) * 32;
+  *rows_per_slab = rows;
+  return (int)rx_cdiv(M, rows);
 }
 
 extern "C" int rx_bn_apply(const float* d_x, int64_t ldx, int64_t M, int32_t C, const float* d_mean,
@@ -276,10 +343,13 @@ extern "C" int rx_bn_apply(const float* d_x, int64_t ldx, int64_t M, int32_t C, 
   if (M == 0) return 0;
   RX_REQUIRE(d_x && d_mean && d_rstd && d_out, "rx_bn_apply: null argument");
   hipStream_t st = (hipStream_t)stream;
+  int64_t rows;
+  const int slabs = bn_ew_slabs(M, C, &rows);
+  const dim3 grid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)slabs);
   if (bn_vec(d_x, ldx, C) && bn_vec(d_out, ldo, C))
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo, rows);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(RX_BLOCK), 0, st, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta, relu, d_keep, keep_scale, d_out, ldo, rows);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -303,10 +373,13 @@ extern "C" int rx_bn_bwd(const float* d_dout, int64_t ldd, const float* d_x, int
   if (vec) hipLaunchKernelGGL(bn_bwd_sums_kernel<true>, grid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, gate, keep_scale, rows, partial);
   else hipLaunchKernelGGL(bn_bwd_sums_kernel<false>, grid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, gate, keep_scale, rows, partial);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)rx_cdiv(C, RX_BLOCK)), dim3(RX_BLOCK), 0, st, (const double*)partial, slabs, M, C, d_dgamma, d_dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)rx_cdiv(C, 64)), dim3(RX_BLOCK), 0, st, (const double*)partial, slabs, M, C, d_dgamma, d_dbeta, coef);
   RX_LAUNCH_CHECK();
-  if (vec) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx);
-  else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(bn_ew_grid(M, C)), dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx);
+  int64_t erows;
+  const int eslabs = bn_ew_slabs(M, C, &erows);
+  const dim3 egrid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)eslabs);
+  if (vec) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, egrid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx, erows);
+  else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, egrid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx, erows);
   RX_LAUNCH_CHECK();
   return 0;
 }
