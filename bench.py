@@ -66,12 +66,13 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
 
         # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
         return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world)
-    if name in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+    if name in ("fm_criteo", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
         B, D = 65536, 16
-        cls = {"fm_criteo": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM, "dcnv2_criteo": fields.DCNv2}[name]
+        cls = {"fm_criteo": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM, "deepfm_criteo_bf16": fields.FieldDeepFM,
+               "dcnv2_criteo": fields.DCNv2}[name]
         with torch.device(device):
-            model = cls(dims, D)
+            model = cls(dims, D, bf16=True) if name == "deepfm_criteo_bf16" else cls(dims, D)
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD", "clip_norm": clip}
@@ -208,7 +209,7 @@ def algo_bytes(desc, op, rho=1.0):
     the per-sample figures are fwd F(8 + De) + 4, bwd 4 + F De + 8F, update rho F 2 De, with
     F fields, D columns, e = 4 bytes and rho the measured distinct-row fraction."""
     B, D = desc["batch_per_gpu"], desc["dim"]
-    if desc["workload"] in ("fm_criteo", "fm_criteo_sharded", "deepfm_criteo", "dcnv2_criteo"):
+    if desc["workload"] in ("fm_criteo", "fm_criteo_sharded", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         F = desc["fields"]
         if op == "fm2_fwd":  # index + row + bias entry per field, one logit out
             return B * (F * (8 + 4 * D + 4) + 4)
@@ -223,13 +224,19 @@ def algo_bytes(desc, op, rho=1.0):
     return None
 
 
+def workload_dtype(name):
+    """Arithmetic type of the path: embedding work is fp32 everywhere; the bf16 workloads round the
+    tower / cross GEMM operands to bf16 (fp32 accumulation, fp32 master weights)."""
+    return "bf16" if name in ("dcnv2_criteo", "deepfm_criteo_bf16") else "f32"
+
+
 def dense_flops_per_sample(name):
     """Algorithmic flops of the dense layers per sample, fwd + grad-x + grad-w (3 x 2 MACs)."""
     def mlp(dims):
         return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
     if name == "dcnv2_criteo":
         return 6.0 * (3 * 432 * 432 + mlp([432, 1024, 512, 256, 1]))
-    if name == "deepfm_criteo":
+    if name in ("deepfm_criteo", "deepfm_criteo_bf16"):
         return 6.0 * mlp([432, 432, 216, 108, 1])
     if name == "neumf_ml1m":  # per (user, item) pair: MLP 128-64-32, GMF 64-32, head 64-1; 5 pairs per sample
         return 6.0 * 5 * (mlp([128, 64, 32]) + 64 * 32 + 64)
@@ -261,9 +268,10 @@ def cpu_baseline(name, desc, clip, budget_s=25.0):
 
     threads = torch.get_num_threads()
     B = desc["batch_per_gpu"]
-    if name in ("fm_criteo", "deepfm_criteo", "dcnv2_criteo"):
+    if name in ("fm_criteo", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
-        cls = {"fm_criteo": "FieldFM", "deepfm_criteo": "FieldDeepFM", "dcnv2_criteo": "DCNv2"}[name]
+        cls = {"fm_criteo": "FieldFM", "deepfm_criteo": "FieldDeepFM", "deepfm_criteo_bf16": "FieldDeepFM",
+               "dcnv2_criteo": "DCNv2"}[name]
         torch.manual_seed(1234)
         m = getattr(fields, cls)(dims, desc["dim"])
         oracle = FieldOracle(cls, m.state_dict(), dims, dropout=0.1)
@@ -310,7 +318,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,dcnv2_criteo",
+    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
@@ -371,6 +379,7 @@ def main():
         del w
 
     dominant = {"fm_criteo": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm", "deepfm_criteo": "linear_bwd_w",
+                "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
     if world > 1 and args.workload == "fm_criteo":
@@ -388,7 +397,7 @@ def main():
     out = {
         "metric": "train samples/sec (fwd+bwd+update)", "value": value, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": workload_dtype(args.workload), "data": "synthetic",
         "config": dict(w["desc"], global_batch=B * world, parallelism=f"dp{world}" if world > 1 else "single"),
         "final_loss": last_loss,
     }
@@ -415,7 +424,8 @@ def main():
         out["other_workloads"] = []
         for name in extras:
             w2, el2, _, _ = run(name, 30, 5)
-            entry = {"workload": name, "samples_per_s": w2["B"] * 30 / el2, "ms_per_step": 1e3 * el2 / 30}
+            entry = {"workload": name, "samples_per_s": w2["B"] * 30 / el2, "ms_per_step": 1e3 * el2 / 30,
+                     "dtype": workload_dtype(name)}
             fl = dense_flops_per_sample(name)
             if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
                 entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12

@@ -88,10 +88,10 @@ class FieldDeepFM(_FieldTable):
     reference rule [in, in/2, in/4] (deep_factorization_machine.py:47-51)."""
     _sparse_names = ["feature_embedding.weight", "bias_embedding.weight"]
 
-    def __init__(self, field_dims, embedding_dim, n_dense=13, dropout=0.1):
+    def __init__(self, field_dims, embedding_dim, n_dense=13, dropout=0.1, bf16=False):
         super().__init__()
         self._init_fields(field_dims, embedding_dim)
-        self.n_dense = n_dense
+        self.n_dense, self.bf16 = n_dense, bf16   # bf16: tower GEMM operands rounded to bf16, fp32 accumulation
         self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
         self.bias_embedding = nn.Embedding(self.n_features, 1)
         d_in = self.n_fields * embedding_dim + n_dense
@@ -105,7 +105,7 @@ class FieldDeepFM(_FieldTable):
         fm, x = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
                               self.bias_embedding.weight, True, True, d_emb + self.n_dense + self.pad, True,
                               _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
-        return fm + run_tower(self.deep_mlp, x)
+        return fm + run_tower(self.deep_mlp, x, bf16=self.bf16)
 
 
 def _dense_input(inputs, n_dense, rows, pad=0):
