@@ -11,8 +11,9 @@ step (recsys/utils.py:96-103: zero_grad, loss, backward, global grad-norm clip a
 optimizer step) with the optimizer being the fused sparse SGD row update.
 
 Rank 0 prints ONE JSON line.  ``roofline`` prices the dominant kernel of the step by its
-algorithmic bytes (DESIGN.md lists the per-kernel formulas) over its average duration, measured
-with HIP events on the launch stream inside the timed region.  ``cpu_baseline`` is the CPU oracle
+algorithmic bytes (formulas in algo_bytes below) over its average duration, measured
+with HIP events on the launch stream, re-issuing the op back to back with the arguments of its last call
+in the step.  ``cpu_baseline`` is the CPU oracle
 (a PyTorch restatement of the reference modules and train step) timed on this host's cores on a
 bounded number of steps of the same workload.
 """
