@@ -438,14 +438,30 @@ def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False, out: Option
     return out if out is not None else SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
 
 
+def segreduce_grid(n: int, dim: int) -> int:
+    """Number of per-block partials a reduce over n occurrences of width dim writes."""
+    return max(int(lib.rx_segreduce_grid(n, dim)), 1)
+
+
+def _sq_buffer(n: int, dim: int, device, sq_out: Optional[Tensor]) -> Tensor:
+    need = segreduce_grid(n, dim)
+    if sq_out is None:
+        return torch.empty(need, dtype=torch.float32, device=device)
+    _req(sq_out, torch.float32, "sq_out")
+    if sq_out.numel() != need or not sq_out.is_contiguous():
+        raise ValueError(f"sq_out: expected {need} contiguous floats")
+    return sq_out
+
+
 def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state: Optional[Tensor] = None,
               lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None,
               want_sq: bool = False, occ_ld: Optional[int] = None, dim: Optional[int] = None,
               occ2: Optional[Tensor] = None, target2: Optional[Tensor] = None,
-              state2: Optional[Tensor] = None) -> Optional[Tensor]:
+              state2: Optional[Tensor] = None, sq_out: Optional[Tensor] = None) -> Optional[Tensor]:
     """Run rx_segreduce.  ``occ`` is [n, dim] (or 1-D for dim == 1); ``target`` the table / dense
     gradient / compact buffer.  ``occ2`` / ``target2`` / ``state2``: companion scalar table on the
-    same rows.  Returns the per-block sum-of-squares partials when asked."""
+    same rows.  Returns the per-block sum-of-squares partials when asked (written to ``sq_out``, a
+    buffer of ``segreduce_grid(n, dim)`` floats, when that is given)."""
     if occ2 is not None:
         _req(occ2, torch.float32, "companion gradients"); _req(target2, torch.float32, "companion target")
         if occ2.numel() < si.n:
@@ -458,9 +474,7 @@ def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state:
         occ_ld = dim
     if occ.numel() < (si.n - 1) * occ_ld + dim and si.n > 0:
         raise ValueError("occurrence gradients: too few elements for the index list")
-    sq = None
-    if want_sq:
-        sq = torch.empty(max(int(lib.rx_segreduce_grid(si.n, dim)), 1), dtype=torch.float32, device=occ.device)
+    sq = _sq_buffer(si.n, dim, occ.device, sq_out) if want_sq else None
     ws = _ws(int(lib.rx_segreduce_workspace_bytes(si.n, dim)), occ.device)
     check(lib.rx_segreduce(_p(occ), occ_ld, si.n, dim, _p(si.sorted_pos), _p(si.sorted_slot), _p(si.uniq_rows),
                            _p(si.seg_off), _p(si.n_uniq), mode, _p(target), _p(state), _p(occ2), _p(target2),
@@ -472,15 +486,14 @@ def segreduce(occ: Tensor, si: SortedIndex, mode: int, target: Tensor, *, state:
 def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mode: int, target: Tensor, *,
                  table: Optional[Tensor] = None, state: Optional[Tensor] = None, target2: Optional[Tensor] = None,
                  state2: Optional[Tensor] = None, lr: float = 0.0, eps: float = 0.0,
-                 scale: Optional[Tensor] = None, want_sq: bool = False) -> Optional[Tensor]:
+                 scale: Optional[Tensor] = None, want_sq: bool = False,
+                 sq_out: Optional[Tensor] = None) -> Optional[Tensor]:
     """rx_segreduce_fm: N == 1 FM backward straight from T [B, D] and g [B] (no per-occurrence rows)."""
     _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
     B, dim = tsum.shape
     if g.numel() != B or si.n != B * (n_fields_ex + 1):
         raise ValueError("segreduce_fm: shapes disagree with the sorted occurrence list")
-    sq = None
-    if want_sq:
-        sq = torch.empty(max(int(lib.rx_segreduce_grid(si.n, dim)), 1), dtype=torch.float32, device=tsum.device)
+    sq = _sq_buffer(si.n, dim, tsum.device, sq_out) if want_sq else None
     ws = _ws(int(lib.rx_segreduce_workspace_bytes(si.n, dim)), tsum.device)
     check(lib.rx_segreduce_fm(_p(tsum), tsum.stride(0), _p(g), B, n_fields_ex, dim, _p(si.sorted_pos),
                               _p(si.sorted_slot), _p(si.uniq_rows), _p(si.seg_off), _p(si.n_uniq), mode, _p(target),

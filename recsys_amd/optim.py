@@ -54,7 +54,7 @@ class SparseRule:
         compact = torch.empty(max(si.n, 1), d, dtype=torch.float32, device=table.device)
         compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if param2 is not None else None
         sq = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, compact, dim=dim, occ_ld=occ_ld, want_sq=True,
-                           occ2=occ2, target2=compact2)
+                           occ2=occ2, target2=compact2, sq_out=self.owner._sq_slice(si.n, d, table.device))
         self.owner._pending.append((self, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
 
 
@@ -73,7 +73,7 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex):
     compact = torch.empty(max(si.n, 1), tsum.shape[1], dtype=torch.float32, device=table.device)
     compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
     sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2,
-                          want_sq=True)
+                          want_sq=True, sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device))
     self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
 
 
@@ -107,6 +107,8 @@ class FusedOptimizer:
             p._rx_sparse = rule
             self.rules.append(rule)
         self._pending = []
+        self._sq_buf: Optional[torch.Tensor] = None   # norm partials of all table reduces of a step, back to back
+        self._sq_used = 0
         self._dense_state = {}
         self._step = 0
         self.last_total_norm: Optional[torch.Tensor] = None
@@ -121,6 +123,21 @@ class FusedOptimizer:
         for p in self.dense:
             p.grad = None
         self._pending.clear()
+        self._sq_used = 0
+
+    def _sq_slice(self, n: int, dim: int, device):
+        """Room for one reduce's norm partials in the step's shared buffer (None when it is full: the
+        reduce then allocates its own and the step adds it separately)."""
+        need = ops.segreduce_grid(n, dim)
+        if self._sq_buf is None or self._sq_buf.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self._sq_buf = torch.empty(1 << 16, dtype=torch.float32, device=device)
+        if self._sq_used + need > self._sq_buf.numel():
+            return None
+        out = self._sq_buf[self._sq_used:self._sq_used + need]
+        self._sq_used += need
+        return out
 
     def _dense_update(self, p, scale):
         g = p.grad
@@ -174,6 +191,11 @@ class FusedOptimizer:
             acc = None
             grads = [p.grad.contiguous().reshape(-1) for p in self.dense if p.grad is not None]
             parts = [e[4] for e in self._pending if e[4] is not None]
+            if self._sq_buf is not None and self._sq_used:
+                # partials written back to back into the shared buffer count as one array
+                base = self._sq_buf.data_ptr()
+                own = [q for q in parts if not (base <= q.data_ptr() < base + self._sq_buf.numel() * 4)]
+                parts = own + [self._sq_buf[:self._sq_used]]
             parts64 = ops.multi_sumsq_partials(grads[:_lib.RX_MULTI_MAX]) if grads else None
             rest = grads[_lib.RX_MULTI_MAX:]
             if rest or len(parts) > 1:
@@ -200,4 +222,5 @@ class FusedOptimizer:
                     ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
                                    eps=rule.eps, scale=scale)
             self._pending.clear()
+            self._sq_used = 0
         self._dense_step_all(scale)
