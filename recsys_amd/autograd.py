@@ -23,15 +23,39 @@ Tensor = torch.Tensor
 
 
 _SORT_CACHE: list = []
+_PRESORTED: dict = {}
+
+
+def _sort_key(flat: Tensor, n_rows: int):
+    return (flat.data_ptr(), flat.numel(), flat._version, int(n_rows), flat.device)
+
+
+def presort(idx: Tensor, n_rows: int, out=None):
+    """Sort + dedup an index tensor ahead of the step that will need it (``HotPathModule.prepare``;
+    typically on a side stream while the previous step runs) and pin the result so that the
+    backward's ``sorted_index`` finds it.  ``out``: a SortedIndex from an earlier call for the same
+    tensor, overwritten in place (static buffers for graph replay)."""
+    flat = idx.reshape(-1)
+    if not flat.is_contiguous():
+        raise ValueError("presort: the index tensor must be contiguous")
+    si = ops.sort_dedup(flat, n_rows, out=out)
+    _PRESORTED[_sort_key(flat, n_rows)] = (flat, si)
+    while len(_PRESORTED) > 512:
+        _PRESORTED.pop(next(iter(_PRESORTED)))
+    return si
 
 
 def sorted_index(idx: Tensor, n_rows: int):
     """``ops.sort_dedup`` with a small memo: NeuMF-style models look the same index tensor up in
     several tables of equal height (GMF and MLP embeddings), and one sort serves them all.  An
     entry is keyed by storage address, length and version counter and keeps its index tensor
-    alive, so a hit can only be the same, unmodified data."""
+    alive, so a hit can only be the same, unmodified data.  Results pinned by ``presort`` are
+    found first."""
     flat = idx.reshape(-1)
-    key = (flat.data_ptr(), flat.numel(), flat._version, int(n_rows), flat.device)
+    key = _sort_key(flat, n_rows)
+    hit = _PRESORTED.get(key)
+    if hit is not None:
+        return hit[1]
     for k, _, si in _SORT_CACHE:
         if k == key:
             return si

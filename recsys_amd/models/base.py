@@ -25,12 +25,22 @@ class HotPathModule(nn.Module):
             if n in named:
                 yield named[n]
 
+    def _index_lists(self, inputs):
+        """``[(index tensor, table height), ...]`` whose sort the backward will ask for."""
+        return []
+
     def prepare(self, inputs, out=None):
-        """Index preparation that depends on the batch only (flat row ids, sort, dedup), done ahead
-        of the step — e.g. on a side stream while the previous step runs.  Returns ``inputs`` with
-        the result attached; models without such work return ``inputs`` unchanged.  ``out``: a
-        previously prepared batch whose buffers are overwritten in place."""
-        return inputs
+        """Index preparation that depends on the batch only (sort, dedup), done ahead of the step —
+        e.g. on a side stream while the previous step runs.  Returns ``inputs`` with the result
+        attached; models without such work return ``inputs`` unchanged.  ``out``: a previously
+        prepared batch whose buffers are overwritten in place."""
+        lists = self._index_lists(inputs)
+        if not lists:
+            return inputs
+        old = out.get("_rx_sorted") if out is not None else None
+        res = dict(inputs)
+        res["_rx_sorted"] = [rxa.presort(t, rows, out=old[k] if old else None) for k, (t, rows) in enumerate(lists)]
+        return res
 
     def loss(self, inputs, *args, **kwargs):
         labels = inputs["label"]

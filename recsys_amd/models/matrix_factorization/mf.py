@@ -27,6 +27,18 @@ class VanillaMF(HotPathModule):
     def _extras(self, inputs):
         return dict(occs=None, temps=None, O=None, UT=None, T=None, user_bias=None, item_bias=None, bias=None)
 
+    def _index_lists(self, inputs):
+        if inputs.get("item_code") is None:
+            return []
+        lists = [(as_index(inputs["user_code"], "user_code"), self.n_users),
+                 (as_index(inputs["item_code"], "item_code"), self.n_items)]
+        e = self._extras(inputs)
+        if e["occs"] is not None:
+            lists.append((e["occs"], e["O"].shape[0]))
+        if e["temps"] is not None:
+            lists.append((e["temps"], e["T"].shape[0]))
+        return lists
+
     def forward(self, inputs):
         users = as_index(inputs["user_code"], "user_code")
         items = inputs["item_code"]

@@ -53,6 +53,12 @@ class GMF(HotPathModule):
         nn.init.xavier_uniform_(self.linear.weight)
         _zero_linear_biases(self)
 
+    def _index_lists(self, inputs):
+        if inputs.get("item_code") is None:
+            return []
+        return [(as_index(inputs["user_code"], "user_code"), self.n_users),
+                (as_index(inputs["item_code"], "item_code"), self.n_items)]
+
     def forward(self, inputs, pointwise=False):
         users = as_index(inputs["user_code"], "user_code")
         items = inputs["item_code"]
@@ -85,6 +91,12 @@ class MLP(HotPathModule):
             if isinstance(layer, nn.Linear):
                 nn.init.xavier_uniform_(layer.weight)
         _zero_linear_biases(self)
+
+    def _index_lists(self, inputs):
+        if inputs.get("item_code") is None:
+            return []
+        return [(as_index(inputs["user_code"], "user_code"), self.n_users),
+                (as_index(inputs["item_code"], "item_code"), self.n_items)]
 
     def forward(self, inputs, pointwise=False):
         users = as_index(inputs["user_code"], "user_code")
@@ -125,6 +137,12 @@ class NeuMF(HotPathModule):
         nn.init.xavier_uniform_(self.linear_gmf.weight)
         nn.init.xavier_uniform_(self.linear_final.weight)
         _zero_linear_biases(self)
+
+    def _index_lists(self, inputs):
+        if inputs.get("item_code") is None:
+            return []
+        return [(as_index(inputs["user_code"], "user_code"), self.n_users),
+                (as_index(inputs["item_code"], "item_code"), self.n_items)]
 
     def forward(self, inputs, pointwise=False):
         users = as_index(inputs["user_code"], "user_code")
