@@ -393,12 +393,16 @@ int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t
  *   counts [G] int64        number of indices owned by each rank
  *   send_local [n] int64    local row ids (r / G) grouped by owner, original order kept
  *   perm [n] int32          perm[j] = position in the input of the j-th sent index
+ * d_n_valid (may be NULL): device count of the leading entries of d_idx that are real (the distinct
+ * rows of rx_sort_dedup, whose count never visits the host); the rest is padding that is counted for
+ * no rank and sorts behind every sent index.
  * rx_unpermute_rows scatters received rows back: out[perm[j], :] = rows[j, :];
  * rx_permute_rows gathers gradient rows into send order: out[j, :] = rows[perm[j], :]. */
 size_t rx_bucketize_workspace_bytes(int64_t n, int32_t G);
-int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G, int64_t n_rows_global,
-                          int64_t* d_counts, int64_t* d_send_local, int32_t* d_perm, void* ws,
-                          size_t ws_bytes, int32_t* err_flag, int device, void* stream);
+int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, const int32_t* d_n_valid, int32_t G,
+                          int64_t n_rows_global, int64_t* d_counts, int64_t* d_send_local,
+                          int32_t* d_perm, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
+                          void* stream);
 int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
                       float* d_out, int device, void* stream);
 int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,

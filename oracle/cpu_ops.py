@@ -37,13 +37,17 @@ class SortedIndex:
     inverse: Optional[torch.Tensor] = None
 
 
-def bucketize_by_owner(idx, world, n_rows_global):
+def bucketize_by_owner(idx, world, n_rows_global, n_valid=None):
     flat = idx.reshape(-1)
-    if ((flat < 0) | (flat >= n_rows_global)).any():
+    n = flat.numel()
+    m = int(n_valid) if n_valid is not None else n
+    real = flat[:m]
+    if ((real < 0) | (real >= n_rows_global)).any():
         raise IndexError("index out of range")
-    owner = flat % world
+    owner = torch.cat([real % world, torch.full((n - m,), world, dtype=flat.dtype)])   # padding: spare bin, last
     perm = torch.sort(owner, stable=True)[1]
-    return torch.bincount(owner, minlength=world), (flat // world)[perm], perm.to(torch.int32)
+    local = torch.cat([real // world, torch.zeros(n - m, dtype=flat.dtype)])
+    return torch.bincount(owner[:m], minlength=world)[:world], local[perm], perm.to(torch.int32)
 
 
 def gather_concat(segs, out_rows, out_cols, out=None):
@@ -115,13 +119,37 @@ def segreduce(occ, si, mode, target, *, state=None, lr=0.0, eps=0.0, scale=None,
 
 
 def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base, want_deep=False, second_order=True, deep_cols=None,
-            want_logits=True, extra=None):
+            want_logits=True, extra=None, want_tsum=False):
     ex = feat[ex_idx + ex_base[None, :]]
     item = feat[item_idx + item_base]
     b = bias[ex_idx + ex_base[None, :]].sum(1, keepdim=True) + bias[item_idx + item_base]
     s = ex.sum(1, keepdim=True) + item
     q = (ex * ex).sum(1, keepdim=True) + item * item
-    return b + 0.5 * (s * s - q).sum(-1), None
+    logits = b + 0.5 * (s * s - q).sum(-1)
+    return (logits, None, s[:, 0, :].contiguous()) if want_tsum else (logits, None)
+
+
+def segreduce_fm(tsum, g, n_fields_ex, si, mode, target, *, table=None, state=None, target2=None, state2=None,
+                 lr=0.0, eps=0.0, scale=None, want_sq=False, sq_out=None):
+    """G_r = sum_b g_b T_b - (sum_b g_b) e_r over the occurrences of row r; bias gradient sum_b g_b."""
+    B = tsum.shape[0]
+    split = B * n_fields_ex
+    pos = si.sorted_pos.long()
+    sample = torch.where(pos < split, pos // n_fields_ex, pos - split)
+    nu = int(si.n_uniq)
+    slot = si.sorted_slot.long()
+    g = g.reshape(-1)
+    gs = torch.zeros(nu).index_add_(0, slot, g[sample])
+    G = torch.zeros(nu, tsum.shape[1]).index_add_(0, slot, g[sample][:, None] * tsum[sample])
+    rows = si.uniq_rows[:nu]
+    src = table if table is not None else target
+    G = G - gs[:, None] * src[rows]
+    if mode != _lib.RX_SEG_COMPACT:
+        raise NotImplementedError("the CPU stand-in covers the compact mode the sharded path uses")
+    target[:nu] = G
+    if target2 is not None:
+        target2.reshape(-1)[:nu] = gs
+    return None
 
 
 def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base, second_order=True):

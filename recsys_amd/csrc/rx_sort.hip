@@ -479,10 +479,15 @@ extern "C" int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, in
 // Row r lives on rank r % G.  A single stable radix pass keyed by the owner groups a rank's
 // indices by destination while keeping their original order inside each group.
 __global__ void __launch_bounds__(RX_BLOCK)
-owner_init_kernel(const int64_t* __restrict__ idx, int64_t n, int G, int64_t n_rows_global,
-                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* err_flag) {
+owner_init_kernel(const int64_t* __restrict__ idx, int64_t n, const int32_t* __restrict__ n_valid, int G,
+                  int64_t n_rows_global, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* err_flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (n_valid && i >= n_valid[0]) {  // padding of a list whose length lives on the device: spare bin, sent nowhere
+    keys[i] = (uint32_t)G;
+    vals[i] = (uint32_t)i;
+    return;
+  }
   int64_t r = idx[i];
   if (r < 0 || r >= n_rows_global) {
     if (err_flag) atomicOr(err_flag, RX_ERR_INDEX);
@@ -519,9 +524,10 @@ extern "C" size_t rx_bucketize_workspace_bytes(int64_t n, int32_t G) {
   return rx_sort_dedup_workspace_bytes(n);
 }
 
-extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G, int64_t n_rows_global,
-                                     int64_t* d_counts, int64_t* d_send_local, int32_t* d_perm, void* ws,
-                                     size_t ws_bytes, int32_t* err_flag, int device, void* stream) {
+extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, const int32_t* d_n_valid, int32_t G,
+                                     int64_t n_rows_global, int64_t* d_counts, int64_t* d_send_local,
+                                     int32_t* d_perm, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
+                                     void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(G >= 1 && G < SORT_MAX_BINS, "rx_bucketize_by_owner: G=%d outside 1..%d", G, SORT_MAX_BINS - 1);
   RX_REQUIRE(n >= 0 && n < (1ll << 31) && n_rows_global >= 1, "rx_bucketize_by_owner: bad sizes");
@@ -537,7 +543,7 @@ extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, int32_t G,
   const int nb = (int)rx_cdiv(n, SORT_TILE);
   int bits = 1;
   while ((1 << bits) < G + 1) ++bits;  // one spare bin so that bin G marks the end of bin G-1
-  hipLaunchKernelGGL(owner_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, G, n_rows_global, w.ka, w.va, err_flag);
+  hipLaunchKernelGGL(owner_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, d_n_valid, G, n_rows_global, w.ka, w.va, err_flag);
   RX_LAUNCH_CHECK();
   if (sort_pass(w, nullptr, n_rows_global, err_flag, w.ka, w.va, w.kb, w.vb, n, 0, bits, false, st)) return 1;
   const int64_t work = n > G ? n : G;

@@ -747,7 +747,8 @@ def cross_combine_bwd(dxn, x0, u, dx0_acc):
 
 
 # ------------------------------------------------------------------ exchange helpers / eval
-def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int):
+def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int, n_valid: Optional[Tensor] = None):
+    """``n_valid``: device int32 count of the leading entries that are real (the rest is padding)."""
     _idx(idx, "indices")
     flat = idx.reshape(-1)
     n, dev = flat.numel(), idx.device
@@ -755,7 +756,7 @@ def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int):
     send_local = torch.empty(n, dtype=torch.int64, device=dev)
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     ws = _ws(int(lib.rx_bucketize_workspace_bytes(n, world)), dev)
-    check(lib.rx_bucketize_by_owner(_p(flat), n, world, n_rows_global, _p(counts), _p(send_local), _p(perm),
+    check(lib.rx_bucketize_by_owner(_p(flat), n, _p(n_valid), world, n_rows_global, _p(counts), _p(send_local), _p(perm),
                                     _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)),
           "rx_bucketize_by_owner")
     return counts, send_local, perm

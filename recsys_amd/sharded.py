@@ -61,17 +61,21 @@ class ShardedTable:
         self.rule = (mode, lr, eps, state)
 
     # ---- exchange plan for one index list -------------------------------------------------
-    def plan(self, idx: torch.Tensor):
-        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows)
+    def plan(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor] = None):
+        """``n_valid``: device count of the leading entries of ``idx`` that are real (a padded list of
+        distinct rows); the one host read below then also yields that count."""
+        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
         if self.G == 1:
-            return dict(send=[idx.numel()], recv=[idx.numel()], recv_idx=send_local, perm=perm, n=idx.numel())
+            m = idx.numel() if n_valid is None else int(counts.sum().item())
+            return dict(send=[m], recv=[m], recv_idx=send_local[:m], perm=perm[:m], n=m)
         recv_counts = torch.empty_like(counts)
         dist.all_to_all_single(recv_counts, counts, group=self.group)
-        send = counts.tolist()          # one host sync per lookup: split sizes must be host integers
-        recv = recv_counts.tolist()
+        both = torch.stack([counts, recv_counts]).tolist()   # the one host sync per lookup: split sizes must be host integers
+        send, recv = both[0], both[1]
+        m = sum(send)
         recv_idx = torch.empty(sum(recv), dtype=torch.int64, device=idx.device)
-        dist.all_to_all_single(recv_idx, send_local, recv, send, group=self.group)
-        return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm, n=idx.numel())
+        dist.all_to_all_single(recv_idx, send_local[:m].contiguous(), recv, send, group=self.group)
+        return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm[:m], n=m)
 
     def _to_owners(self, rows_in_send_order: torch.Tensor, plan) -> torch.Tensor:
         if self.G == 1:
@@ -170,8 +174,9 @@ def sharded_lookup_pair(table: ShardedTable, companion: ShardedTable, idx: torch
 
 class ShardedFieldFM(torch.nn.Module):
     """26-field FM (see models.fields.FieldFM) over row-sharded feature and bias tables.  Each rank
-    feeds its own slice of the global batch; the FM interaction runs on the rows it received, with
-    the same rx_fm2 kernels (the received rows act as a batch-local table addressed by position)."""
+    feeds its own slice of the global batch; the FM interaction runs on the distinct rows it
+    received, with the same rx_fm2 / rx_segreduce_fm kernels (the received rows act as a
+    batch-local table addressed through the batch's inverse map)."""
 
     def __init__(self, field_dims, embedding_dim, device, group=None, backend=None, full_state=None):
         super().__init__()
@@ -194,14 +199,18 @@ class ShardedFieldFM(torch.nn.Module):
         self.feature.set_rule(kind, lr, eps)
         self.bias.set_rule(kind, lr, eps)
 
-    def _positions(self, B, device):
-        key = (B, str(device))
+    def _zero_base(self, F, device):
+        key = ("base", F, str(device))
         if key not in self._pos:
-            F = self.n_fields - 1
-            ex = torch.arange(B * F, device=device, dtype=torch.int64).reshape(B, F)
-            item = torch.arange(B * F, B * F + B, device=device, dtype=torch.int64).reshape(B, 1)
-            self._pos[key] = (ex, torch.zeros(F, dtype=torch.int64, device=device), item)
+            self._pos[key] = torch.zeros(F, dtype=torch.int64, device=device)
         return self._pos[key]
+
+    def _iota(self, n, device):
+        key = ("iota", str(device))
+        t = self._pos.get(key)
+        if t is None or t.numel() < n:
+            t = self._pos[key] = torch.arange(n, dtype=torch.int64, device=device)
+        return t[:n]
 
     def forward(self, inputs):
         sparse = inputs["sparse"]
@@ -209,9 +218,7 @@ class ShardedFieldFM(torch.nn.Module):
         glob = sparse + self._offsets[None, :]
         # occurrence order of the FM kernels: all (b, f < F) first, then the last field's B entries
         flat = torch.cat([glob[:, :F].reshape(-1), glob[:, F]]).contiguous()
-        rows, bias = sharded_lookup_pair(self.feature, self.bias, flat, self._anchor)   # [B*(F+1), D], [B*(F+1), 1]
-        ex, base, item = self._positions(B, sparse.device)
-        return _LocalFM.apply(rows, bias, ex, base, item, self.ops)
+        return _ShardedFM.apply(self._anchor, self, flat, B, F)
 
     def loss(self, inputs):
         if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
@@ -220,19 +227,48 @@ class ShardedFieldFM(torch.nn.Module):
         return bce_with_logits(self(inputs), inputs["label"])
 
 
-class _LocalFM(torch.autograd.Function):
-    """FM over a batch-local row buffer (rows received from their owners)."""
+class _ShardedFM(torch.autograd.Function):
+    """The 26-field FM over row-sharded tables, with the batch's rows deduplicated before they
+    cross the fabric:
+
+      forward   sort + dedup the batch's occurrence list locally; ask the owners for the *distinct*
+                rows only (feature + bias, one plan); run rx_fm2_fwd on the received buffer, addressed
+                through the inverse map; keep T_b = sum of the sample's rows
+      backward  rx_segreduce_fm turns (T, dL/dlogit) into one gradient row per distinct row, with
+                no per-occurrence rows; those compact rows (and the bias gradients) go back to the
+                owners, which sort what arrived from all ranks and reduce + update.
+
+    Per step a rank sends ~rho * n indices and receives / returns ~rho * n rows instead of n."""
 
     @staticmethod
-    def forward(ctx, rows, bias, ex, base, item, ops):
-        logits, _ = ops.fm2_fwd(rows, bias.reshape(-1), ex, base, item, 0)
-        ctx.save_for_backward(rows, bias)
-        ctx.idx, ctx.ops = (ex, base, item), ops
+    def forward(ctx, anchor, model, flat, B, F):
+        ops, feat, bias = model.ops, model.feature, model.bias
+        n = flat.numel()
+        si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
+        plan = feat.plan(si.uniq_rows, si.n_uniq)        # padded list + device count; one host read inside
+        nu = plan["n"]
+        rows_u = feat.gather(plan)                        # [nu, D], in distinct-row order
+        bias_u = bias.gather(plan)                        # [nu, 1]
+        inv = si.inverse.to(torch.int64)
+        ex = inv[:B * F].reshape(B, F)
+        item = inv[B * F:].reshape(B, 1)
+        base = model._zero_base(F, flat.device)
+        logits, _, tsum = ops.fm2_fwd(rows_u, bias_u.reshape(-1), ex, base, item, 0, want_tsum=True)
+        ctx.model, ctx.plan, ctx.si, ctx.nu, ctx.F = model, plan, si, nu, F
+        ctx.save_for_backward(tsum, rows_u)
         return logits
 
     @staticmethod
     def backward(ctx, g):
-        rows, bias = ctx.saved_tensors
-        ex, base, item = ctx.idx
-        occ, bias_occ = ctx.ops.fm2_bwd(g.contiguous(), None, rows, bias.reshape(-1), ex, base, item, 0)
-        return occ, bias_occ.reshape(-1, 1), None, None, None, None
+        tsum, rows_u = ctx.saved_tensors
+        model, si, nu = ctx.model, ctx.si, ctx.nu
+        ops, feat, bias = model.ops, model.feature, model.bias
+        # the received buffer is addressed by slot, so the reduce sees "row u = slot u"
+        slots = ops.SortedIndex(si.n, max(nu, 1), si.sorted_pos, si.sorted_slot, model._iota(si.n, g.device), si.seg_off,
+                                si.n_uniq, None)
+        compact = torch.empty(max(nu, 1), feat.dim, dtype=torch.float32, device=g.device)
+        compact2 = torch.empty(max(nu, 1), dtype=torch.float32, device=g.device)
+        ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, slots, _lib.RX_SEG_COMPACT, compact, table=rows_u,
+                         target2=compact2)
+        feat.scatter_grad(compact[:nu], ctx.plan, bias, compact2[:nu])
+        return None, None, None, None, None
