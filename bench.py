@@ -387,7 +387,6 @@ def main():
         args.workload = "fm_criteo_sharded"
     if args.workload == "fm_criteo_sharded":
         use_graph = False
-        dominant = "fm2_bwd"  # the sharded step exchanges per-occurrence gradient rows, so it keeps the unfused backward
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
     if use_graph:
         # the dominant kernel is timed with HIP events on the launch stream after a short eager pass of

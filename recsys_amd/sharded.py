@@ -48,6 +48,8 @@ class ShardedTable:
         else:
             g = torch.Generator(device=self.device).manual_seed(seed * 1000 + self.rank)
             self.weight = torch.randn(self.local_rows, dim, device=self.device, generator=g) * init_std
+        # run the collectives even with one rank (exercises the RCCL calls on a one-GPU machine)
+        self.force_exchange = False
         self.grad: Optional[torch.Tensor] = None      # dense local gradient (when no rule is set)
         self.rule = None                               # (mode, lr, eps, state) for the fused row update
 
@@ -65,7 +67,7 @@ class ShardedTable:
         """``n_valid``: device count of the leading entries of ``idx`` that are real (a padded list of
         distinct rows); the one host read below then also yields that count."""
         counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
-        if self.G == 1:
+        if self.G == 1 and not self.force_exchange:
             m = idx.numel() if n_valid is None else int(counts.sum().item())
             return dict(send=[m], recv=[m], recv_idx=send_local[:m], perm=perm[:m], n=m)
         recv_counts = torch.empty_like(counts)
@@ -78,7 +80,7 @@ class ShardedTable:
         return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm[:m], n=m)
 
     def _to_owners(self, rows_in_send_order: torch.Tensor, plan) -> torch.Tensor:
-        if self.G == 1:
+        if self.G == 1 and not self.force_exchange:
             return rows_in_send_order
         out = torch.empty((sum(plan["recv"]),) + tuple(rows_in_send_order.shape[1:]), dtype=rows_in_send_order.dtype,
                           device=rows_in_send_order.device)
@@ -86,7 +88,7 @@ class ShardedTable:
         return out
 
     def _from_owners(self, rows_at_owner: torch.Tensor, plan) -> torch.Tensor:
-        if self.G == 1:
+        if self.G == 1 and not self.force_exchange:
             return rows_at_owner
         out = torch.empty((plan["n"],) + tuple(rows_at_owner.shape[1:]), dtype=rows_at_owner.dtype,
                           device=rows_at_owner.device)
