@@ -306,7 +306,7 @@ gemm_bf16_kernel(GemmArgs g) {
 
 // ---------------------------------------------------------------- bf16 operands, pipelined
 // The kernel the aligned shapes take (16-byte aligned operands, leading dimensions and
-// contiguous extents that are multiples of 4, K-contiguous reduction lengths multiples of 8).
+// contiguous extents and reduction lengths that are multiples of 4).
 //   * 128x128 tile, 2x2 waves, each wave 2x2 MFMA tiles of v_mfma_f32_32x32x16_bf16
 //   * the next K-step's global loads are issued before the current step's MFMAs and land in
 //     registers; they are rounded to bf16 (v_cvt_pk_bf16_f32) and written to the other LDS buffer
@@ -342,11 +342,13 @@ __device__ __forceinline__ void g2_load_kc(const float* __restrict__ P, int64_t 
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int64_t row = r0 + (tid >> 2) + 64 * p;
-    const bool ok = row < r_lim && k < k_end;
+    // k_end is a multiple of 4 on this path: each 16-byte half is either whole or absent
+    const bool ok = row < r_lim && k < k_end, ok2 = row < r_lim && k + 4 < k_end;
     const float* src = P + (ok ? row : 0) * rs + (ok ? k : 0);
     float4 a = *reinterpret_cast<const float4*>(src);
-    float4 b = *reinterpret_cast<const float4*>(src + 4);
-    if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+    float4 b = *reinterpret_cast<const float4*>(src + (ok2 ? 4 : 0));
+    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok2) b = make_float4(0.f, 0.f, 0.f, 0.f);
     t.v[2 * p] = a;
     t.v[2 * p + 1] = b;
   }
@@ -718,9 +720,9 @@ colsum_slab_kernel(const float* __restrict__ dY, int64_t ldd, int64_t M, int N, 
 template <bool A_KC, bool B_KC>
 static bool pipe_ok(const GemmArgs& g) {
   if (!g.a_vec || !g.b_vec) return false;
-  // K-contiguous operands are read 8 k at a time (every slab starts at a multiple of 32);
-  // M/N-contiguous ones 4 elements at a time along M/N
-  if ((A_KC || B_KC) && (g.K % 8 != 0)) return false;
+  // K-contiguous operands are read as two 16-byte halves of 8 k (every slab starts at a multiple
+  // of 32); M/N-contiguous ones 4 elements at a time along M/N
+  if ((A_KC || B_KC) && (g.K % 4 != 0)) return false;
   if (!A_KC && (g.M % 4 != 0)) return false;
   if (!B_KC && (g.N % 4 != 0)) return false;
   if (g.k_per_slab % G2_BK != 0 && g.k_per_slab < g.K) return false;

@@ -356,7 +356,8 @@ def test_linear_bf16_within_1e2(ops, M, N, K):
     assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=1e-2, what="bf16 bwd w")
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 200, 136), (260, 132, 40), (4096, 1024, 432), (8192, 96, 72), (128, 128, 32)])
+@pytest.mark.parametrize("M,N,K", [(1000, 200, 136), (260, 132, 40), (4096, 1024, 432), (8192, 96, 72), (128, 128, 32),
+                                   (2048, 216, 108), (1028, 108, 216)])
 def test_linear_bf16_exact_on_rounded_operands(ops, M, N, K):
     """With operands that are already bf16 values the bf16-operand kernels (pipelined path:
     N > 64, aligned shapes) must match an fp32-accumulating reference to rounding: catches any
