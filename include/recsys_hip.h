@@ -256,9 +256,16 @@ int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
  * sort must be the rx_fm2_flat_indices order: n_samples*F entries (b, f) then n_samples item
  * entries.  d_table: the feature table (needed to read e_r when `mode` writes a gradient
  * buffer; ignored for the optimizer modes, which read d_target).  d_target2 / d_state2: the
- * bias table (or its dense / compact gradient) and its Adagrad state, or NULL. */
-int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, int64_t n_samples, int32_t F,
-                    int32_t dim, const int32_t* d_sorted_pos, const int32_t* d_sorted_slot,
+ * bias table (or its dense / compact gradient) and its Adagrad state, or NULL.
+ * d_deep (may be NULL) [n_samples, deep_ld]: gradient of the tower input that rx_fm2_fwd laid out
+ * as [item row, field 0 .. F-1 rows, extra columns] (DeepFM / DCN-v2: the same gathered rows feed
+ * the tower, deep_factorization_machine.py:94-103); occurrence (b, f) then also receives
+ * d_deep[b, (1+f)*dim ...] and the item d_deep[b, 0 ...], so G_r gains the sum of those slices and
+ * no per-occurrence gradient rows are written for the tower path either.  A model with a tower but
+ * no FM term passes g = 0. */
+int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, const float* d_deep,
+                    int64_t deep_ld, int64_t n_samples, int32_t F, int32_t dim,
+                    const int32_t* d_sorted_pos, const int32_t* d_sorted_slot,
                     const int64_t* d_uniq_rows, const int32_t* d_seg_off, const int32_t* d_n_uniq,
                     int mode, float* d_target, float* d_state, const float* d_table, float* d_target2,
                     float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,

@@ -173,15 +173,16 @@ class Presort:
         return self.si
 
 
-def table_backward_fm(feat, bias_table, si: SortedIndex, tsum, g, n_fields_ex: int):
-    """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm)."""
+def table_backward_fm(feat, bias_table, si: SortedIndex, tsum, g, n_fields_ex: int, deep=None):
+    """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm); ``deep``: gradient of the
+    tower input, whose per-field slices join the rows' gradients in the same walk."""
     rule = getattr(feat, "_rx_sparse", None)
     if rule is not None:
-        rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex)
+        rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex, deep)
         return None, None
     grad = torch.zeros_like(feat)
     grad2 = torch.zeros_like(bias_table) if bias_table is not None else None
-    ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2)
+    ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep)
     return grad, grad2
 
 
@@ -196,8 +197,10 @@ class FM2(Function):
                 deep_cols=None, want_logits=True, extra=None, presort=None):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         n_items = item_idx.shape[1] if item_idx.dim() == 2 else 1
-        # with one item per sample and no tower the backward needs only T_b = sum of the sample's rows
-        fused = n_items == 1 and second_order and want_logits and not want_deep
+        # with one item per sample the backward needs only T_b = sum of the sample's rows (plus the
+        # tower-input gradient when there is a tower): no per-occurrence gradient rows
+        # (a tower-only model, e.g. DCN-v2, has no FM term: its rows receive the tower gradient alone)
+        fused = n_items == 1 and ((second_order and (want_logits or want_deep)) or (want_deep and not want_logits))
         out = ops.fm2_fwd(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, want_deep, second_order, deep_cols,
                           want_logits, extra, want_tsum=fused)
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
@@ -216,10 +219,11 @@ class FM2(Function):
         if g_deep is not None and g_deep.stride(-1) != 1:
             g_deep = g_deep.contiguous()
         none_tail = (None,) * 6
-        if ctx.tsum is not None and g_deep is None and g is not None:
+        if ctx.tsum is not None and (g is not None or g_deep is not None):
             s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
                 ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])
-            gfeat, gbias = table_backward_fm(feat, bias_table, s, ctx.tsum, g.reshape(-1), ex_idx.shape[1])
+            gl = g.reshape(-1) if g is not None else torch.zeros(ctx.tsum.shape[0], dtype=torch.float32, device=feat.device)
+            gfeat, gbias = table_backward_fm(feat, bias_table, s, ctx.tsum, gl, ex_idx.shape[1], g_deep)
             return (None, None, None, None, gfeat, gbias) + none_tail
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         occ, bias_occ = ops.fm2_bwd(g, g_deep, feat, bias_flat, ex_idx, ex_base, item_idx, item_base,

@@ -44,6 +44,10 @@ struct SegArgs {
   const float* fm_table;  // table to read the old row from when `target` is a gradient buffer
   int64_t fm_split;
   int fm_div;
+  // optional tower-input gradient [samples, fm_deep_ld] laid out [item row, field 0 .. F-1 rows, ...]:
+  // the occurrence of field f additionally receives fm_deep[b, (1 + f) * dim ...], the item's [b, 0 ...]
+  const float* fm_deep;
+  int64_t fm_deep_ld;
   // cross-piece workspace
   float* partials;    // [pieces][2][dim]
   float* partials2;   // [pieces][2]
@@ -202,9 +206,8 @@ __device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* 
   if (threadIdx.x == 0) sq_part[blockIdx.x] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
 }
 
-template <int VEC, int CH, int MODE, bool FM>
-__global__ void __launch_bounds__(RX_BLOCK)
-segreduce_chunk_kernel(SegArgs a) {
+template <int VEC, int CH, int MODE, bool FM, bool DEEP>
+__device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a) {
   // LDS tile of the block's sorted positions, staged by one coalesced sweep.  Each piece owns
   // PS = SEG_CHUNK + 1 consecutive entries: (slot, position) of its positions (slot -1 past the end
   // of the list) and, in the extra entry, the slot of its right neighbour.  The odd stride puts
@@ -220,6 +223,7 @@ segreduce_chunk_kernel(SegArgs a) {
   const int T = gpb * SEG_CHUNK;
   int2* tile = meta + 2;
   uint32_t* rowid = reinterpret_cast<uint32_t*>(tile + gpb * PS);
+  uint32_t* deepoff = rowid + gpb * PS;   // DEEP only: element offset of the occurrence's slice of fm_deep
   const int64_t piece0 = (int64_t)blockIdx.x * gpb;
   {
     // Eight entries per thread and round: all index loads of a round are issued before the
@@ -246,7 +250,13 @@ segreduce_chunk_kernel(SegArgs a) {
         const int j = j0 + r * RX_BLOCK + threadIdx.x;
         if (j < T + 2) {
           int pos = ps[r];
-          if (FM) pos = pos < a.fm_split ? pos / a.fm_div : pos - (int)a.fm_split;  // sample of the occurrence
+          uint32_t doff = 0;
+          if (FM) {
+            const bool ex = pos < a.fm_split;
+            const int b = ex ? pos / a.fm_div : pos - (int)a.fm_split;  // sample of the occurrence
+            if (DEEP) doff = (uint32_t)((int64_t)b * a.fm_deep_ld + (ex ? (1 + pos - b * a.fm_div) * a.dim : 0));
+            pos = b;
+          }
           const int2 e = make_int2(sl[r], sl[r] >= 0 ? pos : 0);
           const int t = j - 1;
           if (t < 0) {
@@ -256,6 +266,7 @@ segreduce_chunk_kernel(SegArgs a) {
             if (t < T) {
               tile[pc * PS + off] = e;
               rowid[pc * PS + off] = sl[r] >= 0 ? rw[r] : 0u;
+              if (DEEP) deepoff[pc * PS + off] = sl[r] >= 0 ? doff : 0u;
             }
             if (off == 0 && t > 0) tile[(pc - 1) * PS + SEG_CHUNK] = e;
           }
@@ -276,6 +287,7 @@ segreduce_chunk_kernel(SegArgs a) {
     const float scale = a.scale ? a.scale[0] : 1.f;
     const int2* mine = tile + my * PS;  // mine[-2] (the previous piece's last entry) and mine[SEG_CHUNK] are the neighbours
     const uint32_t* myrow = rowid + my * PS;
+    const uint32_t* mydeep = deepoff + my * PS;
     const int left = mine[-2].x, right = mine[SEG_CHUNK].x;
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
@@ -304,7 +316,7 @@ segreduce_chunk_kernel(SegArgs a) {
     struct Batch {
       int sl[BATCH + 1];
       uint32_t rid[BATCH];
-      Acc<VEC, CH> rows[BATCH], oldx[BATCH], oldst[BATCH];
+      Acc<VEC, CH> rows[BATCH], oldx[BATCH], oldst[BATCH], deep[DEEP ? BATCH : 1];
       float s2[BATCH], old2[BATCH];
     };
     auto load_batch = [&](int b0, Batch& t) {
@@ -316,6 +328,11 @@ segreduce_chunk_kernel(SegArgs a) {
 #pragma unroll
         for (int k = 0; k < CH; ++k) t.rows[j].p[k] = rx_load<VEC>(src + col[k]);
         t.s2[j] = keep2 ? src2[m.y] : 0.f;
+        if constexpr (DEEP) {
+          const float* dsrc = a.fm_deep + mydeep[b0 + j];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) t.deep[j].p[k] = rx_load<VEC>(dsrc + col[k]);
+        }
         // the row's current value (and state) ride along, so that the end of a run has them at hand
         const uint32_t r = myrow[b0 + j];
         t.rid[j] = r;
@@ -335,6 +352,7 @@ segreduce_chunk_kernel(SegArgs a) {
         if constexpr (OLD2) asm volatile("" ::"v"(t.old2[j]));
         ACC_FOREACH(k, i) {
           asm volatile("" ::"v"(t.rows[j].p[k].v[i]));
+          if constexpr (DEEP) asm volatile("" ::"v"(t.deep[j].p[k].v[i]));
           if constexpr (FM || MODE >= RX_SEG_SGD) asm volatile("" ::"v"(t.oldx[j].p[k].v[i]));
           if constexpr (MODE == RX_SEG_ADAGRAD) asm volatile("" ::"v"(t.oldst[j].p[k].v[i]));
         }
@@ -346,6 +364,7 @@ segreduce_chunk_kernel(SegArgs a) {
           if (col_ok[k]) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
+              if constexpr (DEEP) g.p[k].v[i] += t.deep[j].p[k].v[i];
               if constexpr (FM) g.p[k].v[i] += t.s2[j] * t.rows[j].p[k].v[i];
               else g.p[k].v[i] += t.rows[j].p[k].v[i];
             }
@@ -427,6 +446,19 @@ segreduce_chunk_kernel(SegArgs a) {
     if (lg == 0) a.tail_row[piece] = tail;
   }
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_chunk_kernel(SegArgs a) {
+  segreduce_chunk_body<VEC, CH, MODE, FM, false>(a);
+}
+
+// FM synthesis plus the tower-input gradient slice of every occurrence (FM is implied)
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_chunk_deep_kernel(SegArgs a) {
+  segreduce_chunk_body<VEC, CH, MODE, true, true>(a);
 }
 
 template <int VEC, int CH, int MODE, bool FM>
@@ -584,8 +616,10 @@ static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t w
   a.group = sh.group;
   const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n, dim);
   const size_t tile = (size_t)(RX_BLOCK / sh.group) * (SEG_CHUNK + 1);
-  const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
-  SEG_DISPATCH(a.mode, fm, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
+  const bool deep = fm && a.fm_deep != nullptr;
+  const size_t lds = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t) * (deep ? 2 : 1);
+  if (deep) SEG_DISPATCH_F(a.mode, true, sh, segreduce_chunk_deep_kernel, dim3(g1), lds, st, a);
+  else SEG_DISPATCH(a.mode, fm, sh, segreduce_chunk_kernel, dim3(g1), lds, st, a);
   RX_LAUNCH_CHECK();
   if (a.sq_part) a.sq_part = a.sq_part + g1;
   SEG_DISPATCH(a.mode, fm, sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
@@ -610,8 +644,9 @@ extern "C" int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32
   return segreduce_run(a, false, "rx_segreduce", ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, int64_t n_samples,
-                               int32_t F, int32_t dim, const int32_t* d_sorted_pos,
+extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, const float* d_deep,
+                               int64_t deep_ld, int64_t n_samples, int32_t F, int32_t dim,
+                               const int32_t* d_sorted_pos,
                                const int32_t* d_sorted_slot, const int64_t* d_uniq_rows,
                                const int32_t* d_seg_off, const int32_t* d_n_uniq, int mode,
                                float* d_target, float* d_state, const float* d_table, float* d_target2,
@@ -630,6 +665,11 @@ extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g,
   a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale; a.sq_part = d_sq_part;
   a.occ2 = nullptr; a.target2 = d_target2; a.state2 = d_state2;
   a.fm_g = d_g; a.fm_table = d_table; a.fm_split = n_samples * (int64_t)F; a.fm_div = F;
+  if (d_deep) {
+    RX_REQUIRE(deep_ld >= (int64_t)(F + 1) * dim && n_samples * deep_ld < (1ll << 32), "rx_segreduce_fm: bad tower-gradient stride");
+    RX_REQUIRE(dim % 4 != 0 || (deep_ld % 4 == 0 && rx_aligned16(d_deep)), "rx_segreduce_fm: tower gradient must be 16-byte aligned with a row stride that is a multiple of 4");
+    a.fm_deep = d_deep; a.fm_deep_ld = deep_ld;
+  }
   return segreduce_run(a, true, "rx_segreduce_fm", ws, ws_bytes, (hipStream_t)stream);
 }
 

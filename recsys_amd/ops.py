@@ -487,15 +487,22 @@ def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mod
                  table: Optional[Tensor] = None, state: Optional[Tensor] = None, target2: Optional[Tensor] = None,
                  state2: Optional[Tensor] = None, lr: float = 0.0, eps: float = 0.0,
                  scale: Optional[Tensor] = None, want_sq: bool = False,
-                 sq_out: Optional[Tensor] = None) -> Optional[Tensor]:
-    """rx_segreduce_fm: N == 1 FM backward straight from T [B, D] and g [B] (no per-occurrence rows)."""
+                 sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None) -> Optional[Tensor]:
+    """rx_segreduce_fm: N == 1 FM backward straight from T [B, D] and g [B] (no per-occurrence rows).
+    ``deep`` [B, >= (1+F)*D]: gradient of the tower input laid out by fm2_fwd; its per-field slices
+    are added to the rows' gradients in the same walk."""
     _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
     B, dim = tsum.shape
+    deep_ld = 0
+    if deep is not None:
+        deep, deep_ld = _mat(deep, "deep")
+        if deep.shape[0] != B or deep.shape[1] < (n_fields_ex + 1) * dim:
+            raise ValueError("deep: expected [B, >= (1+F)*dim]")
     if g.numel() != B or si.n != B * (n_fields_ex + 1):
         raise ValueError("segreduce_fm: shapes disagree with the sorted occurrence list")
     sq = _sq_buffer(si.n, dim, tsum.device, sq_out) if want_sq else None
     ws = _ws(int(lib.rx_segreduce_workspace_bytes(si.n, dim)), tsum.device)
-    check(lib.rx_segreduce_fm(_p(tsum), tsum.stride(0), _p(g), B, n_fields_ex, dim, _p(si.sorted_pos),
+    check(lib.rx_segreduce_fm(_p(tsum), tsum.stride(0), _p(g), _p(deep), deep_ld, B, n_fields_ex, dim, _p(si.sorted_pos),
                               _p(si.sorted_slot), _p(si.uniq_rows), _p(si.seg_off), _p(si.n_uniq), mode, _p(target),
                               _p(state), _p(table), _p(target2), _p(state2), si.n_rows, lr, eps, _p(scale), _p(sq),
                               _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_segreduce_fm")
