@@ -53,6 +53,8 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         B, D = 65536, 16
         model = ShardedFieldFM(dims, D, device)
         model.set_rule("sgd", 0.05)
+        if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
+            model.feature.force_exchange = model.bias.force_exchange = True
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": None,
@@ -331,7 +333,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RX_BENCH_FORCE_DIST") == "1"   # rehearse the multi-rank code path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
@@ -383,7 +386,7 @@ def main():
                 "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
-    if world > 1 and args.workload == "fm_criteo":
+    if (world > 1 or force_dist) and args.workload == "fm_criteo":
         args.workload = "fm_criteo_sharded"
     if args.workload == "fm_criteo_sharded":
         use_graph = False
