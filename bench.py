@@ -56,9 +56,10 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
             model.feature.force_exchange = model.bias.force_exchange = True
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
+        cap = model.calibrate(batches)   # fixed-capacity exchange: equal all-to-all splits, no host read in the step
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": None,
-                "launch": "eager (all-to-all split sizes are read back on the host)"}
+                "launch": f"eager, asynchronous (distinct rows only, {cap} exchange slots per owner)"}
 
         class _Opt:
             def zero_grad(self):

@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define RX_ABI_VERSION 1
-#define RX_ERR_INDEX 1 /* bit set in *err_flag when an index was out of range */
+#define RX_ERR_INDEX 1    /* bit set in *err_flag when an index was out of range */
+#define RX_ERR_CAPACITY 2 /* bit set when a fixed-capacity exchange buffer was too small */
 
 #define RX_MAX_SEGS 8   /* segments per rx_gather_concat call */
 #define RX_MAX_DIM 1024 /* widest embedding row the fused kernels take */
@@ -404,16 +405,28 @@ int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t
  * rows of rx_sort_dedup, whose count never visits the host); the rest is padding that is counted for
  * no rank and sorts behind every sent index.
  * rx_unpermute_rows scatters received rows back: out[perm[j], :] = rows[j, :];
- * rx_permute_rows gathers gradient rows into send order: out[j, :] = rows[perm[j], :]. */
+ * rx_permute_rows gathers gradient rows into send order: out[j, :] = rows[perm[j], :].
+ * d_n_valid (may be NULL) on both: device count of the leading entries of perm that are real. */
 size_t rx_bucketize_workspace_bytes(int64_t n, int32_t G);
 int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, const int32_t* d_n_valid, int32_t G,
                           int64_t n_rows_global, int64_t* d_counts, int64_t* d_send_local,
                           int32_t* d_perm, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
                           void* stream);
-int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
-                      float* d_out, int device, void* stream);
-int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
-                    float* d_out, int device, void* stream);
+int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n,
+                      const int32_t* d_n_valid, int32_t dim, float* d_out, int device, void* stream);
+int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, const int32_t* d_n_valid,
+                    int32_t dim, float* d_out, int device, void* stream);
+/* Fixed-capacity variant of the exchange (no host-side split sizes, so nothing in the step waits
+ * for the host): the owner-grouped list of rx_bucketize_by_owner is packed into G slots of
+ * `capacity` entries, d_packed [G * capacity] (padding slot i of a group names local row
+ * i % pad_rows, pad_rows <= every owner's local height; its gradient slot stays zero, so that row
+ * is left bit-identical), and d_src_of[p] = packed slot of list position p.  A group larger than `capacity` sets
+ * RX_ERR_CAPACITY in *err_flag.  Rows / gradients travel in the same layout and are read /
+ * written in list order with rx_permute_rows / rx_unpermute_rows (perm = d_src_of,
+ * d_n_valid = the list's device-side length). */
+int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const int64_t* d_counts,
+                     int32_t G, int64_t n, int64_t capacity, int64_t pad_rows, int64_t* d_packed,
+                     int32_t* d_src_of, int32_t* err_flag, int device, void* stream);
 
 /* ------------------------------------------------------------------ evaluation
  * Top-k item codes per user from list-wise scores, replacing the host numpy

@@ -59,14 +59,35 @@ def gather_concat(segs, out_rows, out_cols, out=None):
     return out
 
 
-def unpermute_rows(rows, perm):
-    out = torch.empty_like(rows)
-    out[perm.long()] = rows
+def unpermute_rows(rows, perm, n_valid=None, out=None):
+    m = perm.numel() if n_valid is None else int(n_valid)
+    if out is None:
+        out = torch.empty_like(rows)
+    out[perm[:m].long()] = rows[:m]
     return out
 
 
-def permute_rows(rows, perm):
-    return rows[perm.long()]
+def permute_rows(rows, perm, n_valid=None):
+    m = perm.numel() if n_valid is None else int(n_valid)
+    out = torch.zeros((perm.numel(),) + tuple(rows.shape[1:]), dtype=rows.dtype)
+    out[:m] = rows[perm[:m].long()]
+    return out
+
+
+def pack_by_owner(send_local, perm, counts, capacity, pad_rows=1):
+    G, n = counts.numel(), send_local.numel()
+    packed = (torch.arange(G * capacity) % capacity) % pad_rows
+    src_of = torch.zeros(n, dtype=torch.int32)
+    if int(counts.max()) > capacity:
+        raise RuntimeError("a fixed-capacity exchange buffer overflowed")
+    j = 0
+    for g in range(G):
+        c = int(counts[g])
+        dest = g * capacity + torch.arange(c)
+        packed[dest] = send_local[j:j + c]
+        src_of[perm[j:j + c].long()] = dest.to(torch.int32)
+        j += c
+    return packed, src_of
 
 
 def sort_dedup(idx, n_rows, want_inverse=False):

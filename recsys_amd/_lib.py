@@ -95,13 +95,15 @@ PROTOTYPES = {
     "rx_cross_combine_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rx_bucketize_by_owner": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
-    "rx_unpermute_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),
-    "rx_permute_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),
+    "rx_unpermute_rows": (C.c_int, [vp, vp, i64, vp, i32, vp, C.c_int, vp]),
+    "rx_permute_rows": (C.c_int, [vp, vp, i64, vp, i32, vp, C.c_int, vp]),
+    "rx_pack_by_owner": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp, vp, vp, C.c_int, vp]),
     "rx_topk_codes": (C.c_int, [vp, vp, i64, i32, i32, vp, C.c_int, vp]),
 }
 
 RX_SEG_DENSE, RX_SEG_COMPACT, RX_SEG_SGD, RX_SEG_ADAGRAD, RX_SEG_ROWWISE_ADAGRAD = range(5)
 RX_ERR_INDEX = 1
+RX_ERR_CAPACITY = 2
 RX_ABI_VERSION = 1
 
 

@@ -104,14 +104,16 @@ extern "C" int rx_gather_concat_bwd(const float* d_dout, int64_t out_rows, int64
 }
 
 // ---------------------------------------------------------------- permutation of row blocks
+// n_valid (may be null): device count of the leading entries of perm that are real; threads past
+// it exit, so lists whose length never visits the host can be sized by their upper bound.
 template <bool SCATTER>
 __global__ void __launch_bounds__(RX_BLOCK)
 permute_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ perm, int64_t n,
-                    int dim, float* __restrict__ out) {
+                    const int32_t* __restrict__ n_valid, int dim, float* __restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t j = gid / dim;
   const int c = (int)(gid % dim);
-  if (j >= n) return;
+  if (j >= n || (n_valid && j >= n_valid[0])) return;
   const int64_t p = perm[j];
   if (SCATTER)
     out[p * dim + c] = rows[j * dim + c];
@@ -120,25 +122,85 @@ permute_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ 
 }
 
 extern "C" int rx_unpermute_rows(const float* d_rows, const int32_t* d_perm, int64_t n,
-                                 int32_t dim, float* d_out, int device, void* stream) {
+                                 const int32_t* d_n_valid, int32_t dim, float* d_out, int device,
+                                 void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && dim >= 1, "rx_unpermute_rows: bad shape");
   if (n == 0) return 0;
   RX_REQUIRE(d_rows && d_perm && d_out, "rx_unpermute_rows: null argument");
   const unsigned grid = (unsigned)rx_cdiv(n * dim, RX_BLOCK);
-  hipLaunchKernelGGL(permute_rows_kernel<true>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, dim, d_out);
+  hipLaunchKernelGGL(permute_rows_kernel<true>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, d_n_valid, dim, d_out);
   RX_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, int32_t dim,
-                               float* d_out, int device, void* stream) {
+extern "C" int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n,
+                               const int32_t* d_n_valid, int32_t dim, float* d_out, int device,
+                               void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && dim >= 1, "rx_permute_rows: bad shape");
   if (n == 0) return 0;
   RX_REQUIRE(d_rows && d_perm && d_out, "rx_permute_rows: null argument");
   const unsigned grid = (unsigned)rx_cdiv(n * dim, RX_BLOCK);
-  hipLaunchKernelGGL(permute_rows_kernel<false>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, dim, d_out);
+  hipLaunchKernelGGL(permute_rows_kernel<false>, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_rows, d_perm, n, d_n_valid, dim, d_out);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// Fixed-capacity send buffers: the j-th entry of the owner-grouped list goes to slot
+// owner * capacity + (j - start of its owner's group); src_of[perm[j]] remembers that slot, so
+// rows that come back in the same layout can be read in list order.  Group starts come from the
+// device-side counts, so nothing here needs a host-side length.
+// Padding slots name a valid local row each (slot i of a group -> row i % pad_rows): their
+// gradient slots stay zero, so the owner's update leaves those rows bit-identical, and because the
+// rows differ the owner's reduce sees many short runs instead of one giant run on a single row.
+__global__ void __launch_bounds__(RX_BLOCK)
+pack_fill_kernel(int64_t* __restrict__ packed, int64_t total, int64_t capacity, int64_t pad_rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) packed[i] = (i % capacity) % pad_rows;
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+pack_by_owner_kernel(const int64_t* __restrict__ send_local, const int32_t* __restrict__ perm,
+                     const int64_t* __restrict__ counts, int G, int64_t n, int64_t capacity,
+                     int64_t* __restrict__ packed, int32_t* __restrict__ src_of, int32_t* err_flag) {
+  extern __shared__ int64_t starts[];  // [G + 1]
+  if (threadIdx.x == 0) {
+    int64_t run = 0;
+    for (int g = 0; g < G; ++g) { starts[g] = run; run += counts[g]; }
+    starts[G] = run;
+  }
+  __syncthreads();
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || j >= starts[G]) return;
+  int lo = 0, hi = G;  // owner g with starts[g] <= j < starts[g + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= j) lo = mid; else hi = mid;
+  }
+  const int64_t off = j - starts[lo];
+  if (off >= capacity) {
+    if (err_flag) atomicOr(err_flag, RX_ERR_CAPACITY);
+    return;
+  }
+  const int64_t dest = (int64_t)lo * capacity + off;
+  packed[dest] = send_local[j];
+  src_of[perm[j]] = (int32_t)dest;
+}
+
+extern "C" int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const int64_t* d_counts,
+                                int32_t G, int64_t n, int64_t capacity, int64_t pad_rows, int64_t* d_packed,
+                                int32_t* d_src_of, int32_t* err_flag, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(G >= 1 && G <= 4096 && n >= 0 && capacity >= 1 && pad_rows >= 1 && (int64_t)G * capacity < (1ll << 31), "rx_pack_by_owner: bad sizes");
+  RX_REQUIRE(d_counts && d_packed, "rx_pack_by_owner: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)G * capacity;
+  hipLaunchKernelGGL(pack_fill_kernel, dim3((unsigned)rx_cdiv(total, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_packed, total, capacity, pad_rows);
+  RX_LAUNCH_CHECK();
+  if (n == 0) return 0;
+  RX_REQUIRE(d_send_local && d_perm && d_src_of, "rx_pack_by_owner: null argument");
+  hipLaunchKernelGGL(pack_by_owner_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), (G + 1) * sizeof(int64_t), st, d_send_local, d_perm, d_counts, G, n, capacity, d_packed, d_src_of, err_flag);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -45,9 +45,13 @@ def raise_if_index_error(device=None) -> None:
     for key, t in list(_err_flags.items()):
         if device is not None and torch.device(device).index not in (None, key):
             continue
-        if int(t.item()) & _lib.RX_ERR_INDEX:
+        bits = int(t.item())
+        if bits:
             t.zero_()
+        if bits & _lib.RX_ERR_INDEX:
             raise IndexError("index out of range in a recsys_amd embedding lookup")
+        if bits & _lib.RX_ERR_CAPACITY:
+            raise RuntimeError("a fixed-capacity exchange buffer overflowed: raise the capacity of the sharded lookup")
 
 
 def _after_index_op(device) -> None:
@@ -769,20 +773,40 @@ def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int, n_valid: Opt
     return counts, send_local, perm
 
 
-def unpermute_rows(rows: Tensor, perm: Tensor) -> Tensor:
-    out = torch.empty_like(rows)
+def unpermute_rows(rows: Tensor, perm: Tensor, n_valid: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """out[perm[j]] = rows[j] for the first ``n_valid`` (device count; default all) entries of ``perm``.
+    ``out``: destination with at least max(perm) + 1 rows (default: same shape as ``rows``)."""
+    if out is None:
+        out = torch.empty_like(rows)
     dim = rows.shape[1] if rows.dim() == 2 else 1
-    check(lib.rx_unpermute_rows(_p(rows), _p(perm), perm.numel(), dim, _p(out), _dev(rows), _stream(rows)),
+    # every real entry owns a distinct row of ``out``, so at most out.shape[0] entries are real
+    n = min(perm.numel(), out.shape[0]) if n_valid is not None else perm.numel()
+    check(lib.rx_unpermute_rows(_p(rows), _p(perm), n, _p(n_valid), dim, _p(out), _dev(rows), _stream(rows)),
           "rx_unpermute_rows")
     return out
 
 
-def permute_rows(rows: Tensor, perm: Tensor) -> Tensor:
-    out = torch.empty_like(rows)
+def permute_rows(rows: Tensor, perm: Tensor, n_valid: Optional[Tensor] = None) -> Tensor:
+    """out[j] = rows[perm[j]] for the first ``n_valid`` entries of ``perm``; ``out`` has one row per entry."""
     dim = rows.shape[1] if rows.dim() == 2 else 1
-    check(lib.rx_permute_rows(_p(rows), _p(perm), perm.numel(), dim, _p(out), _dev(rows), _stream(rows)),
+    out = torch.empty((perm.numel(), dim) if rows.dim() == 2 else (perm.numel(),), dtype=rows.dtype, device=rows.device)
+    n = min(perm.numel(), rows.shape[0]) if n_valid is not None else perm.numel()   # real entries read distinct rows
+    check(lib.rx_permute_rows(_p(rows), _p(perm), n, _p(n_valid), dim, _p(out), _dev(rows), _stream(rows)),
           "rx_permute_rows")
     return out
+
+
+def pack_by_owner(send_local: Tensor, perm: Tensor, counts: Tensor, capacity: int, pad_rows: int = 1):
+    """Owner-grouped list -> fixed-capacity send buffer.  Returns (packed [G * capacity] int64,
+    src_of [n] int32: packed slot of every list position).  Padding slot i names local row
+    i % pad_rows (``pad_rows`` <= every owner's local height)."""
+    G, n = counts.numel(), send_local.numel()
+    packed = torch.empty(G * capacity, dtype=torch.int64, device=send_local.device)
+    src_of = torch.empty(n, dtype=torch.int32, device=send_local.device)
+    check(lib.rx_pack_by_owner(_p(send_local), _p(perm), _p(counts), G, n, capacity, pad_rows, _p(packed), _p(src_of),
+                               _p(_err_flag(send_local.device)), _dev(send_local), _stream(send_local)),
+          "rx_pack_by_owner")
+    return packed, src_of
 
 
 def topk_codes(scores: Tensor, codes: Optional[Tensor], k: int) -> Tensor:

@@ -79,6 +79,26 @@ class ShardedTable:
         dist.all_to_all_single(recv_idx, send_local[:m].contiguous(), recv, send, group=self.group)
         return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm[:m], n=m)
 
+    def plan_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int):
+        """Exchange plan with ``capacity`` slots per owner and equal all-to-all splits: no host-side
+        sizes, so the step never waits for the host.  A group that does not fit sets the deferred
+        RX_ERR_CAPACITY flag (``ops.raise_if_index_error``)."""
+        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
+        packed, src_of = self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1))
+        recv_idx = packed
+        if not (self.G == 1 and not self.force_exchange):
+            recv_idx = torch.empty_like(packed)
+            dist.all_to_all_single(recv_idx, packed, group=self.group)
+        return dict(fixed=True, recv_idx=recv_idx, src_of=src_of, n_valid=n_valid, capacity=capacity, n=idx.numel())
+
+    def _swap(self, buf: torch.Tensor) -> torch.Tensor:
+        """All-to-all of a [G * capacity, ...] buffer with equal splits."""
+        if self.G == 1 and not self.force_exchange:
+            return buf
+        out = torch.empty_like(buf)
+        dist.all_to_all_single(out, buf, group=self.group)
+        return out
+
     def _to_owners(self, rows_in_send_order: torch.Tensor, plan) -> torch.Tensor:
         if self.G == 1 and not self.force_exchange:
             return rows_in_send_order
@@ -99,6 +119,8 @@ class ShardedTable:
         """Rows for the planned index list, in the list's own order: [n, dim]."""
         seg = self.ops.Segment(self.weight, plan["recv_idx"], 0)
         mine = self.ops.gather_concat([seg], plan["recv_idx"].numel(), self.dim)
+        if plan.get("fixed"):
+            return self.ops.permute_rows(self._swap(mine), plan["src_of"], plan["n_valid"])
         back = self._from_owners(mine, plan)
         return self.ops.unpermute_rows(back, plan["perm"])
 
@@ -107,12 +129,21 @@ class ShardedTable:
         """Send per-occurrence gradient rows (list order) to the owners and reduce / update there.
         ``companion`` / ``occ2`` [n]: a second table addressed by the same rows (the [rows, 1] bias
         table) and its per-occurrence gradients; they share this list's plan, sort and reduce."""
-        sent = self.ops.permute_rows(occ.contiguous(), plan["perm"])
-        got = self._to_owners(sent, plan)
         got2 = None
-        if companion is not None:
-            sent2 = self.ops.permute_rows(occ2.reshape(-1, 1).contiguous(), plan["perm"])
-            got2 = self._to_owners(sent2, plan).reshape(-1)
+        if plan.get("fixed"):
+            slots = plan["recv_idx"].numel()
+            sent = torch.zeros(slots, self.dim, dtype=torch.float32, device=occ.device)   # padding slots carry zero gradients
+            got = self._swap(self.ops.unpermute_rows(occ.contiguous(), plan["src_of"], plan["n_valid"], out=sent))
+            if companion is not None:
+                sent2 = torch.zeros(slots, 1, dtype=torch.float32, device=occ.device)
+                got2 = self._swap(self.ops.unpermute_rows(occ2.reshape(-1, 1).contiguous(), plan["src_of"],
+                                                          plan["n_valid"], out=sent2)).reshape(-1)
+        else:
+            sent = self.ops.permute_rows(occ.contiguous(), plan["perm"])
+            got = self._to_owners(sent, plan)
+            if companion is not None:
+                sent2 = self.ops.permute_rows(occ2.reshape(-1, 1).contiguous(), plan["perm"])
+                got2 = self._to_owners(sent2, plan).reshape(-1)
         if got.shape[0] == 0:
             return
         si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
@@ -196,6 +227,30 @@ class ShardedFieldFM(torch.nn.Module):
         self.bias = ShardedTable(n, 1, device, group, backend, seed=2, full_weight=bw)
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=device))
         self._pos = {}
+        # slots per owner of the fixed-capacity exchange; None = exact sizes (one host read per step)
+        self.capacity: Optional[int] = None
+
+    def _flat(self, sparse):
+        F = self.n_fields - 1
+        glob = sparse + self._offsets[None, :]
+        # occurrence order of the FM kernels: all (b, f < F) first, then the last field's B entries
+        return torch.cat([glob[:, :F].reshape(-1), glob[:, F]]).contiguous()
+
+    def calibrate(self, batches, slack: float = 1.25) -> int:
+        """Pick the exchange capacity from sample batches: the largest number of distinct rows any
+        rank sends to one owner (maximum over ranks), times ``slack``, rounded up to 256.  Host work,
+        done once before training."""
+        G = self.feature.G
+        worst = 1
+        for b in batches:
+            uniq = torch.unique(self._flat(b["sparse"]))
+            worst = max(worst, int(torch.bincount(uniq % G, minlength=G).max()))
+        if dist.is_initialized() and G > 1:
+            t = torch.tensor([worst], dtype=torch.int64, device=self._offsets.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.feature.group)
+            worst = int(t.item())
+        self.capacity = (int(worst * slack) + 255) // 256 * 256
+        return self.capacity
 
     def set_rule(self, kind, lr, eps=1e-10):
         self.feature.set_rule(kind, lr, eps)
@@ -216,11 +271,7 @@ class ShardedFieldFM(torch.nn.Module):
 
     def forward(self, inputs):
         sparse = inputs["sparse"]
-        B, F = sparse.shape[0], self.n_fields - 1
-        glob = sparse + self._offsets[None, :]
-        # occurrence order of the FM kernels: all (b, f < F) first, then the last field's B entries
-        flat = torch.cat([glob[:, :F].reshape(-1), glob[:, F]]).contiguous()
-        return _ShardedFM.apply(self._anchor, self, flat, B, F)
+        return _ShardedFM.apply(self._anchor, self, self._flat(sparse), sparse.shape[0], self.n_fields - 1)
 
     def loss(self, inputs):
         if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
@@ -247,8 +298,12 @@ class _ShardedFM(torch.autograd.Function):
         ops, feat, bias = model.ops, model.feature, model.bias
         n = flat.numel()
         si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
-        plan = feat.plan(si.uniq_rows, si.n_uniq)        # padded list + device count; one host read inside
-        nu = plan["n"]
+        if model.capacity:
+            plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity)   # nothing here waits for the host
+            nu = n                                                            # buffers sized by the upper bound
+        else:
+            plan = feat.plan(si.uniq_rows, si.n_uniq)    # padded list + device count; one host read inside
+            nu = plan["n"]
         rows_u = feat.gather(plan)                        # [nu, D], in distinct-row order
         bias_u = bias.gather(plan)                        # [nu, 1]
         inv = si.inverse.to(torch.int64)

@@ -66,8 +66,9 @@ def test_epoch_loader_on_device():
     assert n == data.implicit_matrix.nnz and len(dl) == -(-n // 256)
 
 
+@pytest.mark.parametrize("fixed", [False, True])
 @pytest.mark.parametrize("kind", ["sgd", "adagrad", None])
-def test_sharded_fm_world1_matches_field_fm(kind):
+def test_sharded_fm_world1_matches_field_fm(kind, fixed):
     """World size 1: the exchange degenerates to local permutations, all through the HIP kernels."""
     from recsys_amd.models.fields import FieldFM
     from recsys_amd.optim import FusedOptimizer
@@ -80,6 +81,8 @@ def test_sharded_fm_world1_matches_field_fm(kind):
     g = torch.Generator().manual_seed(4)
     batch = {"sparse": torch.stack([torch.randint(0, d, (333,), generator=g) for d in dims], 1).cuda(),
              "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
+    if fixed:
+        sh.calibrate([batch])
     if kind:
         opt = FusedOptimizer(ref, kind=kind, lr=0.1)
         sh.set_rule(kind, 0.1)
@@ -171,11 +174,15 @@ def test_sharded_fm_one_rank_through_rccl():
                  "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
         opt = FusedOptimizer(ref, kind="sgd", lr=0.1)
         sh.set_rule("sgd", 0.1)
-        for _ in range(2):
+        for step in range(3):
+            if step == 1:
+                sh.calibrate([batch])     # from here on: fixed-capacity exchange, equal all-to-all splits
             ref.zero_grad()
             l1 = ref.loss(batch); l1.backward(); opt.step()
             l2 = sh.loss(batch); l2.backward()
             assert_close(l2.item(), l1.item(), rtol=1e-6, what="loss")
+        ops_mod = __import__("recsys_amd.ops", fromlist=["x"])
+        ops_mod.raise_if_index_error()
         assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
         assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
     finally:

@@ -48,6 +48,10 @@ def _worker(rank, world, port, kind, out):
         assert torch.equal(got, full["feature_embedding.weight"][idx])
         # two data-parallel steps
         m = ShardedFieldFM(DIMS, DIM, "cpu", backend=cpu_ops, full_state=full)
+        fixed = kind.endswith("+capacity")
+        kind = kind.split("+")[0]
+        if fixed:   # fixed-capacity exchange: equal all-to-all splits, capacity from the batch itself
+            assert m.calibrate([local]) % 256 == 0
         if kind != "dense":
             m.set_rule(kind, lr=0.1)
         losses = []
@@ -73,7 +77,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adagrad", "dense"])
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "dense", "sgd+capacity", "adagrad+capacity"])
 def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
     from oracle.fields import FieldOracle
     world = 2
@@ -84,6 +88,7 @@ def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
     feat, bias = torch.empty(n, DIM), torch.empty(n, 1)
     for r, (fw, bw, _) in enumerate(shards):
         feat[r::world], bias[r::world] = fw, bw
+    kind = kind.split("+")[0]
     oracle = FieldOracle("FieldFM", _full_state(), DIMS)
     opt = (torch.optim.Adagrad if kind == "adagrad" else torch.optim.SGD)(oracle.parameters(), lr=0.1)
     batch = _global_batch(world)
