@@ -100,14 +100,30 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None)
     if use_graph:
         from recsys_amd.graph import GraphedTrainStep
-        gs = GraphedTrainStep(model, opt, pipeline=True)
+        gs = GraphedTrainStep(model, opt, pipeline=True, cycle=True)
         gs.add_batches(batches)
         w["graphed"] = gs
-        desc["launch"] = ("one HIP graph replay per step; the graph of batch i also sorts the indices of "
-                          "batch i+1 on a side stream (one sort per step, off the critical path)")
+        desc["launch"] = (f"HIP graph replays: one graph per round over the {n_batches} resident batches where the step "
+                          "count allows, one graph per step otherwise; the indices of batch i+1 are sorted on a side "
+                          "stream while batch i trains (one sort per step, off the critical path)")
     else:
         desc["launch"] = "eager"
     return w
+
+
+def run_steps(w, first: int, count: int):
+    """Steps first .. first+count-1 (batch = step % resident batches); whole rounds go through the
+    round graph when there is one.  Returns the last loss."""
+    gs, K = w.get("graphed"), len(w["batches"])
+    i, end, loss = first, first + count, None
+    while i < end:
+        if gs is not None and gs.cycle_graph is not None and i % K == 0 and end - i >= K:
+            loss = gs.run_cycle()[-1]
+            i += K
+        else:
+            loss = one_step(w, i)
+            i += 1
+    return loss
 
 
 def one_step(w, i):
@@ -346,8 +362,10 @@ def main():
 
     def run(name, steps, warmup, timed_op=None, use_graph=True):
         w = build_workload(name, device, rank, world, clip, use_graph)
-        for i in range(warmup):
-            one_step(w, i)
+        # the timed region starts on resident batch 0, where a whole-round graph may begin (any slot
+        # can go first: all were prepared when they were registered)
+        first = (-warmup) % len(w["batches"])
+        run_steps(w, first, warmup)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -355,8 +373,7 @@ def main():
         timer = OpTimer([timed_op] if timed_op else [])
         t0 = time.perf_counter()
         with timer:
-            for i in range(steps):
-                loss = one_step(w, warmup + i)
+            loss = run_steps(w, first + warmup, steps)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

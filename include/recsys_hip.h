@@ -42,6 +42,10 @@ extern "C" {
 
 int rx_abi_version(void);
 const char* rx_last_error(void);
+/* Measurement aid without a counterpart in the reference: writes the device wall clock (ticks of
+ * the constant 100 MHz counter, 10 ns each) to *d_slot in stream order.  Works between the nodes
+ * of a captured HIP graph, where HIP events cannot be queried per replay. */
+int rx_wall_clock(int64_t* d_slot, int device, void* stream);
 
 /* ------------------------------------------------------------------ gather / assemble
  * Replaces nn.Embedding lookups followed by unsqueeze/repeat/cat/view when a tower input
@@ -217,6 +221,14 @@ int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_so
                   int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                   int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
                   void* stream);
+/* The same over the row list of an FM batch, read straight from the index matrices in `a`
+ * (ex_idx, ex_base, item_idx, item_base, B, F, N, n_feat = rows of the table; the table pointers
+ * are not touched): entry i < B*F is extra field i % F of sample i / F plus that field's base row,
+ * the remaining B*N entries are the item rows plus item_base, i.e. exactly the list
+ * rx_fm2_flat_indices writes, without writing it.  n = B*(F+N) sizes the outputs and the workspace. */
+int rx_sort_dedup_fm(const rx_fm_args* a, int32_t* d_sorted_pos, int32_t* d_sorted_slot,
+                     int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq, int32_t* d_inverse,
+                     void* ws, size_t ws_bytes, int32_t* err_flag, int device, void* stream);
 
 /* ------------------------------------------------------------------ segmented reduce + update
  * Second stage.  For each distinct row u the gradient

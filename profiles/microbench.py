@@ -52,6 +52,10 @@ F = len(dims) - 1
 B = 65536
 flat_fm = torch.cat([(b["sparse"][:, :F] + offs[None, :F]).reshape(-1), b["sparse"][:, F] + offs[F]]).contiguous()
 si_fm = ops.sort_dedup(flat_fm, rows)
+ex, item = b["sparse"][:, :F], b["sparse"][:, F:]
+ex_base, item_base = offs[:F].contiguous(), int(offs[F])
+print(f"flat list + sort_dedup {timeit(lambda: ops.sort_dedup(ops.fm2_flat_indices(table, ex, ex_base, item, item_base), rows)):8.1f} us")
+print(f"fm_sort_dedup (no flat list) {timeit(lambda: ops.fm_sort_dedup(table, ex, ex_base, item, item_base)):8.1f} us")
 T = torch.randn(B, dim, device=dev)
 gl = torch.randn(B, device=dev) / B
 print(f"segreduce_fm COMPACT+sq{timeit(lambda: ops.segreduce_fm(T, gl, F, si_fm, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2, want_sq=True)):8.1f} us")

@@ -49,6 +49,7 @@ class TensorList(C.Structure):
 PROTOTYPES = {
     "rx_abi_version": (C.c_int, []),
     "rx_last_error": (C.c_char_p, []),
+    "rx_wall_clock": (C.c_int, [vp, C.c_int, vp]),
     "rx_gather_concat": (C.c_int, [C.POINTER(GatherSeg), C.c_int, vp, i64, i64, vp, C.c_int, vp]),
     "rx_gather_concat_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, C.c_int, vp]),
     "rx_mf_score_fwd": (C.c_int, [C.POINTER(MFArgs), vp, vp, C.c_int, vp]),
@@ -64,6 +65,7 @@ PROTOTYPES = {
     "rx_bce_fwd": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, sz, C.c_int, vp]),
     "rx_sort_dedup_workspace_bytes": (sz, [i64]),
     "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
+    "rx_sort_dedup_fm": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_segreduce_grid": (i64, [i64, i32]),
     "rx_segreduce_workspace_bytes": (sz, [i64, i32]),
     "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),

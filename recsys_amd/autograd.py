@@ -150,24 +150,22 @@ class _AsyncSort:
         self.side = _side_stream(dev)
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
-            flat = ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base)
-            self.si = ops.sort_dedup(flat, feat.shape[0])
-        self.flat = flat
+            self.si = ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base)
 
     def join(self) -> SortedIndex:
-        main = torch.cuda.current_stream(self.flat.device)
+        main = torch.cuda.current_stream(self.si.seg_off.device)
         main.wait_stream(self.side)
-        for t in (self.si.sorted_pos, self.si.sorted_slot, self.si.uniq_rows, self.si.seg_off, self.si.n_uniq, self.flat):
+        for t in (self.si.sorted_pos, self.si.sorted_slot, self.si.uniq_rows, self.si.seg_off, self.si.n_uniq):
             t.record_stream(main)
         return self.si
 
 
 class Presort:
-    """Index preparation done ahead of the step (see HotPathModule.prepare): the flat row-id list
-    of a batch and its sort / dedup result, in buffers that can be refreshed in place."""
+    """Index preparation done ahead of the step (see HotPathModule.prepare): the sort / dedup
+    result of a batch's row list, in buffers that can be refreshed in place."""
 
-    def __init__(self, flat, si: SortedIndex):
-        self.flat, self.si = flat, si
+    def __init__(self, si: SortedIndex):
+        self.si = si
 
     def join(self) -> SortedIndex:
         return self.si
@@ -220,16 +218,14 @@ class FM2(Function):
             g_deep = g_deep.contiguous()
         none_tail = (None,) * 6
         if ctx.tsum is not None and (g is not None or g_deep is not None):
-            s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
-                ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])
+            s = ctx.sort.join() if ctx.sort is not None else ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base)
             gl = g.reshape(-1) if g is not None else torch.zeros(ctx.tsum.shape[0], dtype=torch.float32, device=feat.device)
             gfeat, gbias = table_backward_fm(feat, bias_table, s, ctx.tsum, gl, ex_idx.shape[1], g_deep)
             return (None, None, None, None, gfeat, gbias) + none_tail
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         occ, bias_occ = ops.fm2_bwd(g, g_deep, feat, bias_flat, ex_idx, ex_base, item_idx, item_base,
                                     ctx.second_order)
-        s = ctx.sort.join() if ctx.sort is not None else ops.sort_dedup(
-            ops.fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base), feat.shape[0])
+        s = ctx.sort.join() if ctx.sort is not None else ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base)
         if bias_table is not None:
             gfeat, gbias = table_backward(feat, s, occ, param2=bias_table, occ2=bias_occ)
         else:

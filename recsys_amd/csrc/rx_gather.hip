@@ -10,6 +10,18 @@ thread_local char rx_err_buf[512] = "";
 extern "C" const char* rx_last_error(void) { return rx_err_buf; }
 extern "C" int rx_abi_version(void) { return RX_ABI_VERSION; }
 
+// Device wall clock (constant 100 MHz counter) written in stream order: brackets work inside a
+// replayed HIP graph, where events cannot be placed between nodes after capture.
+__global__ void wall_clock_kernel(int64_t* slot) { *slot = (int64_t)wall_clock64(); }
+
+extern "C" int rx_wall_clock(int64_t* d_slot, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(d_slot, "rx_wall_clock: null slot");
+  hipLaunchKernelGGL(wall_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d_slot);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 struct GatherSegs {
   rx_gather_seg s[RX_MAX_SEGS];
   int n;

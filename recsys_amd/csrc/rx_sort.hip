@@ -22,18 +22,46 @@
 #define SORT_WAVE_KEYS (64 * SORT_ITEMS)
 #define SCAN_TILE (RX_BLOCK * 8)           // entries of the count array per scan block
 
-// The first pass reads the caller's int64 rows directly (RAW): key = row clamped into range
-// (rows < 2^32), value = position.  Later passes read the uint32 pairs of the previous one.
-__device__ __forceinline__ uint32_t raw_key(const int64_t* __restrict__ idx, int64_t i, int64_t n_rows, bool* bad) {
-  const int64_t r = idx[i];
+// The first pass reads the caller's int64 rows directly: key = row clamped into range (rows < 2^32),
+// value = position.  Later passes read the uint32 pairs of the previous one.  RAW selects the source:
+//   0  uint32 keys of the previous pass
+//   1  a plain int64 list
+//   2  the FM model's index matrices: position i < B*F is extra field i % F of sample i / F, shifted
+//      by that field's base row; the rest are the B*N item rows shifted by item_base (the order
+//      rx_fm2_flat_indices writes, without materialising that list)
+struct RawSrc {
+  const int64_t* idx;
+  const int64_t* ex_idx;
+  const int64_t* ex_base;
+  const int64_t* item_idx;
+  int64_t ex_ld, item_ld, item_base;
+  uint32_t n_ex, F, N;
+};
+
+template <int RAW>
+__device__ __forceinline__ uint32_t raw_key(const RawSrc& s, int64_t i, int64_t n_rows, bool* bad) {
+  int64_t r;
+  if constexpr (RAW == 2) {
+    // branch-free, so that the loads of a thread's 16 keys are all in flight together
+    const uint32_t u = (uint32_t)i;
+    const bool is_ex = u < s.n_ex;
+    const uint32_t q = is_ex ? u : u - s.n_ex;
+    const uint32_t per = is_ex ? s.F : s.N;
+    const uint32_t b = q / per, k = q - b * per;
+    const int64_t* p = is_ex ? s.ex_idx + ((int64_t)b * s.ex_ld + k) : s.item_idx + ((int64_t)b * s.item_ld + k);
+    const int64_t shift = s.ex_base[is_ex ? k : 0];
+    r = *p + (is_ex ? shift : s.item_base);
+  } else {
+    r = s.idx[i];
+  }
   *bad = r < 0 || r >= n_rows;
   return (uint32_t)(r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r));
 }
 
 // counts[digit][block] for this pass (bins = 1 << bits)
-template <bool RAW>
+template <int RAW>
 __global__ void __launch_bounds__(RX_BLOCK)
-sort_hist_kernel(const void* __restrict__ keys_in, int64_t n, int64_t n_rows, int shift, int bits,
+sort_hist_kernel(RawSrc src, const uint32_t* __restrict__ keys_in, int64_t n, int64_t n_rows, int shift, int bits,
                  uint32_t* __restrict__ block_hist, int n_blocks, int32_t* err_flag) {
   extern __shared__ uint32_t h[];
   const int bins = 1 << bits;
@@ -46,20 +74,39 @@ sort_hist_kernel(const void* __restrict__ keys_in, int64_t n, int64_t n_rows, in
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = base + it * RX_BLOCK + threadIdx.x;
     const int64_t ii = i < n ? i : n - 1;
-    if constexpr (RAW) {
+    if constexpr (RAW != 0) {
       bool bad;
-      key[it] = raw_key((const int64_t*)keys_in, ii, n_rows, &bad);
+      key[it] = raw_key<RAW>(src, ii, n_rows, &bad);
       any_bad |= bad;
     } else {
-      key[it] = ((const uint32_t*)keys_in)[ii];
+      key[it] = keys_in[ii];
     }
   }
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
     const int64_t i = base + it * RX_BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&h[(key[it] >> shift) & (bins - 1)], 1u);
+    const uint32_t d = (key[it] >> shift) & (bins - 1);
+    bool todo = i < n;
+    if constexpr (RAW == 0) {
+      // High digits of row ids are skewed (a few digits hold most keys), and 64 lanes adding to one
+      // LDS word serialise.  Two rounds of "everyone with the first pending lane's digit": that
+      // lane adds the group's size once.  Whatever is left goes through plain atomics.
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        const unsigned long long pend = __ballot(todo);
+        if (pend == 0) break;
+        const int leader = __ffsll((long long)pend) - 1;
+        const uint32_t dl = (uint32_t)__shfl((int)d, leader, 64);
+        const bool mine = todo && d == dl;
+        const unsigned long long grp = __ballot(mine);
+        if (lane == leader) atomicAdd(&h[dl], (uint32_t)__popcll(grp));
+        todo = todo && !mine;
+      }
+    }
+    if (todo) atomicAdd(&h[d], 1u);
   }
-  if (RAW && any_bad && err_flag) atomicOr(err_flag, RX_ERR_INDEX);
+  if (RAW != 0 && any_bad && err_flag) atomicOr(err_flag, RX_ERR_INDEX);
   __syncthreads();
   for (int d = threadIdx.x; d < bins; d += blockDim.x) block_hist[(int64_t)d * n_blocks + blockIdx.x] = h[d];
 }
@@ -134,9 +181,9 @@ scan_totals_kernel(uint32_t* __restrict__ sums, int64_t count) {
 // flight, which saves a single-block launch per pass.  Otherwise they arrive scanned.
 #define SCAN_FOLD_MAX 1024
 
-template <bool RAW, bool FOLD>
+template <int RAW, bool FOLD>
 __global__ void __launch_bounds__(RX_BLOCK)
-sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
+sort_scatter_kernel(RawSrc src, const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
                     int64_t n_rows, int shift, int bits, const uint32_t* __restrict__ block_off,
                     const uint32_t* __restrict__ tile_sums, int n_tiles, int n_blocks,
                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
@@ -163,12 +210,12 @@ sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict
     const int64_t i = wbase + it * 64 + lane;
     const bool live = i < n;
     const int64_t ii = live ? i : n - 1;
-    if constexpr (RAW) {
+    if constexpr (RAW != 0) {
       bool bad;
-      key[it] = raw_key((const int64_t*)keys_in, ii, n_rows, &bad);
+      key[it] = raw_key<RAW>(src, ii, n_rows, &bad);
       val[it] = (uint32_t)ii;
     } else {
-      key[it] = ((const uint32_t*)keys_in)[ii];
+      key[it] = keys_in[ii];
       val[it] = vals_in[ii];
     }
     if (!live) key[it] = 0xFFFFFFFFu;
@@ -285,28 +332,50 @@ sort_scatter_kernel(const void* __restrict__ keys_in, const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------- run-length compaction
-#define DEDUP_ITEMS 2
+#define DEDUP_ITEMS 8
 #define DEDUP_TILE (RX_BLOCK * DEDUP_ITEMS)
 
-__device__ __forceinline__ bool is_head(const uint32_t* keys, int64_t i) { return i == 0 || keys[i] != keys[i - 1]; }
+// a thread's DEDUP_ITEMS consecutive keys (vector loads when the whole group is inside the list),
+// and which of them start a run
+__device__ __forceinline__ uint32_t dedup_heads(const uint32_t* __restrict__ keys, int64_t base, int64_t n,
+                                                uint32_t (&k)[DEDUP_ITEMS], bool (&head)[DEDUP_ITEMS]) {
+  if (base + DEDUP_ITEMS <= n) {
+#pragma unroll
+    for (int q = 0; q < DEDUP_ITEMS / 4; ++q) {
+      const uint4 v = *(const uint4*)(keys + base + 4 * q);
+      k[4 * q] = v.x; k[4 * q + 1] = v.y; k[4 * q + 2] = v.z; k[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < DEDUP_ITEMS; ++it) k[it] = base + it < n ? keys[base + it] : 0u;
+  }
+  const uint32_t prev = (base > 0 && base < n) ? keys[base - 1] : 0u;
+  uint32_t c = 0;
+#pragma unroll
+  for (int it = 0; it < DEDUP_ITEMS; ++it) {
+    const uint32_t before = it == 0 ? prev : k[it - 1];
+    head[it] = base + it < n && (base + it == 0 || k[it] != before);
+    c += head[it] ? 1u : 0u;
+  }
+  return c;
+}
 
 __global__ void __launch_bounds__(RX_BLOCK)
 dedup_count_kernel(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t wsum[RX_BLOCK / 64];
   const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE + (int64_t)threadIdx.x * DEDUP_ITEMS;
-  uint32_t c = 0;
-#pragma unroll
-  for (int it = 0; it < DEDUP_ITEMS; ++it) {
-    const int64_t i = base + it;
-    if (i < n && is_head(keys, i)) ++c;
-  }
+  uint32_t k[DEDUP_ITEMS];
+  bool head[DEDUP_ITEMS];
+  uint32_t c = dedup_heads(keys, base, n, k, head);
   for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// block_counts holds the exclusive scan of the per-block head counts on entry
+// FOLD: block_counts holds the raw per-block head counts (at most SCAN_FOLD_MAX of them) and every
+// block sums the ones before it; otherwise their exclusive scan.
+template <bool FOLD>
 __global__ void __launch_bounds__(RX_BLOCK)
 dedup_write_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
                    const uint32_t* __restrict__ block_base, int n_blocks,
@@ -314,36 +383,68 @@ dedup_write_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict
                    int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq,
                    int32_t* __restrict__ inverse, int32_t* __restrict__ sorted_slot) {
   __shared__ uint32_t lds4[4];
+  __shared__ uint32_t before_lds[4];
   const int64_t base = (int64_t)blockIdx.x * DEDUP_TILE + (int64_t)threadIdx.x * DEDUP_ITEMS;
   bool head[DEDUP_ITEMS];
   uint32_t k[DEDUP_ITEMS], v[DEDUP_ITEMS];
-  uint32_t c = 0;
+  const uint32_t c = dedup_heads(keys, base, n, k, head);
+  if (base + DEDUP_ITEMS <= n) {
 #pragma unroll
-  for (int it = 0; it < DEDUP_ITEMS; ++it) {
-    const int64_t i = base + it;
-    k[it] = i < n ? keys[i] : 0u;
-    v[it] = i < n ? vals[i] : 0u;
-    head[it] = i < n && is_head(keys, i);
-    c += head[it] ? 1u : 0u;
+    for (int q = 0; q < DEDUP_ITEMS / 4; ++q) {
+      const uint4 t = *(const uint4*)(vals + base + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < DEDUP_ITEMS; ++it) v[it] = base + it < n ? vals[base + it] : 0u;
+  }
+  uint32_t first;
+  if constexpr (FOLD) {
+    // heads in the blocks before this one: SCAN_FOLD_MAX / RX_BLOCK counts per thread, fixed tree
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_FOLD_MAX / RX_BLOCK; ++e) {
+      const int b = e * RX_BLOCK + threadIdx.x;
+      if (b < (int)blockIdx.x) mine += block_base[b];
+    }
+    for (int m = 32; m > 0; m >>= 1) mine += __shfl_xor(mine, m, 64);
+    if ((threadIdx.x & 63) == 0) before_lds[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    first = before_lds[0] + before_lds[1] + before_lds[2] + before_lds[3];
+  } else {
+    first = block_base[blockIdx.x];
   }
   uint32_t tile_total;
-  uint32_t slot = block_base[blockIdx.x] + block_exclusive_scan(c, lds4, &tile_total);
+  uint32_t slot = first + block_exclusive_scan(c, lds4, &tile_total);
+  int32_t slots[DEDUP_ITEMS];
 #pragma unroll
   for (int it = 0; it < DEDUP_ITEMS; ++it) {
     const int64_t i = base + it;
-    if (i < n) {
-      if (head[it]) {
-        uniq_rows[slot] = (int64_t)k[it];
-        seg_off[slot] = (int32_t)i;
-        ++slot;
-      }
-      sorted_pos[i] = (int32_t)v[it];
-      if (sorted_slot) sorted_slot[i] = (int32_t)(slot - 1);
-      if (inverse) inverse[v[it]] = (int32_t)(slot - 1);
+    if (head[it]) {
+      uniq_rows[slot] = (int64_t)k[it];
+      seg_off[slot] = (int32_t)i;
+      ++slot;
     }
+    slots[it] = (int32_t)(slot - 1);
+    if (i < n && inverse) inverse[v[it]] = slots[it];
+  }
+  const bool out16 = (((uintptr_t)sorted_pos | (uintptr_t)sorted_slot) & 15) == 0;
+  if (out16 && base + DEDUP_ITEMS <= n) {
+#pragma unroll
+    for (int q = 0; q < DEDUP_ITEMS / 4; ++q) {
+      *(int4*)(sorted_pos + base + 4 * q) = make_int4((int)v[4 * q], (int)v[4 * q + 1], (int)v[4 * q + 2], (int)v[4 * q + 3]);
+      if (sorted_slot) *(int4*)(sorted_slot + base + 4 * q) = make_int4(slots[4 * q], slots[4 * q + 1], slots[4 * q + 2], slots[4 * q + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < DEDUP_ITEMS; ++it)
+      if (base + it < n) {
+        sorted_pos[base + it] = (int32_t)v[it];
+        if (sorted_slot) sorted_slot[base + it] = slots[it];
+      }
   }
   if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) {
-    const uint32_t total = block_base[blockIdx.x] + tile_total;
+    const uint32_t total = first + tile_total;
     n_uniq[0] = (int32_t)total;
     seg_off[total] = (int32_t)n;
   }
@@ -393,12 +494,12 @@ static SortWs sort_ws_layout(void* ws, int64_t n) {
 
 extern "C" size_t rx_sort_dedup_workspace_bytes(int64_t n) { return sort_ws_layout(nullptr, n).bytes; }
 
-// one stable counting pass on `bits` bits starting at `shift`.  raw_idx != NULL: first pass of
-// the row sort, reading the caller's int64 rows.  fold: the scatter scans the tile totals itself;
+// one stable counting pass on `bits` bits starting at `shift`.  raw_mode != 0: first pass of the
+// row sort, keys taken from `raw` (see RawSrc).  fold: the scatter scans the tile totals itself;
 // callers that read w.tiles afterwards ask for the separately scanned form.
-static int sort_pass(const SortWs& w, const int64_t* raw_idx, int64_t n_rows, int32_t* err_flag, const uint32_t* kin,
-                     const uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift, int bits,
-                     bool allow_fold, hipStream_t st) {
+static int sort_pass(const SortWs& w, const RawSrc& raw, int raw_mode, int64_t n_rows, int32_t* err_flag,
+                     const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift,
+                     int bits, bool allow_fold, hipStream_t st) {
   const int nb = (int)rx_cdiv(n, SORT_TILE);
   const int bins = 1 << bits;
   const int64_t entries = (int64_t)nb * bins;
@@ -407,8 +508,12 @@ static int sort_pass(const SortWs& w, const int64_t* raw_idx, int64_t n_rows, in
   const size_t hl = bins * sizeof(uint32_t);
   const size_t stage = (size_t)(SORT_WAVES * bins > 2 * SORT_TILE ? SORT_WAVES * bins : 2 * SORT_TILE);
   const size_t sl = (2 * (size_t)bins + stage) * sizeof(uint32_t);
-  if (raw_idx) hipLaunchKernelGGL(sort_hist_kernel<true>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)raw_idx, n, n_rows, shift, bits, w.hist, nb, err_flag);
-  else hipLaunchKernelGGL(sort_hist_kernel<false>, dim3(nb), dim3(RX_BLOCK), hl, st, (const void*)kin, n, n_rows, shift, bits, w.hist, nb, err_flag);
+#define HIST(RAWV) \
+  hipLaunchKernelGGL(sort_hist_kernel<RAWV>, dim3(nb), dim3(RX_BLOCK), hl, st, raw, kin, n, n_rows, shift, bits, w.hist, nb, err_flag)
+  if (raw_mode == 2) HIST(2);
+  else if (raw_mode == 1) HIST(1);
+  else HIST(0);
+#undef HIST
   RX_LAUNCH_CHECK();
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.hist, entries, w.tiles);
   RX_LAUNCH_CHECK();
@@ -416,13 +521,55 @@ static int sort_pass(const SortWs& w, const int64_t* raw_idx, int64_t n_rows, in
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
     RX_LAUNCH_CHECK();
   }
-#define SCATTER(RAWV, FOLDV, KEYS) \
-  hipLaunchKernelGGL((sort_scatter_kernel<RAWV, FOLDV>), dim3(nb), dim3(RX_BLOCK), sl, st, (const void*)(KEYS), vin, n, n_rows, shift, bits, w.hist, w.tiles, n_tiles, nb, kout, vout)
-  if (raw_idx && fold) SCATTER(true, true, raw_idx);
-  else if (raw_idx) SCATTER(true, false, raw_idx);
-  else if (fold) SCATTER(false, true, kin);
-  else SCATTER(false, false, kin);
+#define SCATTER(RAWV, FOLDV) \
+  hipLaunchKernelGGL((sort_scatter_kernel<RAWV, FOLDV>), dim3(nb), dim3(RX_BLOCK), sl, st, raw, kin, vin, n, n_rows, shift, bits, w.hist, w.tiles, n_tiles, nb, kout, vout)
+  if (raw_mode == 2) { if (fold) SCATTER(2, true); else SCATTER(2, false); }
+  else if (raw_mode == 1) { if (fold) SCATTER(1, true); else SCATTER(1, false); }
+  else { if (fold) SCATTER(0, true); else SCATTER(0, false); }
 #undef SCATTER
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// rows given by `raw` (mode 1 or 2) -> sorted positions, distinct rows, run offsets
+static int sort_dedup_run(const RawSrc& raw, int raw_mode, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
+                          int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
+                          int32_t* d_inverse, void* ws, int32_t* err_flag, hipStream_t st) {
+  RX_REQUIRE(((uintptr_t)ws & 15) == 0, "sort workspace must be 16-byte aligned");
+  SortWs w = sort_ws_layout(ws, n);
+  int passes, bits;
+  sort_plan(n_rows, &passes, &bits);
+
+  uint32_t *kin = w.ka, *kout = w.kb, *vin = w.va, *vout = w.vb;
+  for (int p = 0; p < passes; ++p) {
+    if (sort_pass(w, raw, p == 0 ? raw_mode : 0, n_rows, err_flag, kin, vin, kout, vout, n, p * bits, bits, true, st)) return 1;
+    uint32_t* t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  const int ndb = (int)rx_cdiv(n, DEDUP_TILE);
+  hipLaunchKernelGGL(dedup_count_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, n, w.counts);
+  RX_LAUNCH_CHECK();
+  if (ndb <= SCAN_FOLD_MAX) {
+    // few block counts: every block of the write kernel scans them itself
+    hipLaunchKernelGGL(dedup_write_kernel<true>, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, vin, n, w.counts, ndb, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, d_sorted_slot);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  if (ndb <= (1 << 18)) {
+    // few enough block counts for one block to scan in place
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.counts, (int64_t)ndb);
+    RX_LAUNCH_CHECK();
+  } else {
+    // tiles in place + totals, then fold the totals back in
+    const int n_tiles = (int)rx_cdiv(ndb, SCAN_TILE);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(add_tile_offsets_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
+    RX_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(dedup_write_kernel<false>, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, vin, n, w.counts, ndb, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, d_sorted_slot);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -443,36 +590,42 @@ extern "C" int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, in
   }
   RX_REQUIRE(d_idx && d_sorted_pos && d_uniq_rows && ws, "rx_sort_dedup: null argument");
   RX_REQUIRE(ws_bytes >= rx_sort_dedup_workspace_bytes(n), "rx_sort_dedup: workspace %zu < %zu bytes", ws_bytes, rx_sort_dedup_workspace_bytes(n));
-  SortWs w = sort_ws_layout(ws, n);
-  int passes, bits;
-  sort_plan(n_rows, &passes, &bits);
+  RawSrc raw = {};
+  raw.idx = d_idx;
+  return sort_dedup_run(raw, 1, n, n_rows, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, ws, err_flag, st);
+}
 
-  uint32_t *kin = w.ka, *kout = w.kb, *vin = w.va, *vout = w.vb;
-  for (int p = 0; p < passes; ++p) {
-    if (sort_pass(w, p == 0 ? d_idx : nullptr, n_rows, err_flag, kin, vin, kout, vout, n, p * bits, bits, true, st)) return 1;
-    uint32_t* t = kin; kin = kout; kout = t;
-    t = vin; vin = vout; vout = t;
+extern "C" int rx_sort_dedup_fm(const rx_fm_args* a, int32_t* d_sorted_pos, int32_t* d_sorted_slot,
+                                int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq, int32_t* d_inverse,
+                                void* ws, size_t ws_bytes, int32_t* err_flag, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(a && a->B >= 0 && a->F >= 1 && a->N >= 1, "rx_sort_dedup_fm: bad shape");
+  RX_REQUIRE(a->ex_idx && a->ex_base && a->item_idx, "rx_sort_dedup_fm: null index pointer");
+  RX_REQUIRE(a->ex_ld >= a->F && a->item_ld >= a->N, "rx_sort_dedup_fm: index row strides smaller than F / N");
+  const int64_t n = a->B * ((int64_t)a->F + a->N);
+  const int64_t n_rows = a->n_feat;
+  RX_REQUIRE(n < (1ll << 31), "rx_sort_dedup_fm: n=%lld outside [0, 2^31)", (long long)n);
+  RX_REQUIRE(n_rows >= 1 && n_rows <= (1ll << 32), "rx_sort_dedup_fm: n_rows=%lld outside [1, 2^32]", (long long)n_rows);
+  RX_REQUIRE(d_seg_off && d_n_uniq, "rx_sort_dedup_fm: null output");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    RX_HIP(hipMemsetAsync(d_n_uniq, 0, sizeof(int32_t), st));
+    RX_HIP(hipMemsetAsync(d_seg_off, 0, sizeof(int32_t), st));
+    return 0;
   }
-  const int ndb = (int)rx_cdiv(n, DEDUP_TILE);
-  hipLaunchKernelGGL(dedup_count_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, n, w.counts);
-  RX_LAUNCH_CHECK();
-  if (ndb <= (1 << 18)) {
-    // few enough block counts for one block to scan in place
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.counts, (int64_t)ndb);
-    RX_LAUNCH_CHECK();
-  } else {
-    // tiles in place + totals, then fold the totals back in
-    const int n_tiles = (int)rx_cdiv(ndb, SCAN_TILE);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
-    RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, st, w.tiles, (int64_t)n_tiles);
-    RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(add_tile_offsets_kernel, dim3(n_tiles), dim3(RX_BLOCK), 0, st, w.counts, (int64_t)ndb, w.tiles);
-    RX_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(dedup_write_kernel, dim3(ndb), dim3(RX_BLOCK), 0, st, kin, vin, n, w.counts, ndb, d_sorted_pos, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, d_sorted_slot);
-  RX_LAUNCH_CHECK();
-  return 0;
+  RX_REQUIRE(d_sorted_pos && d_uniq_rows && ws, "rx_sort_dedup_fm: null argument");
+  RX_REQUIRE(ws_bytes >= rx_sort_dedup_workspace_bytes(n), "rx_sort_dedup_fm: workspace %zu < %zu bytes", ws_bytes, rx_sort_dedup_workspace_bytes(n));
+  RawSrc raw = {};
+  raw.ex_idx = a->ex_idx;
+  raw.ex_base = a->ex_base;
+  raw.item_idx = a->item_idx;
+  raw.ex_ld = a->ex_ld;
+  raw.item_ld = a->item_ld;
+  raw.item_base = a->item_base;
+  raw.n_ex = (uint32_t)(a->B * a->F);
+  raw.F = (uint32_t)a->F;
+  raw.N = (uint32_t)a->N;
+  return sort_dedup_run(raw, 2, n, n_rows, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, ws, err_flag, st);
 }
 
 // ---------------------------------------------------------------- bucketise by owning rank
@@ -545,7 +698,7 @@ extern "C" int rx_bucketize_by_owner(const int64_t* d_idx, int64_t n, const int3
   while ((1 << bits) < G + 1) ++bits;  // one spare bin so that bin G marks the end of bin G-1
   hipLaunchKernelGGL(owner_init_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, n, d_n_valid, G, n_rows_global, w.ka, w.va, err_flag);
   RX_LAUNCH_CHECK();
-  if (sort_pass(w, nullptr, n_rows_global, err_flag, w.ka, w.va, w.kb, w.vb, n, 0, bits, false, st)) return 1;
+  if (sort_pass(w, RawSrc{}, 0, n_rows_global, err_flag, w.ka, w.va, w.kb, w.vb, n, 0, bits, false, st)) return 1;
   const int64_t work = n > G ? n : G;
   hipLaunchKernelGGL(owner_finish_kernel, dim3((unsigned)rx_cdiv(work, RX_BLOCK)), dim3(RX_BLOCK), 0, st, d_idx, w.vb, n, G, n_rows_global, w.hist, w.tiles, nb, d_counts, d_send_local, d_perm);
   RX_LAUNCH_CHECK();

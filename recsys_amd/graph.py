@@ -14,6 +14,12 @@ instead of sitting on its critical path.  Every replay still performs exactly on
 replays must then follow the cyclic slot order 0, 1, ..., K-1, 0, ... (``copy_batch`` of slot i+1 has
 to happen before slot i is replayed).
 
+``cycle=True`` additionally records ONE graph holding a whole round over the resident batches
+(slots 0..K-1 in order).  Replaying it (``run_cycle``) removes the host's launch gap between steps,
+and the index preparation runs ahead freely on its side stream: step i only waits for the
+preparation of slot i, and the preparation of slot 0 for the next round waits for this round's
+step 0.  A round must start when slot 0 is next in the cyclic order.
+
 Limits: the batch tensors are captured by address, so a graph is tied to its batch object
 (``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place);
 ``dense_kind="adam"`` bakes the step count into the recording and is refused.
@@ -29,7 +35,7 @@ from .autograd import backward_from_loss
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False):
+    def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False):
         if getattr(optimizer, "dense_kind", None) == "adam" and optimizer.dense:
             raise ValueError("dense Adam keeps its step count on the host and cannot be captured")
         self.model, self.opt, self.warmup = model, optimizer, warmup
@@ -38,7 +44,9 @@ class GraphedTrainStep:
         self.losses: List[torch.Tensor] = []
         self._pool = None
         self.pipeline = pipeline
-        self._finalized = False
+        self.cycle = cycle
+        self.cycle_graph = None
+        self.cycle_losses: List[torch.Tensor] = []
 
     def _eager(self, batch):
         self.opt.zero_grad()
@@ -83,6 +91,42 @@ class GraphedTrainStep:
             self.graphs.append(g)
             self.batches.append(b)
             self.losses.append(loss)
+        if self.cycle:
+            self._record_cycle(prepared, dev)
+
+    def _record_cycle(self, prepared, dev) -> None:
+        K = len(prepared)
+        g = torch.cuda.CUDAGraph()
+        self.opt.zero_grad()
+        with torch.cuda.graph(g, pool=self._pool):
+            main = torch.cuda.current_stream(dev)
+            fork = torch.cuda.Stream(device=dev)
+            fork.wait_stream(main)
+            ready = None          # preparation of the slot the next step consumes
+            step0_done = None
+            for i, b in enumerate(prepared):
+                if ready is not None:
+                    main.wait_event(ready)
+                nxt = (i + 1) % K
+                with torch.cuda.stream(fork):
+                    if nxt == 0:
+                        fork.wait_event(step0_done)   # slot 0's sort result was read by this round's step 0
+                    self.model.prepare(prepared[nxt], out=prepared[nxt])
+                    ready = torch.cuda.Event()
+                    ready.record(fork)
+                self.cycle_losses.append(self._eager(b))
+                if i == 0:
+                    step0_done = torch.cuda.Event()
+                    step0_done.record(main)
+            main.wait_stream(fork)
+        self.cycle_graph = g
+
+    def run_cycle(self) -> List[torch.Tensor]:
+        """One step on every resident batch, slots 0..K-1 in order, as a single graph launch."""
+        if self.cycle_graph is None:
+            raise RuntimeError("no cycle graph: construct with pipeline=True, cycle=True and >= 2 batches")
+        self.cycle_graph.replay()
+        return self.cycle_losses
 
     def add_batch(self, batch: Dict[str, torch.Tensor]) -> int:
         """Record one graph bound to ``batch``'s tensors.  Before the first recording the step is

@@ -47,12 +47,11 @@ class _FieldTable(HotPathModule):
         ex, base, item, item_base = self._split(inputs)
         feat = self.feature_embedding.weight
         old = out.get("_rx_presort") if out is not None else None
-        flat = ops.fm2_flat_indices(feat, ex, base, item, item_base, out=old.flat if old else None)
-        si = ops.sort_dedup(flat, feat.shape[0], out=old.si if old else None)
+        si = ops.fm_sort_dedup(feat, ex, base, item, item_base, out=old.si if old else None)
         if out is not None and old is not None:
             return out
         prepared = dict(inputs)
-        prepared["_rx_presort"] = rxa.Presort(flat, si)
+        prepared["_rx_presort"] = rxa.Presort(si)
         return prepared
 
 

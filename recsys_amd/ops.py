@@ -375,6 +375,13 @@ def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base: int, se
     return occ, bias_occ
 
 
+def wall_clock(slot: Tensor) -> None:
+    """Writes the device wall clock (10 ns ticks) into the one-element int64 tensor ``slot`` in
+    stream order (rx_wall_clock); usable inside a captured graph."""
+    _req(slot, torch.int64, "slot")
+    check(lib.rx_wall_clock(_p(slot), _dev(slot), _stream(slot)), "rx_wall_clock")
+
+
 def fm2_flat_indices(feat, ex_idx, ex_base, item_idx, item_base: int, out: Optional[Tensor] = None) -> Tensor:
     a, B, F, N = _fm_args(feat, None, ex_idx, ex_base, item_idx, item_base)
     flat = out if out is not None else torch.empty(B * (F + N), dtype=torch.int64, device=feat.device)
@@ -440,6 +447,26 @@ def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False, out: Option
     check(lib.rx_sort_dedup(_p(flat), n, n_rows, _p(sorted_pos), _p(sorted_slot), _p(uniq), _p(seg), _p(nu),
                             _p(inv), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(idx), _stream(idx)), "rx_sort_dedup")
     return out if out is not None else SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
+
+
+def fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base: int, out: Optional[SortedIndex] = None) -> SortedIndex:
+    """sort_dedup(fm2_flat_indices(...)) without materialising the flat list (rx_sort_dedup_fm)."""
+    a, B, F, N = _fm_args(feat, None, ex_idx, ex_base, item_idx, item_base)
+    n, n_rows, dev = B * (F + N), feat.shape[0], feat.device
+    if out is not None:
+        if out.n != n or out.n_rows != n_rows:
+            raise ValueError("fm_sort_dedup: `out` was made for a different batch shape")
+        sorted_pos, sorted_slot, uniq, seg, nu = out.sorted_pos, out.sorted_slot, out.uniq_rows, out.seg_off, out.n_uniq
+    else:
+        sorted_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        sorted_slot = torch.empty(n, dtype=torch.int32, device=dev)
+        uniq = torch.empty(n, dtype=torch.int64, device=dev)
+        seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        nu = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _ws(int(lib.rx_sort_dedup_workspace_bytes(n)), dev)
+    check(lib.rx_sort_dedup_fm(C.byref(a), _p(sorted_pos), _p(sorted_slot), _p(uniq), _p(seg), _p(nu), None,
+                               _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(feat), _stream(feat)), "rx_sort_dedup_fm")
+    return out if out is not None else SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, None)
 
 
 def segreduce_grid(n: int, dim: int) -> int:

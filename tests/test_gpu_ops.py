@@ -61,7 +61,8 @@ def test_empty_batch(ops):
 
 # ------------------------------------------------------------------ sort / dedup
 @pytest.mark.parametrize("n,n_rows", [(1, 1), (5, 3), (64, 7), (1000, 50), (4096, 4096), (4097, 100000),
-                                      (70001, 6040), (300000, 33_000_000), (200000, 2**32)])
+                                      (70001, 6040), (300000, 33_000_000), (200000, 2**32),
+                                      (2047, 9), (2048, 2000), (2049, 5), (2_100_003, 33_000_000)])
 def test_sort_dedup_bit_exact(ops, n, n_rows):
     g = _gen(n)
     if n_rows > 2**31:
@@ -81,6 +82,28 @@ def test_sort_dedup_bit_exact(ops, n, n_rows):
     assert torch.equal(seg[1:] - seg[:-1], counts)
     assert int(seg[0]) == 0 and int(seg[-1]) == n
     assert torch.equal(si.inverse.cpu().long(), inv)
+    assert torch.equal(si.sorted_slot.cpu().long(), inv[exp_pos])
+
+
+@pytest.mark.parametrize("B,F,N,pad", [(1, 1, 1, 0), (77, 3, 1, 2), (5000, 25, 1, 0), (3001, 7, 4, 1)])
+def test_fm_sort_dedup_equals_sort_of_flat_list(ops, B, F, N, pad):
+    # keys read straight from the index matrices (strided views included) == sorting the flat list
+    g = _gen(B + F)
+    dims = [int(x) for x in torch.randint(1, 70000, (F + 1,), generator=g)]
+    base = torch.tensor([sum(dims[:f]) for f in range(F)]).cuda()
+    item_base, n_feat = sum(dims[:F]), sum(dims)
+    both = torch.stack([torch.randint(0, d, (B,), generator=g) for d in dims[:F]] +
+                       [torch.randint(0, dims[F], (B,), generator=g) for _ in range(N + pad)], 1).cuda()
+    ex, item = both[:, :F], both[:, F:F + N]
+    feat = torch.zeros(n_feat, 4).cuda()
+    a = ops.fm_sort_dedup(feat, ex, base, item, item_base)
+    b = ops.sort_dedup(ops.fm2_flat_indices(feat, ex, base, item, item_base), n_feat)
+    nu = int(a.n_uniq.item())
+    assert nu == int(b.n_uniq.item())
+    for x, y in ((a.sorted_pos, b.sorted_pos), (a.sorted_slot, b.sorted_slot), (a.uniq_rows[:nu], b.uniq_rows[:nu]),
+                 (a.seg_off[: nu + 1], b.seg_off[: nu + 1])):
+        assert torch.equal(x, y)
+    ops.raise_if_index_error()
 
 
 def test_sort_dedup_is_deterministic(ops):

@@ -147,6 +147,50 @@ def test_pipelined_graph_with_presorted_indices_matches_eager_bitwise(name):
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("name", ["FieldFM", "NeuMF"])
+def test_round_graph_matches_eager_bitwise(name):
+    """One graph holding a whole round over 3 resident batches (index sorts running ahead on the
+    side stream), mixed with single-step replays: same weights, bit for bit, as eager steps."""
+    from recsys_amd import ops, synthetic
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.models.fields import FieldFM
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    dims = [7, 1000, 13, 5000, 3, 211]
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(6)
+        with torch.device("cuda"):
+            m = FieldFM(dims, 16) if name == "FieldFM" else NeuMF(d["n_users"], d["n_items"], 16, dropout=0.0)
+        m.train()
+        if name == "FieldFM":
+            batches = [synthetic.criteo_batch(dims, 300, seed=40 + i, device="cuda") for i in range(3)]
+        else:
+            batches = [synthetic.ml1m_batch(256, seed=20 + i, device="cuda") for i in range(3)]
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True, cycle=True)
+                gs.add_batches(batches)
+                gs(0); gs(1); gs(2)                 # single-step graphs
+                gs.run_cycle(); gs.run_cycle()      # two rounds
+                gs(0)                               # and back
+                loss = gs.losses[0]
+            else:
+                for i in [0, 0] + [0, 1, 2] * 3 + [0]:
+                    opt.zero_grad(); loss = m.loss(batches[i]); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_sharded_fm_one_rank_through_rccl():
     """A one-rank process group on the nccl (RCCL) backend with the collectives forced on: the
     all-to-all calls, their split-size handling and dtypes run for real on the GPU, and the step
