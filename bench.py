@@ -49,8 +49,11 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         # tables row-sharded over the ranks (row r on rank r % G), batch data parallel, index / row /
         # gradient exchange by all-to-all; per-GPU batch fixed (weak scaling)
         from recsys_amd.sharded import ShardedFieldFM
-        dims = synthetic.criteo_field_dims()
-        B, D = 65536, 16
+        # weak scaling towards the 1 B-row x 128 configuration: 125 M rows (64 GB of fp32 rows) per GPU,
+        # same cardinality profile; at 8 GPUs the tables total 1.0 B rows
+        rows_per_gpu = int(os.environ.get("RX_BENCH_SHARDED_ROWS", 125_000_000))
+        dims = synthetic.criteo_field_dims(total_rows=rows_per_gpu * world)
+        B, D = 65536, int(os.environ.get("RX_BENCH_SHARDED_DIM", 128))
         model = ShardedFieldFM(dims, D, device)
         model.set_rule("sgd", 0.05)
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
@@ -69,7 +72,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
                 pass
 
         # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
-        return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world)
+        return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
     if name in ("fm_criteo", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
         B, D = 65536, 16
@@ -338,7 +341,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo",
+    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_criteo_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
@@ -428,13 +431,14 @@ def main():
         rho = 1.0
         if "fields" in w["desc"]:
             from recsys_amd import synthetic
-            rho = unique_fraction(w["batches"], synthetic.criteo_field_dims())
+            rho = unique_fraction(w["batches"], w.get("dims") or synthetic.criteo_field_dims())
         ab = algo_bytes(w["desc"], dominant, rho)
         if ab:
             ach = ab / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dominant, "kernels": OP_KERNELS.get(dominant), "achieved": ach,
+            roof = {"bound": "hbm", "kernel": dominant,
+                    "kernels": OP_KERNELS.get(dominant) if w["desc"].get("dim") == 16 else None, "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": measured_traffic(dominant), "avg_us": ms * 1e3, "launches_timed": cnt,
+                    "traffic": measured_traffic(dominant) if args.workload == "fm_criteo" else None, "avg_us": ms * 1e3, "launches_timed": cnt,
                     "algorithmic_bytes_per_launch": ab, "distinct_row_fraction": rho}
     out["roofline"] = roof
     del w
@@ -447,6 +451,9 @@ def main():
             w2, el2, _, _ = run(name, 30, 5)
             entry = {"workload": name, "samples_per_s": w2["B"] * 30 / el2, "ms_per_step": 1e3 * el2 / 30,
                      "dtype": workload_dtype(name)}
+            if name == "fm_criteo_sharded":
+                # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
+                entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")
             fl = dense_flops_per_sample(name)
             if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
                 entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12

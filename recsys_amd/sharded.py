@@ -47,7 +47,9 @@ class ShardedTable:
             self.weight = full_weight[self.rank::self.G].to(self.device).contiguous().float()
         else:
             g = torch.Generator(device=self.device).manual_seed(seed * 1000 + self.rank)
-            self.weight = torch.randn(self.local_rows, dim, device=self.device, generator=g) * init_std
+            self.weight = torch.randn(self.local_rows, dim, device=self.device, generator=g)
+            if init_std != 1.0:
+                self.weight.mul_(init_std)      # in place: the table may take a good part of the HBM
         # run the collectives even with one rank (exercises the RCCL calls on a one-GPU machine)
         self.force_exchange = False
         self.grad: Optional[torch.Tensor] = None      # dense local gradient (when no rule is set)

@@ -131,3 +131,59 @@ def test_fused_step_matches_dense_restatement_full_size(setup):
     assert torch.equal(w1[~touched], w0[~touched]) and torch.equal(b1[~touched], b0[~touched]), "untouched rows moved"
     assert_close(w1[touched].cpu().numpy(), wr.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated rows")
     assert_close(b1[touched].cpu().numpy(), br.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated bias rows")
+
+
+def test_fused_step_on_table_beyond_2G_elements():
+    """A table whose element count passes 2^31 (18 M rows x 128 floats = 9.2 GB): rows at the very
+    end of the table are gathered, reduced and updated at 64-bit offsets.  Reference: the same step
+    on the compacted set of touched rows with plain torch ops (renumbering rows changes nothing)."""
+    from recsys_amd import ops
+    from recsys_amd.models import fields
+    from recsys_amd.optim import FusedOptimizer
+    ops.set_index_check("sync")
+    dev = torch.device("cuda", 0)
+    dims, Dw, Bs = [9_000_000, 50, 9_000_000], 128, 4096
+    assert sum(dims) * Dw > 2**31
+    g = torch.Generator().manual_seed(11)
+    cols = []
+    for d in dims:
+        hi = torch.randint(max(d - 3000, 0), d, (Bs,), generator=g)        # the last rows of every field
+        lo = torch.randint(0, d, (Bs,), generator=g)
+        cols.append(torch.where(torch.rand(Bs, generator=g) < 0.7, hi, lo))
+    sparse = torch.stack(cols, 1)
+    sparse[0, 2] = dims[2] - 1                                              # the table's very last row
+    batch = {"sparse": sparse.to(dev), "label": (torch.rand(Bs, 1, generator=g) < 0.25).double().to(dev)}
+    torch.manual_seed(3)
+    with torch.device(dev):
+        m = fields.FieldFM(dims, Dw)
+    w0, b0 = m.feature_embedding.weight.detach().clone(), m.bias_embedding.weight.detach().clone()
+    offs = torch.tensor([0] + dims[:-1], device=dev).cumsum(0)
+    idx = batch["sparse"] + offs[None, :]
+    uniq, inv = torch.unique(idx, return_inverse=True)
+    wc, bc = w0[uniq].clone().requires_grad_(True), b0[uniq].clone().requires_grad_(True)
+    e = wc[inv]
+    s = e.sum(1)
+    logits = bc[inv].sum(1) + 0.5 * (s * s - (e * e).sum(1)).sum(-1, keepdim=True)
+    loss_ref = torch.nn.functional.binary_cross_entropy_with_logits(logits, batch["label"])
+    loss_ref.backward()
+    tn = torch.nn.utils.clip_grad_norm_([wc, bc], 1.0)
+    lr = 0.05
+    with torch.no_grad():
+        wc -= lr * wc.grad
+        bc -= lr * bc.grad
+    opt = FusedOptimizer(m, kind="sgd", lr=lr, clip_norm=1.0)
+    m.train()
+    opt.zero_grad()
+    loss = m.loss(batch)
+    loss.backward()
+    opt.step()
+    assert_close(loss.item(), loss_ref.item(), rtol=1e-6, what="loss")
+    assert_close(opt.last_total_norm.item(), tn.item(), rtol=1e-5, what="global gradient norm")
+    w1, b1 = m.feature_embedding.weight.detach(), m.bias_embedding.weight.detach()
+    moved = (w1 != w0).any(1) | (b1 != b0).any(1)
+    touched = torch.zeros(sum(dims), dtype=torch.bool, device=dev)
+    touched[uniq] = True
+    assert not (moved & ~touched).any(), "untouched rows moved"
+    assert moved[sum(dims) - 1], "the last row was not updated"
+    assert_close(w1[uniq].cpu().numpy(), wc.detach().cpu().numpy(), rtol=1e-5, what="updated rows")
+    assert_close(b1[uniq].cpu().numpy(), bc.detach().cpu().numpy(), rtol=1e-5, what="updated bias rows")
