@@ -73,11 +73,14 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
 
         # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
         return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
-    if name in ("fm_criteo", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
+    if name in ("fm_criteo", "fm_wide_d128", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
         B, D = 65536, 16
-        cls = {"fm_criteo": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM, "deepfm_criteo_bf16": fields.FieldDeepFM,
-               "dcnv2_criteo": fields.DCNv2}[name]
+        if name == "fm_wide_d128":
+            # one GPU's share of the 1 B-row x 128 configuration, unsharded: 125 M rows of 512 bytes (64 GB)
+            dims, D = synthetic.criteo_field_dims(total_rows=125_000_000), 128
+        cls = {"fm_criteo": fields.FieldFM, "fm_wide_d128": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM,
+               "deepfm_criteo_bf16": fields.FieldDeepFM, "dcnv2_criteo": fields.DCNv2}[name]
         with torch.device(device):
             model = cls(dims, D, bf16=True) if name == "deepfm_criteo_bf16" else cls(dims, D)
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
@@ -100,7 +103,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         raise SystemExit(f"unknown workload {name}")
     model.train()
     opt = FusedOptimizer(model, kind="sgd", lr=lr, clip_norm=clip)
-    w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None)
+    w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None, dims=dims if "fields" in desc else None)
     if use_graph:
         from recsys_amd.graph import GraphedTrainStep
         gs = GraphedTrainStep(model, opt, pipeline=True, cycle=True)
@@ -232,7 +235,7 @@ def algo_bytes(desc, op, rho=1.0):
     the per-sample figures are fwd F(8 + De) + 4, bwd 4 + F De + 8F, update rho F 2 De, with
     F fields, D columns, e = 4 bytes and rho the measured distinct-row fraction."""
     B, D = desc["batch_per_gpu"], desc["dim"]
-    if desc["workload"] in ("fm_criteo", "fm_criteo_sharded", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
+    if desc["workload"] in ("fm_criteo", "fm_wide_d128", "fm_criteo_sharded", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         F = desc["fields"]
         if op == "fm2_fwd":  # index + row + bias entry per field, one logit out
             return B * (F * (8 + 4 * D + 4) + 4)
@@ -245,6 +248,14 @@ def algo_bytes(desc, op, rho=1.0):
         if op == "row_update":  # compact gradient in, row in, row out
             return rho * B * F * 3 * 4 * D
     return None
+
+
+def embedding_bytes_per_sample(desc, rho):
+    """Algorithmic HBM bytes of the embedding work of one sample over the whole step (fp32, plain SGD,
+    N = 1, a D = 1 bias table beside the D-wide one): fwd F(8 + 4D + 4) + 4, bwd 4 + 4FD + 8F,
+    update rho F 2 (4D + 4)."""
+    F, D = desc["fields"], desc["dim"]
+    return F * (8 + 4 * D + 4) + 4 + 4 + 4 * F * D + 8 * F + rho * F * 2 * (4 * D + 4)
 
 
 def workload_dtype(name):
@@ -341,7 +352,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_criteo_sharded",
+    ap.add_argument("--extra", default="mf_ml1m,neumf_ml1m,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
@@ -403,7 +414,7 @@ def main():
             print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
         del w
 
-    dominant = {"fm_criteo": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm", "deepfm_criteo": "linear_bwd_w",
+    dominant = {"fm_criteo": "segreduce_fm", "fm_wide_d128": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm", "deepfm_criteo": "linear_bwd_w",
                 "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
@@ -426,12 +437,12 @@ def main():
         "final_loss": last_loss,
     }
     roof = None
+    rho = 1.0
+    if "fields" in w["desc"]:
+        from recsys_amd import synthetic
+        rho = unique_fraction(w["batches"], w.get("dims") or synthetic.criteo_field_dims())
     if dominant in ops_ms:
         ms, cnt = ops_ms[dominant]
-        rho = 1.0
-        if "fields" in w["desc"]:
-            from recsys_amd import synthetic
-            rho = unique_fraction(w["batches"], w.get("dims") or synthetic.criteo_field_dims())
         ab = algo_bytes(w["desc"], dominant, rho)
         if ab:
             ach = ab / (ms * 1e-3) / 1e9
@@ -441,6 +452,11 @@ def main():
                     "traffic": measured_traffic(dominant) if args.workload == "fm_criteo" else None, "avg_us": ms * 1e3, "launches_timed": cnt,
                     "algorithmic_bytes_per_launch": ab, "distinct_row_fraction": rho}
     out["roofline"] = roof
+    if args.workload in ("fm_criteo", "fm_wide_d128", "fm_criteo_sharded"):
+        bps = embedding_bytes_per_sample(w["desc"], rho)
+        out["embedding_hbm"] = {"algorithmic_bytes_per_sample": bps, "achieved": bps * value / world / 1e9, "unit": "GB/s per GPU",
+                                "peak": HBM_PEAK_GBS, "frac": bps * value / world / 1e9 / HBM_PEAK_GBS,
+                                "note": "whole step (fwd + bwd + update), all kernels, at the measured distinct-row fraction"}
     del w
     torch.cuda.empty_cache()
 
@@ -451,6 +467,11 @@ def main():
             w2, el2, _, _ = run(name, 30, 5)
             entry = {"workload": name, "samples_per_s": w2["B"] * 30 / el2, "ms_per_step": 1e3 * el2 / 30,
                      "dtype": workload_dtype(name)}
+            if name in ("fm_wide_d128", "fm_criteo_sharded"):
+                r2 = unique_fraction(w2["batches"], w2["dims"])
+                b2 = embedding_bytes_per_sample(w2["desc"], r2)
+                entry["embedding_hbm_frac"] = b2 * entry["samples_per_s"] / 1e9 / HBM_PEAK_GBS
+                entry["distinct_row_fraction"] = r2
             if name == "fm_criteo_sharded":
                 # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
                 entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")

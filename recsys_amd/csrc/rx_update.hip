@@ -499,7 +499,36 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
-    for (int q = s; q < np; q += slots) {
+    // A hot row's run spans hundreds of pieces and one wavefront walks them all: while whole rounds
+    // of U pieces per lane slot remain, U partials are fetched together (independent loads in
+    // flight) and then added in the order of the walk; the rest goes one piece at a time.
+    constexpr int U = CH == 1 ? 8 : (CH == 2 ? 4 : 2);
+    int q = s;
+    for (int round = np / (slots * U); round > 0; --round, q += slots * U) {
+      RxPack<VEC> v[U][CH];
+      float p2[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int qj = q + j * slots;
+        const int64_t e = (piece + qj) * 2 + (qj == 0 ? 1 : 0);
+        const float* src = a.partials + e * (int64_t)dim;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int c = (lg + k * group) * VEC;
+          v[j][k] = c < dim ? rx_load<VEC>(src + c) : rx_zero<VEC>();
+        }
+        p2[j] = (keep2 && lg == 0) ? a.partials2[e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v[j][k].v[i];
+        g2 += p2[j];
+      }
+    }
+    for (; q < np; q += slots) {
       const int64_t e = (piece + q) * 2 + (q == 0 ? 1 : 0);
       const float* src = a.partials + e * (int64_t)dim;
 #pragma unroll
