@@ -165,8 +165,13 @@ def segreduce_fm(tsum, g, n_fields_ex, si, mode, target, *, table=None, state=No
     rows = si.uniq_rows[:nu]
     src = table if table is not None else target
     G = G - gs[:, None] * src[rows]
+    if mode == _lib.RX_SEG_DENSE:
+        target[rows] = G
+        if target2 is not None:
+            target2.reshape(-1)[rows] = gs
+        return None
     if mode != _lib.RX_SEG_COMPACT:
-        raise NotImplementedError("the CPU stand-in covers the compact mode the sharded path uses")
+        raise NotImplementedError("the CPU stand-in covers the compact and dense modes the sharded path uses")
     target[:nu] = G
     if target2 is not None:
         target2.reshape(-1)[:nu] = gs

@@ -126,6 +126,21 @@ class ShardedTable:
         back = self._from_owners(mine, plan)
         return self.ops.unpermute_rows(back, plan["perm"])
 
+    def gather_packed(self, plan) -> torch.Tensor:
+        """Fixed-capacity plans only: the requested rows as they arrive, [G * capacity, dim], entry j
+        of the list sitting at row ``plan["src_of"][j]``.  Consumers that address rows through an
+        index anyway compose the two maps instead of paying for a reordering copy."""
+        seg = self.ops.Segment(self.weight, plan["recv_idx"], 0)
+        return self._swap(self.ops.gather_concat([seg], plan["recv_idx"].numel(), self.dim))
+
+    def reduce_packed(self, sent: torch.Tensor, plan, companion: Optional["ShardedTable"] = None,
+                      sent2: Optional[torch.Tensor] = None):
+        """Counterpart of gather_packed: ``sent`` [G * capacity, dim] holds one gradient row per slot
+        (zeros in unused slots), ``sent2`` [G * capacity] the companion table's."""
+        got = self._swap(sent)
+        got2 = self._swap(sent2.reshape(-1, 1)).reshape(-1) if companion is not None else None
+        self._owner_reduce(got, got2, plan, companion)
+
     def scatter_grad(self, occ: torch.Tensor, plan, companion: Optional["ShardedTable"] = None,
                      occ2: Optional[torch.Tensor] = None):
         """Send per-occurrence gradient rows (list order) to the owners and reduce / update there.
@@ -146,6 +161,11 @@ class ShardedTable:
             if companion is not None:
                 sent2 = self.ops.permute_rows(occ2.reshape(-1, 1).contiguous(), plan["perm"])
                 got2 = self._to_owners(sent2, plan).reshape(-1)
+        self._owner_reduce(got, got2, plan, companion)
+
+    def _owner_reduce(self, got, got2, plan, companion):
+        """What arrived from all ranks, one gradient row per received index: sort by local row, reduce
+        the duplicates in that fixed order, then accumulate (no rule) or update in place."""
         if got.shape[0] == 0:
             return
         si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
@@ -301,8 +321,19 @@ class _ShardedFM(torch.autograd.Function):
         n = flat.numel()
         si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
         if model.capacity:
-            plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity)   # nothing here waits for the host
-            nu = n                                                            # buffers sized by the upper bound
+            # nothing here waits for the host.  The rows stay in arrival (slot) order: occurrence ->
+            # distinct row -> slot is composed on the index side, 8 bytes per occurrence instead of a
+            # copy of every row
+            plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity)
+            rows_p, bias_p = feat.gather_packed(plan), bias.gather_packed(plan)
+            slot_of = plan["src_of"].to(torch.int64)
+            occ_slot = slot_of[si.inverse.to(torch.int64)]
+            base = model._zero_base(F, flat.device)
+            logits, _, tsum = ops.fm2_fwd(rows_p, bias_p.reshape(-1), occ_slot[:B * F].reshape(B, F), base,
+                                          occ_slot[B * F:].reshape(B, 1), 0, want_tsum=True)
+            ctx.model, ctx.plan, ctx.si, ctx.F, ctx.slot_of = model, plan, si, F, slot_of
+            ctx.save_for_backward(tsum, rows_p)
+            return logits
         else:
             plan = feat.plan(si.uniq_rows, si.n_uniq)    # padded list + device count; one host read inside
             nu = plan["n"]
@@ -313,15 +344,27 @@ class _ShardedFM(torch.autograd.Function):
         item = inv[B * F:].reshape(B, 1)
         base = model._zero_base(F, flat.device)
         logits, _, tsum = ops.fm2_fwd(rows_u, bias_u.reshape(-1), ex, base, item, 0, want_tsum=True)
-        ctx.model, ctx.plan, ctx.si, ctx.nu, ctx.F = model, plan, si, nu, F
+        ctx.model, ctx.plan, ctx.si, ctx.nu, ctx.F, ctx.slot_of = model, plan, si, nu, F, None
         ctx.save_for_backward(tsum, rows_u)
         return logits
 
     @staticmethod
     def backward(ctx, g):
         tsum, rows_u = ctx.saved_tensors
-        model, si, nu = ctx.model, ctx.si, ctx.nu
+        model, si = ctx.model, ctx.si
         ops, feat, bias = model.ops, model.feature, model.bias
+        if ctx.slot_of is not None:
+            # fixed capacity: distinct row u lives in slot slot_of[u] of the exchange buffers, and the
+            # reduce writes its gradient row straight into the send buffer's slot (unused slots stay 0)
+            n_slots = rows_u.shape[0]
+            by_slot = ops.SortedIndex(si.n, n_slots, si.sorted_pos, si.sorted_slot, ctx.slot_of, si.seg_off, si.n_uniq, None)
+            sent = torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=g.device)
+            sent2 = torch.zeros(n_slots, dtype=torch.float32, device=g.device)
+            ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, by_slot, _lib.RX_SEG_DENSE, sent, table=rows_u,
+                             target2=sent2)
+            feat.reduce_packed(sent, ctx.plan, bias, sent2)
+            return None, None, None, None, None
+        nu = ctx.nu
         # the received buffer is addressed by slot, so the reduce sees "row u = slot u"
         slots = ops.SortedIndex(si.n, max(nu, 1), si.sorted_pos, si.sorted_slot, model._iota(si.n, g.device), si.seg_off,
                                 si.n_uniq, None)
