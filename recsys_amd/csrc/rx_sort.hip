@@ -7,8 +7,10 @@
 //   scan    every block scans 2048 of the [digit][block] counts in place and publishes its total
 //   scatter first folds the scan of those totals into its prologue (they are few), then
 //           each wave ranks its 1024 keys stably: per key, `bits` ballots give the set of lanes
-//           with the same digit (a 64-lane "match"), the lowest such lane advances the wave's
-//           private digit counter, and every lane's rank is counter + popcount(lanes below).
+//           with the same digit (a 64-lane "match"; digit width is a compile-time constant there,
+//           all of a thread's keys are matched before any counter is touched), then key by key
+//           every lane of a group reads the wave's private digit counter, the lowest lane advances
+//           it, and the rank is counter + popcount(lanes below).
 //           Wave counters are prefixed across the block's 4 waves, so the final order is
 //           (block, wave, round, lane) = original order: the sort is stable by construction
 //           and uses no float or global atomics.
@@ -17,7 +19,7 @@
 #define SORT_MAX_BITS 11
 #define SORT_MAX_BINS (1 << SORT_MAX_BITS)
 #define SORT_ITEMS 16
-#define SORT_TILE (RX_BLOCK * SORT_ITEMS)  // 4096 keys per block
+#define SORT_TILE (RX_BLOCK * SORT_ITEMS)  // keys per block
 #define SORT_WAVES (RX_BLOCK / 64)
 #define SORT_WAVE_KEYS (64 * SORT_ITEMS)
 #define SCAN_TILE (RX_BLOCK * 8)           // entries of the count array per scan block
@@ -176,6 +178,27 @@ scan_totals_kernel(uint32_t* __restrict__ sums, int64_t count) {
   }
 }
 
+// For each of a thread's keys: the set of live lanes of the wavefront whose digit equals this
+// lane's (a 64-lane "match").  Per bit one ballot; sb is all ones where the lane's bit is set, so
+// (ballot ^ sb) marks the lanes whose bit differs from mine.
+template <int BITS>
+__device__ __forceinline__ void match_all(const uint32_t (&key)[SORT_ITEMS], int shift, int64_t wbase, int lane,
+                                          int64_t n, unsigned long long (&peers)[SORT_ITEMS]) {
+#pragma unroll
+  for (int it = 0; it < SORT_ITEMS; ++it) {
+    const bool live = (wbase + it * 64 + lane) < n;
+    const uint32_t d = (key[it] >> shift) & ((1u << BITS) - 1);
+    unsigned long long p = __ballot(live);
+#pragma unroll
+    for (int bit = 0; bit < BITS; ++bit) {
+      const int32_t sb = (int32_t)(d << (31 - bit)) >> 31;
+      const unsigned long long m = __ballot(sb != 0);
+      p &= ~(m ^ (unsigned long long)(long long)sb);
+    }
+    peers[it] = live ? p : 0ull;
+  }
+}
+
 // `tile_sums` are the totals published by scan_tiles_kernel.  FOLD: they are still unscanned and
 // at most SCAN_FOLD_MAX many, and every block scans them itself in LDS while its keys are in
 // flight, which saves a single-block launch per pass.  Otherwise they arrive scanned.
@@ -238,29 +261,26 @@ sort_scatter_kernel(RawSrc src, const uint32_t* __restrict__ keys_in, const uint
     }
   }
   __syncthreads();
+  // lanes (live ones) holding the same digit, for all of the thread's keys first: the ballot chains
+  // of different keys are independent and interleave
+  unsigned long long peers[SORT_ITEMS];
+  switch (bits) {  // wave-uniform; the digit width as a compile-time constant unrolls the match
+#define MATCH_CASE(B) case B: match_all<B>(key, shift, wbase, lane, n, peers); break;
+    MATCH_CASE(1) MATCH_CASE(2) MATCH_CASE(3) MATCH_CASE(4) MATCH_CASE(5) MATCH_CASE(6)
+    MATCH_CASE(7) MATCH_CASE(8) MATCH_CASE(9) MATCH_CASE(10) MATCH_CASE(11)
+#undef MATCH_CASE
+  }
+  // then the counters, key by key: every lane of a group reads the digit's counter (one LDS
+  // broadcast), the group's lowest lane advances it.  LDS operations of a wavefront execute in
+  // program order, so the next key's read sees this write.
 #pragma unroll
   for (int it = 0; it < SORT_ITEMS; ++it) {
-    const bool live = (wbase + it * 64 + lane) < n;
     const uint32_t d = (key[it] >> shift) & (bins - 1);
-    // lanes (live ones) holding the same digit
-    unsigned long long peers = __ballot(live);
-    for (int bit = 0; bit < bits; ++bit) {
-      const bool set = (d >> bit) & 1u;
-      const unsigned long long m = __ballot(set);
-      peers &= set ? m : ~m;
-    }
+    const unsigned long long p = peers[it];
     uint32_t base = 0;
-    if (live) {
-      const int leader = __ffsll((long long)peers) - 1;
-      if (lane == leader) {
-        base = my_cnt[d];
-        my_cnt[d] = base + (uint32_t)__popcll(peers);
-      }
-      base = __shfl(base, leader, 64);
-      rank[it] = base + (uint32_t)__popcll(peers & lt_mask);
-    } else {
-      rank[it] = 0;
-    }
+    if (p) base = my_cnt[d];
+    if (p && lane == __ffsll((long long)p) - 1) my_cnt[d] = base + (uint32_t)__popcll(p);
+    rank[it] = base + (uint32_t)__popcll(p & lt_mask);
   }
   __syncthreads();
   // per digit: exclusive prefix over the block's waves (tile-local), the tile's count, and the
