@@ -45,6 +45,32 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
 
     torch.manual_seed(1234)
     n_batches = 8
+    if name == "deepfm_criteo_sharded":
+        # the Criteo-shaped DeepFM with its tables row-sharded and its BatchNorm tower data parallel
+        # (tower gradients summed over the ranks by one all-reduce); 33 M rows x 16 per GPU
+        from recsys_amd.sharded import ShardedFieldDeepFM
+        dims = synthetic.criteo_field_dims(total_rows=33_000_000 * world)
+        B, D, lr = 65536, 16, 0.05
+        model = ShardedFieldDeepFM(dims, D, device)
+        model.set_rule("sgd", lr)
+        model.train()
+        if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
+            model.feature.force_exchange = model.bias.force_exchange = True
+        batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
+        cap = model.calibrate(batches)
+        desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
+                "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank; tower: all-reduce + dense SGD",
+                "clip_norm": None, "launch": f"eager, asynchronous ({cap} exchange slots per owner)"}
+
+        class _DeepOpt:
+            def zero_grad(self):
+                model.zero_dense_grads()
+
+            def step(self):
+                model.allreduce_dense_grads()
+                model.dense_sgd_step(lr)
+
+        return dict(model=model, opt=_DeepOpt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
     if name == "fm_criteo_sharded":
         # tables row-sharded over the ranks (row r on rank r % G), batch data parallel, index / row /
         # gradient exchange by all-to-all; per-GPU batch fixed (weak scaling)
@@ -270,7 +296,7 @@ def dense_flops_per_sample(name):
         return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
     if name == "dcnv2_criteo":
         return 6.0 * (3 * 432 * 432 + mlp([432, 1024, 512, 256, 1]))
-    if name in ("deepfm_criteo", "deepfm_criteo_bf16"):
+    if name in ("deepfm_criteo", "deepfm_criteo_bf16", "deepfm_criteo_sharded"):
         return 6.0 * mlp([432, 432, 216, 108, 1])
     if name == "neumf_ml1m":  # per (user, item) pair: MLP 128-64-32, GMF 64-32, head 64-1; 5 pairs per sample
         return 6.0 * 5 * (mlp([128, 64, 32]) + 64 * 32 + 64)
@@ -414,13 +440,14 @@ def main():
             print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
         del w
 
-    dominant = {"fm_criteo": "segreduce_fm", "fm_wide_d128": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm", "deepfm_criteo": "linear_bwd_w",
+    dominant = {"fm_criteo": "segreduce_fm", "fm_wide_d128": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm",
+                "deepfm_criteo_sharded": "linear_bwd_w", "deepfm_criteo": "linear_bwd_w",
                 "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
     if (world > 1 or force_dist) and args.workload == "fm_criteo":
         args.workload = "fm_criteo_sharded"
-    if args.workload == "fm_criteo_sharded":
+    if args.workload in ("fm_criteo_sharded", "deepfm_criteo_sharded"):
         use_graph = False
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
     if use_graph:

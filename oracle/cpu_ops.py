@@ -147,11 +147,20 @@ def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base, want_deep=False, s
     s = ex.sum(1, keepdim=True) + item
     q = (ex * ex).sum(1, keepdim=True) + item * item
     logits = b + 0.5 * (s * s - q).sum(-1)
-    return (logits, None, s[:, 0, :].contiguous()) if want_tsum else (logits, None)
+    deep = None
+    if want_deep:
+        B, F, D = ex.shape
+        cols = deep_cols if deep_cols is not None else (1 + F) * D
+        deep = torch.zeros(B, cols)
+        deep[:, :D] = item[:, 0, :]
+        deep[:, D:(1 + F) * D] = ex.reshape(B, F * D)
+        if extra is not None:
+            deep[:, (1 + F) * D:(1 + F) * D + extra.shape[1]] = extra
+    return (logits, deep, s[:, 0, :].contiguous()) if want_tsum else (logits, deep)
 
 
 def segreduce_fm(tsum, g, n_fields_ex, si, mode, target, *, table=None, state=None, target2=None, state2=None,
-                 lr=0.0, eps=0.0, scale=None, want_sq=False, sq_out=None):
+                 lr=0.0, eps=0.0, scale=None, want_sq=False, sq_out=None, deep=None):
     """G_r = sum_b g_b T_b - (sum_b g_b) e_r over the occurrences of row r; bias gradient sum_b g_b."""
     B = tsum.shape[0]
     split = B * n_fields_ex
@@ -165,6 +174,12 @@ def segreduce_fm(tsum, g, n_fields_ex, si, mode, target, *, table=None, state=No
     rows = si.uniq_rows[:nu]
     src = table if table is not None else target
     G = G - gs[:, None] * src[rows]
+    if deep is not None:
+        # the occurrence of extra field f adds its slice (1 + f) of the tower-input gradient, the item slice 0
+        D = tsum.shape[1]
+        field = torch.where(pos < split, 1 + pos % n_fields_ex, torch.zeros_like(pos))
+        per_occ = deep.reshape(B, -1)[:, :(1 + n_fields_ex) * D].reshape(B, 1 + n_fields_ex, D)[sample, field]
+        G = G + torch.zeros(nu, D).index_add_(0, slot, per_occ)
     if mode == _lib.RX_SEG_DENSE:
         target[rows] = G
         if target2 is not None:

@@ -293,13 +293,76 @@ class ShardedFieldFM(torch.nn.Module):
 
     def forward(self, inputs):
         sparse = inputs["sparse"]
-        return _ShardedFM.apply(self._anchor, self, self._flat(sparse), sparse.shape[0], self.n_fields - 1)
+        return _ShardedFM.apply(self._anchor, self, self._flat(sparse), sparse.shape[0], self.n_fields - 1)[0]
 
     def loss(self, inputs):
         if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
             return self.ops.bce_loss(self(inputs), inputs["label"])
         from .autograd import bce_with_logits
         return bce_with_logits(self(inputs), inputs["label"])
+
+
+class ShardedFieldDeepFM(ShardedFieldFM):
+    """ShardedFieldFM plus the BatchNorm tower of models.fields.FieldDeepFM over [gathered rows,
+    dense features].  The tables are row-sharded (model parallel); the tower is replicated (data
+    parallel): every rank normalises with the statistics of its own slice of the batch, as
+    DistributedDataParallel does, and ``allreduce_dense_grads`` sums the tower gradients over the
+    ranks in one flat buffer before ``dense_sgd_step``.  The gradient of the tower input joins the
+    rows' FM gradients inside rx_segreduce_fm, so no per-occurrence rows exist on this path either."""
+
+    def __init__(self, field_dims, embedding_dim, device, n_dense=13, dropout=0.1, bf16=False, group=None,
+                 backend=None, full_state=None):
+        super().__init__(field_dims, embedding_dim, device, group, backend, full_state)
+        from .models.fields import _bn_stack, _tower_pad
+        self.n_dense, self.bf16 = n_dense, bf16
+        d_in = self.n_fields * embedding_dim + n_dense
+        self.pad = _tower_pad(d_in, n_dense)
+        d_in += self.pad
+        self.deep_cols = d_in
+        self.deep_mlp = _bn_stack(d_in, [d_in, d_in // 2, d_in // 4], dropout).to(device)
+        if full_state:
+            own = {k[len("deep_mlp."):]: v for k, v in full_state.items() if k.startswith("deep_mlp.")}
+            self.deep_mlp.load_state_dict(own)
+        elif dist.is_initialized() and self.feature.G > 1:
+            for t in list(self.deep_mlp.parameters()) + list(self.deep_mlp.buffers()):
+                dist.broadcast(t.data, 0, group=group)   # replicas start equal
+        self._flat_grad = None
+
+    def dense_parameters(self):
+        return list(self.deep_mlp.parameters())
+
+    def forward(self, inputs):
+        from .models.fields import _dense_input
+        sparse = inputs["sparse"]
+        B = sparse.shape[0]
+        logits, x = _ShardedFM.apply(self._anchor, self, self._flat(sparse), B, self.n_fields - 1, self.deep_cols,
+                                     _dense_input(inputs, self.n_dense, B, self.pad))
+        if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend: the tower as plain torch modules
+            return logits + self.deep_mlp(x)
+        from .models.base import run_tower
+        return logits + run_tower(self.deep_mlp, x, bf16=self.bf16)
+
+    def allreduce_dense_grads(self):
+        """Sum of the tower gradients over the ranks, one collective on a flat buffer (73 MB at the
+        1 B-row x 128 shape; a ring is fine at that size)."""
+        params = [p for p in self.dense_parameters() if p.grad is not None]
+        if not params or not dist.is_initialized() or (self.feature.G == 1 and not self.feature.force_exchange):
+            return
+        n = sum(p.numel() for p in params)
+        if self._flat_grad is None or self._flat_grad.numel() != n:
+            self._flat_grad = torch.empty(n, dtype=torch.float32, device=params[0].device)
+        torch._foreach_copy_(list(self._flat_grad.split([p.numel() for p in params])), [p.grad.reshape(-1) for p in params])
+        dist.all_reduce(self._flat_grad, group=self.feature.group)
+        torch._foreach_copy_([p.grad.reshape(-1) for p in params], list(self._flat_grad.split([p.numel() for p in params])))
+
+    def dense_sgd_step(self, lr: float):
+        params = [p for p in self.dense_parameters() if p.grad is not None]
+        with torch.no_grad():
+            torch._foreach_add_(params, [p.grad for p in params], alpha=-lr)
+
+    def zero_dense_grads(self):
+        for p in self.dense_parameters():
+            p.grad = None
 
 
 class _ShardedFM(torch.autograd.Function):
@@ -316,9 +379,12 @@ class _ShardedFM(torch.autograd.Function):
     Per step a rank sends ~rho * n indices and receives / returns ~rho * n rows instead of n."""
 
     @staticmethod
-    def forward(ctx, anchor, model, flat, B, F):
+    def forward(ctx, anchor, model, flat, B, F, deep_cols=None, extra=None):
+        """``deep_cols``: also return the tower input [B, deep_cols] (gathered rows [item, field 0 ..
+        F-1], then ``extra``, e.g. the dense features); its gradient comes back into the rows'."""
         ops, feat, bias = model.ops, model.feature, model.bias
         n = flat.numel()
+        want_deep = deep_cols is not None
         si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
         if model.capacity:
             # nothing here waits for the host.  The rows stay in arrival (slot) order: occurrence ->
@@ -329,11 +395,12 @@ class _ShardedFM(torch.autograd.Function):
             slot_of = plan["src_of"].to(torch.int64)
             occ_slot = slot_of[si.inverse.to(torch.int64)]
             base = model._zero_base(F, flat.device)
-            logits, _, tsum = ops.fm2_fwd(rows_p, bias_p.reshape(-1), occ_slot[:B * F].reshape(B, F), base,
-                                          occ_slot[B * F:].reshape(B, 1), 0, want_tsum=True)
+            logits, deep, tsum = ops.fm2_fwd(rows_p, bias_p.reshape(-1), occ_slot[:B * F].reshape(B, F), base,
+                                             occ_slot[B * F:].reshape(B, 1), 0, want_deep=want_deep, deep_cols=deep_cols,
+                                             extra=extra, want_tsum=True)
             ctx.model, ctx.plan, ctx.si, ctx.F, ctx.slot_of = model, plan, si, F, slot_of
             ctx.save_for_backward(tsum, rows_p)
-            return logits
+            return logits, deep
         else:
             plan = feat.plan(si.uniq_rows, si.n_uniq)    # padded list + device count; one host read inside
             nu = plan["n"]
@@ -343,14 +410,19 @@ class _ShardedFM(torch.autograd.Function):
         ex = inv[:B * F].reshape(B, F)
         item = inv[B * F:].reshape(B, 1)
         base = model._zero_base(F, flat.device)
-        logits, _, tsum = ops.fm2_fwd(rows_u, bias_u.reshape(-1), ex, base, item, 0, want_tsum=True)
+        logits, deep, tsum = ops.fm2_fwd(rows_u, bias_u.reshape(-1), ex, base, item, 0, want_deep=want_deep,
+                                         deep_cols=deep_cols, extra=extra, want_tsum=True)
         ctx.model, ctx.plan, ctx.si, ctx.nu, ctx.F, ctx.slot_of = model, plan, si, nu, F, None
         ctx.save_for_backward(tsum, rows_u)
-        return logits
+        return logits, deep
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_deep=None):
         tsum, rows_u = ctx.saved_tensors
+        if g is None:
+            g = torch.zeros(tsum.shape[0], dtype=torch.float32, device=tsum.device)
+        if g_deep is not None and g_deep.stride(-1) != 1:
+            g_deep = g_deep.contiguous()
         model, si = ctx.model, ctx.si
         ops, feat, bias = model.ops, model.feature, model.bias
         if ctx.slot_of is not None:
@@ -361,9 +433,9 @@ class _ShardedFM(torch.autograd.Function):
             sent = torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=g.device)
             sent2 = torch.zeros(n_slots, dtype=torch.float32, device=g.device)
             ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, by_slot, _lib.RX_SEG_DENSE, sent, table=rows_u,
-                             target2=sent2)
+                             target2=sent2, deep=g_deep)
             feat.reduce_packed(sent, ctx.plan, bias, sent2)
-            return None, None, None, None, None
+            return (None,) * 7
         nu = ctx.nu
         # the received buffer is addressed by slot, so the reduce sees "row u = slot u"
         slots = ops.SortedIndex(si.n, max(nu, 1), si.sorted_pos, si.sorted_slot, model._iota(si.n, g.device), si.seg_off,
@@ -371,6 +443,6 @@ class _ShardedFM(torch.autograd.Function):
         compact = torch.empty(max(nu, 1), feat.dim, dtype=torch.float32, device=g.device)
         compact2 = torch.empty(max(nu, 1), dtype=torch.float32, device=g.device)
         ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, slots, _lib.RX_SEG_COMPACT, compact, table=rows_u,
-                         target2=compact2)
+                         target2=compact2, deep=g_deep)
         feat.scatter_grad(compact[:nu], ctx.plan, bias, compact2[:nu])
-        return None, None, None, None, None
+        return (None,) * 7

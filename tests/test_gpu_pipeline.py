@@ -102,6 +102,39 @@ def test_sharded_fm_world1_matches_field_fm(kind, fixed):
         assert_close(sh.bias.grad.cpu().numpy(), ref.bias_embedding.weight.grad.cpu().numpy(), what="grad bias")
 
 
+@pytest.mark.parametrize("fixed", [False, True])
+def test_sharded_deepfm_world1_matches_field_deepfm(fixed):
+    """Sharded tables + replicated BatchNorm tower at world size 1 against the unsharded DeepFM,
+    both through the HIP kernels: losses, table rows and tower weights after two SGD steps."""
+    from recsys_amd.models.fields import FieldDeepFM
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.sharded import ShardedFieldDeepFM
+    dims = [7, 1000, 13, 5000, 3, 211]
+    torch.manual_seed(2)
+    ref = FieldDeepFM(dims, 16, n_dense=5, dropout=0.0).cuda()
+    state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    sh = ShardedFieldDeepFM(dims, 16, "cuda", n_dense=5, dropout=0.0, full_state=state)
+    ref.train(); sh.train()
+    g = torch.Generator().manual_seed(4)
+    batch = {"sparse": torch.stack([torch.randint(0, d, (333,), generator=g) for d in dims], 1).cuda(),
+             "dense": torch.randn(333, 5, generator=g).cuda(),
+             "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
+    if fixed:
+        sh.calibrate([batch])
+    opt = FusedOptimizer(ref, kind="sgd", lr=0.1)
+    sh.set_rule("sgd", 0.1)
+    for _ in range(2):
+        opt.zero_grad()
+        sh.zero_dense_grads()
+        l1 = ref.loss(batch); l1.backward(); opt.step()
+        l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads(); sh.dense_sgd_step(0.1)
+        assert_close(l2.item(), l1.item(), rtol=1e-6, what="loss")
+    assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
+    assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
+    for (k, a), (_, b) in zip(sh.deep_mlp.named_parameters(), ref.deep_mlp.named_parameters()):
+        assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, what="tower " + k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["NeuMF", "TemporalMF"])
 def test_pipelined_graph_with_presorted_indices_matches_eager_bitwise(name):
@@ -229,6 +262,28 @@ def test_sharded_fm_one_rank_through_rccl():
         ops_mod.raise_if_index_error()
         assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
         assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
+        # the DeepFM variant: same exchange plus the tower-gradient all-reduce through RCCL
+        from recsys_amd.models.fields import FieldDeepFM
+        from recsys_amd.sharded import ShardedFieldDeepFM
+        torch.manual_seed(3)
+        ref = FieldDeepFM(dims, 16, n_dense=5, dropout=0.0).cuda()
+        state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+        sh = ShardedFieldDeepFM(dims, 16, "cuda", n_dense=5, dropout=0.0, full_state=state)
+        sh.feature.force_exchange = sh.bias.force_exchange = True
+        ref.train(); sh.train()
+        batch["dense"] = torch.randn(333, 5, generator=g).cuda()
+        sh.calibrate([batch])
+        opt = FusedOptimizer(ref, kind="sgd", lr=0.1)
+        sh.set_rule("sgd", 0.1)
+        for step in range(2):
+            opt.zero_grad(); sh.zero_dense_grads()
+            l1 = ref.loss(batch); l1.backward(); opt.step()
+            l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads(); sh.dense_sgd_step(0.1)
+            assert_close(l2.item(), l1.item(), rtol=1e-6, what="deepfm loss")
+        ops_mod.raise_if_index_error()
+        assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="deepfm rows")
+        for (k, a), (_, b) in zip(sh.deep_mlp.named_parameters(), ref.deep_mlp.named_parameters()):
+            assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, what="tower " + k)
     finally:
         if created:
             dist.destroy_process_group()

@@ -104,3 +104,90 @@ def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
     sd = oracle.state_dict()
     assert torch.allclose(feat, sd["feature_embedding.weight"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(bias, sd["bias_embedding.weight"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ DeepFM: sharded tables + data-parallel tower
+N_DENSE = 5
+
+
+def _deepfm_state(seed=3):
+    from recsys_amd.models.fields import FieldDeepFM
+    torch.manual_seed(seed)
+    m = FieldDeepFM(DIMS, DIM, n_dense=N_DENSE, dropout=0.0)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def _deep_batch(world, seed=2):
+    b = _global_batch(world, seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    b["dense"] = torch.randn(B_LOCAL * world, N_DENSE, generator=g)
+    return b
+
+
+def _deep_worker(rank, world, port, fixed, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cpu_ops
+        from recsys_amd.sharded import ShardedFieldDeepFM
+        full = _deepfm_state()
+        batch = _deep_batch(world)
+        sl = slice(rank * B_LOCAL, (rank + 1) * B_LOCAL)
+        local = {k: v[sl] for k, v in batch.items()}
+        m = ShardedFieldDeepFM(DIMS, DIM, "cpu", n_dense=N_DENSE, dropout=0.0, backend=cpu_ops, full_state=full)
+        m.train()
+        if fixed:
+            m.calibrate([local])
+        m.set_rule("sgd", lr=0.1)
+        losses = []
+        for _ in range(2):
+            m.zero_dense_grads()
+            loss = m.loss(local)
+            (loss / world).backward()
+            m.allreduce_dense_grads()
+            m.dense_sgd_step(0.1)
+            losses.append(loss.detach())
+        dense = {k: v.detach().clone() for k, v in m.deep_mlp.state_dict().items()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (m.feature.weight, m.bias.weight, torch.stack(losses), dense))
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_two_rank_sharded_deepfm_matches_single_process(tmp_path, fixed):
+    """Tables sharded, tower replicated: two steps on two ranks equal two steps of the CPU
+    restatement on the mean of the per-rank losses (every rank's BatchNorm sees its own slice)."""
+    from oracle.fields import FieldOracle
+    world = 2
+    out = str(tmp_path / "deep_shards.pt")
+    mp.spawn(_deep_worker, args=(world, _free_port(), fixed, out), nprocs=world, join=True)
+    shards = torch.load(out, weights_only=False)
+    n = sum(DIMS)
+    feat, bias = torch.empty(n, DIM), torch.empty(n, 1)
+    for r, (fw, bw, _, _) in enumerate(shards):
+        feat[r::world], bias[r::world] = fw, bw
+    oracle = FieldOracle("FieldDeepFM", _deepfm_state(), DIMS, dropout=0.0)
+    opt = torch.optim.SGD(oracle.parameters(), lr=0.1)
+    batch = _deep_batch(world)
+    halves = [{k: v[r * B_LOCAL:(r + 1) * B_LOCAL] for k, v in batch.items()} for r in range(world)]
+    ref_losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        per_rank = [oracle.loss(h) for h in halves]
+        (sum(per_rank) / world).backward()
+        opt.step()
+        ref_losses.append([l.item() for l in per_rank])
+    got = torch.stack([s[2] for s in shards]).T      # [step, rank]
+    assert torch.allclose(got, torch.tensor(ref_losses, dtype=got.dtype), rtol=1e-6)
+    sd = oracle.state_dict()
+    assert torch.allclose(feat, sd["feature_embedding.weight"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bias, sd["bias_embedding.weight"], rtol=1e-5, atol=1e-6)
+    for r in range(world):
+        for k, v in shards[r][3].items():
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                continue
+            assert torch.allclose(v, sd["deep_mlp." + k], rtol=1e-5, atol=1e-6), (r, k)
