@@ -52,7 +52,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         dims = synthetic.criteo_field_dims(total_rows=33_000_000 * world)
         B, D, lr = 65536, 16, 0.05
         model = ShardedFieldDeepFM(dims, D, device)
-        model.set_rule("sgd", lr)
+        model.set_rule("sgd", lr, clip_norm=clip)
         model.train()
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
             model.feature.force_exchange = model.bias.force_exchange = True
@@ -60,7 +60,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         cap = model.calibrate(batches)
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank; tower: all-reduce + dense SGD",
-                "clip_norm": None, "launch": f"eager, asynchronous ({cap} exchange slots per owner)"}
+                "clip_norm": clip, "launch": f"eager, asynchronous ({cap} exchange slots per owner)"}
 
         class _DeepOpt:
             def zero_grad(self):
@@ -68,7 +68,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
 
             def step(self):
                 model.allreduce_dense_grads()
-                model.dense_sgd_step(lr)
+                model.dense_sgd_step(lr, model.finish_step(model.dense_grads()))
 
         return dict(model=model, opt=_DeepOpt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
     if name == "fm_criteo_sharded":
@@ -81,13 +81,13 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         dims = synthetic.criteo_field_dims(total_rows=rows_per_gpu * world)
         B, D = 65536, int(os.environ.get("RX_BENCH_SHARDED_DIM", 128))
         model = ShardedFieldFM(dims, D, device)
-        model.set_rule("sgd", 0.05)
+        model.set_rule("sgd", 0.05, clip_norm=clip)
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
             model.feature.force_exchange = model.bias.force_exchange = True
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
         cap = model.calibrate(batches)   # fixed-capacity exchange: equal all-to-all splits, no host read in the step
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
-                "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": None,
+                "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": clip,
                 "launch": f"eager, asynchronous (distinct rows only, {cap} exchange slots per owner)"}
 
         class _Opt:
@@ -95,7 +95,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
                 pass
 
             def step(self):
-                pass
+                model.finish_step()     # global-norm clip over all ranks, then the pending row updates
 
         # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
         return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)

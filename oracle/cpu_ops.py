@@ -139,6 +139,50 @@ def segreduce(occ, si, mode, target, *, state=None, lr=0.0, eps=0.0, scale=None,
     return sq.reshape(1) if want_sq else None
 
 
+def row_update(compact, si, mode, table, *, state=None, lr=0.0, eps=0.0, scale=None, compact2=None, table2=None,
+               state2=None):
+    nu = int(si.n_uniq)
+    rows = si.uniq_rows[:nu]
+    sc = float(scale) if scale is not None else 1.0
+    for G, t, st in ((compact.reshape(si.n, -1)[:nu], table.reshape(table.shape[0], -1), state),
+                     (None if compact2 is None else compact2.reshape(-1, 1)[:nu], None if table2 is None else table2.reshape(-1, 1),
+                      None if state2 is None else state2.reshape(-1, 1))):
+        if G is None:
+            continue
+        if mode == _lib.RX_SEG_SGD:
+            t[rows] -= lr * sc * G
+        elif mode == _lib.RX_SEG_ADAGRAD:
+            st[rows] += (sc * G) ** 2
+            t[rows] -= lr * sc * G / (st[rows].sqrt() + eps)
+        else:
+            raise NotImplementedError("row_update stand-in: SGD and Adagrad")
+
+
+def sum_accumulate(x, acc):
+    acc += x.double().sum()
+
+
+def multi_sumsq_partials(grads):
+    return torch.stack([(g.double() ** 2).sum() for g in grads])
+
+
+def _clip(total, max_norm):
+    tn = total.sqrt().float()
+    return (max_norm / (tn + 1e-6)).clamp(max=1.0).reshape(1), tn.reshape(1)
+
+
+def clip_scale(acc, max_norm):
+    return _clip(acc.reshape(()), max_norm)
+
+
+def clip_scale_parts(parts, acc, max_norm, parts64=None):
+    total = torch.zeros((), dtype=torch.float64)
+    for t in (parts, acc, parts64):
+        if t is not None:
+            total = total + t.double().sum()
+    return _clip(total, max_norm)
+
+
 def fm2_fwd(feat, bias, ex_idx, ex_base, item_idx, item_base, want_deep=False, second_order=True, deep_cols=None,
             want_logits=True, extra=None, want_tsum=False):
     ex = feat[ex_idx + ex_base[None, :]]

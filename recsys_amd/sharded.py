@@ -54,6 +54,10 @@ class ShardedTable:
         self.force_exchange = False
         self.grad: Optional[torch.Tensor] = None      # dense local gradient (when no rule is set)
         self.rule = None                               # (mode, lr, eps, state) for the fused row update
+        # two-phase update for a global gradient-norm clip: the owner-side reduce leaves compact
+        # per-row gradients + sum-of-squares partials here, apply_pending(scale) updates the rows
+        self.clip = False
+        self.pending = None
 
     def set_rule(self, kind: str, lr: float, eps: float = 1e-10):
         mode = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}[kind]
@@ -183,8 +187,28 @@ class ShardedTable:
                 if companion.rule is None or companion.rule[0] != mode:
                     raise RuntimeError("a companion table must carry the same update rule as its main table")
                 w2, st2 = companion.weight, companion.rule[3]
+            if self.clip:
+                compact = torch.empty(si.n, self.dim, dtype=torch.float32, device=got.device)
+                compact2 = torch.empty(si.n, dtype=torch.float32, device=got.device) if companion is not None else None
+                sq = self.ops.segreduce(got, si, _lib.RX_SEG_COMPACT, compact, dim=self.dim, occ2=got2, target2=compact2,
+                                        want_sq=True)
+                self.pending = (compact, compact2, si, sq, companion)
+                return
             self.ops.segreduce(got, si, mode, self.weight, state=state, lr=lr, eps=eps, dim=self.dim,
                                occ2=got2, target2=w2, state2=st2)
+
+    def apply_pending(self, scale: Optional[torch.Tensor]):
+        """Second phase of a clipped step: rows (and the companion's entries) move by the compact
+        gradients kept by the owner-side reduce, scaled by the device scalar ``scale``."""
+        if self.pending is None:
+            return
+        compact, compact2, si, _, companion = self.pending
+        self.pending = None
+        mode, lr, eps, state = self.rule
+        kw = {}
+        if companion is not None:
+            kw = dict(compact2=compact2, table2=companion.weight, state2=companion.rule[3])
+        self.ops.row_update(compact, si, mode, self.weight, state=state, lr=lr, eps=eps, scale=scale, **kw)
 
 
 class _ShardedLookup(torch.autograd.Function):
@@ -274,9 +298,36 @@ class ShardedFieldFM(torch.nn.Module):
         self.capacity = (int(worst * slack) + 255) // 256 * 256
         return self.capacity
 
-    def set_rule(self, kind, lr, eps=1e-10):
+    def set_rule(self, kind, lr, eps=1e-10, clip_norm: Optional[float] = None):
+        """``clip_norm``: clip the global gradient norm (all tables on all ranks, plus any dense
+        gradients handed to ``finish_step``) as torch.nn.utils.clip_grad_norm_ does in
+        recsys/utils.py:101; the row updates then wait for ``finish_step``."""
         self.feature.set_rule(kind, lr, eps)
         self.bias.set_rule(kind, lr, eps)
+        self.clip_norm = clip_norm
+        self.feature.clip = clip_norm is not None
+        self.last_total_norm = None
+
+    def finish_step(self, dense_grads=()):
+        """After backward.  With a clip norm: squared norms of the owner-side table gradients are
+        summed over the ranks (one 8-byte all-reduce; the dense gradients, equal on every rank after
+        their own all-reduce, are counted once), the clip factor is formed on the device, and the
+        pending row updates run with it.  Returns the factor (device scalar) or None."""
+        if getattr(self, "clip_norm", None) is None:
+            return None
+        acc = torch.zeros(1, dtype=torch.float64, device=self._offsets.device)
+        if self.feature.pending is not None:
+            self.ops.sum_accumulate(self.feature.pending[3], acc)
+        if dist.is_initialized() and (self.feature.G > 1 or self.feature.force_exchange):
+            dist.all_reduce(acc, group=self.feature.group)
+        flat = [g.contiguous().reshape(-1) for g in dense_grads]
+        if flat:
+            scale, self.last_total_norm = self.ops.clip_scale_parts(None, acc, float(self.clip_norm),
+                                                                    self.ops.multi_sumsq_partials(flat))
+        else:
+            scale, self.last_total_norm = self.ops.clip_scale(acc, float(self.clip_norm))
+        self.feature.apply_pending(scale)
+        return scale
 
     def _zero_base(self, F, device):
         key = ("base", F, str(device))
@@ -355,10 +406,17 @@ class ShardedFieldDeepFM(ShardedFieldFM):
         dist.all_reduce(self._flat_grad, group=self.feature.group)
         torch._foreach_copy_([p.grad.reshape(-1) for p in params], list(self._flat_grad.split([p.numel() for p in params])))
 
-    def dense_sgd_step(self, lr: float):
+    def dense_grads(self):
+        return [p.grad for p in self.dense_parameters() if p.grad is not None]
+
+    def dense_sgd_step(self, lr: float, scale: Optional[torch.Tensor] = None):
+        """``scale``: the clip factor of ``finish_step`` (device scalar)."""
         params = [p for p in self.dense_parameters() if p.grad is not None]
+        grads = [p.grad for p in params]
         with torch.no_grad():
-            torch._foreach_add_(params, [p.grad for p in params], alpha=-lr)
+            if scale is not None:
+                grads = torch._foreach_mul(grads, scale.reshape(()))
+            torch._foreach_add_(params, grads, alpha=-lr)
 
     def zero_dense_grads(self):
         for p in self.dense_parameters():

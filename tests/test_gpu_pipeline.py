@@ -102,6 +102,35 @@ def test_sharded_fm_world1_matches_field_fm(kind, fixed):
         assert_close(sh.bias.grad.cpu().numpy(), ref.bias_embedding.weight.grad.cpu().numpy(), what="grad bias")
 
 
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_sharded_fm_world1_clipped_step_matches_fused_optimizer(kind):
+    """Global-norm clip on the sharded path (owner-side compact gradients, norm summed over ranks,
+    scaled row update) against FusedOptimizer(clip_norm) on the unsharded model."""
+    from recsys_amd.models.fields import FieldFM
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.sharded import ShardedFieldFM
+    dims = [7, 1000, 13, 5000, 3, 211]
+    torch.manual_seed(2)
+    ref = FieldFM(dims, 16).cuda()
+    state = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    sh = ShardedFieldFM(dims, 16, "cuda", full_state=state)
+    g = torch.Generator().manual_seed(4)
+    batch = {"sparse": torch.stack([torch.randint(0, d, (333,), generator=g) for d in dims], 1).cuda(),
+             "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
+    sh.calibrate([batch])
+    opt = FusedOptimizer(ref, kind=kind, lr=0.1, clip_norm=0.05)
+    sh.set_rule(kind, 0.1, clip_norm=0.05)
+    for _ in range(2):
+        opt.zero_grad()
+        l1 = ref.loss(batch); l1.backward(); opt.step()
+        l2 = sh.loss(batch); l2.backward(); scale = sh.finish_step()
+        assert float(scale) < 1.0
+        assert_close(l2.item(), l1.item(), rtol=1e-6, what="loss")
+        assert_close(sh.last_total_norm.item(), opt.last_total_norm.item(), rtol=1e-5, what="global norm")
+    assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
+    assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
+
+
 @pytest.mark.parametrize("fixed", [False, True])
 def test_sharded_deepfm_world1_matches_field_deepfm(fixed):
     """Sharded tables + replicated BatchNorm tower at world size 1 against the unsharded DeepFM,
@@ -121,13 +150,15 @@ def test_sharded_deepfm_world1_matches_field_deepfm(fixed):
              "label": (torch.rand(333, 1, generator=g) < 0.3).double().cuda()}
     if fixed:
         sh.calibrate([batch])
-    opt = FusedOptimizer(ref, kind="sgd", lr=0.1)
-    sh.set_rule("sgd", 0.1)
+    clip = 0.05 if fixed else None      # the fixed-capacity case also runs the clipped two-phase step
+    opt = FusedOptimizer(ref, kind="sgd", lr=0.1, clip_norm=clip)
+    sh.set_rule("sgd", 0.1, clip_norm=clip)
     for _ in range(2):
         opt.zero_grad()
         sh.zero_dense_grads()
         l1 = ref.loss(batch); l1.backward(); opt.step()
-        l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads(); sh.dense_sgd_step(0.1)
+        l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads()
+        sh.dense_sgd_step(0.1, sh.finish_step(sh.dense_grads()))
         assert_close(l2.item(), l1.item(), rtol=1e-6, what="loss")
     assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="rows")
     assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
@@ -273,12 +304,13 @@ def test_sharded_fm_one_rank_through_rccl():
         ref.train(); sh.train()
         batch["dense"] = torch.randn(333, 5, generator=g).cuda()
         sh.calibrate([batch])
-        opt = FusedOptimizer(ref, kind="sgd", lr=0.1)
-        sh.set_rule("sgd", 0.1)
+        opt = FusedOptimizer(ref, kind="sgd", lr=0.1, clip_norm=0.05)
+        sh.set_rule("sgd", 0.1, clip_norm=0.05)
         for step in range(2):
             opt.zero_grad(); sh.zero_dense_grads()
             l1 = ref.loss(batch); l1.backward(); opt.step()
-            l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads(); sh.dense_sgd_step(0.1)
+            l2 = sh.loss(batch); l2.backward(); sh.allreduce_dense_grads()
+            sh.dense_sgd_step(0.1, sh.finish_step(sh.dense_grads()))
             assert_close(l2.item(), l1.item(), rtol=1e-6, what="deepfm loss")
         ops_mod.raise_if_index_error()
         assert_close(sh.feature.weight.cpu().numpy(), ref.feature_embedding.weight.detach().cpu().numpy(), what="deepfm rows")

@@ -48,17 +48,20 @@ def _worker(rank, world, port, kind, out):
         assert torch.equal(got, full["feature_embedding.weight"][idx])
         # two data-parallel steps
         m = ShardedFieldFM(DIMS, DIM, "cpu", backend=cpu_ops, full_state=full)
-        fixed = kind.endswith("+capacity")
+        fixed = "+capacity" in kind
+        clip = 0.05 if "+clip" in kind else None     # small enough to bite on every step
         kind = kind.split("+")[0]
         if fixed:   # fixed-capacity exchange: equal all-to-all splits, capacity from the batch itself
             assert m.calibrate([local]) % 256 == 0
         if kind != "dense":
-            m.set_rule(kind, lr=0.1)
+            m.set_rule(kind, lr=0.1, clip_norm=clip)
         losses = []
         for _ in range(2):
             m.feature.grad = m.bias.grad = None
             loss = m.loss(local)
             (loss / world).backward()
+            scale = m.finish_step()
+            assert (scale is None) == (clip is None) and (clip is None or float(scale) < 1.0)
             losses.append(loss.detach())
             if kind == "dense":
                 m.feature.weight -= 0.1 * m.feature.grad
@@ -77,7 +80,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adagrad", "dense", "sgd+capacity", "adagrad+capacity"])
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "dense", "sgd+capacity", "adagrad+capacity", "sgd+clip",
+                                  "adagrad+capacity+clip"])
 def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
     from oracle.fields import FieldOracle
     world = 2
@@ -88,6 +92,7 @@ def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
     feat, bias = torch.empty(n, DIM), torch.empty(n, 1)
     for r, (fw, bw, _) in enumerate(shards):
         feat[r::world], bias[r::world] = fw, bw
+    clip = 0.05 if "+clip" in kind else None
     kind = kind.split("+")[0]
     oracle = FieldOracle("FieldFM", _full_state(), DIMS)
     opt = (torch.optim.Adagrad if kind == "adagrad" else torch.optim.SGD)(oracle.parameters(), lr=0.1)
@@ -97,6 +102,8 @@ def test_two_rank_sharded_fm_matches_single_process(tmp_path, kind):
         opt.zero_grad()
         loss = oracle.loss(batch)
         loss.backward()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(oracle.parameters(), clip)
         opt.step()
         ref_losses.append(loss.item())
     mean_losses = torch.stack([s[2] for s in shards]).mean(0)
@@ -124,7 +131,7 @@ def _deep_batch(world, seed=2):
     return b
 
 
-def _deep_worker(rank, world, port, fixed, out):
+def _deep_worker(rank, world, port, fixed, out, clip=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -139,14 +146,14 @@ def _deep_worker(rank, world, port, fixed, out):
         m.train()
         if fixed:
             m.calibrate([local])
-        m.set_rule("sgd", lr=0.1)
+        m.set_rule("sgd", lr=0.1, clip_norm=clip)
         losses = []
         for _ in range(2):
             m.zero_dense_grads()
             loss = m.loss(local)
             (loss / world).backward()
             m.allreduce_dense_grads()
-            m.dense_sgd_step(0.1)
+            m.dense_sgd_step(0.1, m.finish_step(m.dense_grads()))
             losses.append(loss.detach())
         dense = {k: v.detach().clone() for k, v in m.deep_mlp.state_dict().items()}
         gathered = [None] * world
@@ -157,14 +164,14 @@ def _deep_worker(rank, world, port, fixed, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fixed", [False, True])
-def test_two_rank_sharded_deepfm_matches_single_process(tmp_path, fixed):
+@pytest.mark.parametrize("fixed,clip", [(False, None), (True, None), (True, 0.05)])
+def test_two_rank_sharded_deepfm_matches_single_process(tmp_path, fixed, clip):
     """Tables sharded, tower replicated: two steps on two ranks equal two steps of the CPU
     restatement on the mean of the per-rank losses (every rank's BatchNorm sees its own slice)."""
     from oracle.fields import FieldOracle
     world = 2
     out = str(tmp_path / "deep_shards.pt")
-    mp.spawn(_deep_worker, args=(world, _free_port(), fixed, out), nprocs=world, join=True)
+    mp.spawn(_deep_worker, args=(world, _free_port(), fixed, out, clip), nprocs=world, join=True)
     shards = torch.load(out, weights_only=False)
     n = sum(DIMS)
     feat, bias = torch.empty(n, DIM), torch.empty(n, 1)
@@ -179,6 +186,8 @@ def test_two_rank_sharded_deepfm_matches_single_process(tmp_path, fixed):
         opt.zero_grad()
         per_rank = [oracle.loss(h) for h in halves]
         (sum(per_rank) / world).backward()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(oracle.parameters(), clip)
         opt.step()
         ref_losses.append([l.item() for l in per_rank])
     got = torch.stack([s[2] for s in shards]).T      # [step, rank]
