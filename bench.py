@@ -162,6 +162,12 @@ def one_step(w, i):
     if w.get("graphed") is not None:
         return w["graphed"](i % len(w["batches"]))
     batch = w["batches"][i % len(w["batches"])]
+    if hasattr(w["model"], "prepare") and w.get("loss_scale"):
+        # sharded models: the local index work of the next batch goes to a side stream before this
+        # step is launched, and overlaps it
+        ready = w.setdefault("prepared", {})
+        batch = ready.pop(i, None) or w["model"].prepare(batch)
+        ready[i + 1] = w["model"].prepare(w["batches"][(i + 1) % len(w["batches"])])
     w["opt"].zero_grad()
     loss = w["model"].loss(batch)
     if w.get("loss_scale"):

@@ -85,12 +85,17 @@ class ShardedTable:
         dist.all_to_all_single(recv_idx, send_local[:m].contiguous(), recv, send, group=self.group)
         return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm[:m], n=m)
 
-    def plan_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int):
+    def pack_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int):
+        """The local half of plan_fixed (no collective): owner buckets packed into ``capacity`` slots
+        each.  Returns (packed local row ids [G * capacity], slot of every list entry [n])."""
+        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
+        return self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1))
+
+    def plan_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int, packed=None):
         """Exchange plan with ``capacity`` slots per owner and equal all-to-all splits: no host-side
         sizes, so the step never waits for the host.  A group that does not fit sets the deferred
         RX_ERR_CAPACITY flag (``ops.raise_if_index_error``)."""
-        counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
-        packed, src_of = self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1))
+        packed, src_of = packed if packed is not None else self.pack_fixed(idx, n_valid, capacity)
         recv_idx = packed
         if not (self.G == 1 and not self.force_exchange):
             recv_idx = torch.empty_like(packed)
@@ -298,6 +303,41 @@ class ShardedFieldFM(torch.nn.Module):
         self.capacity = (int(worst * slack) + 255) // 256 * 256
         return self.capacity
 
+    def prepare(self, inputs):
+        """Index work of a later step that needs neither the tables nor a collective (occurrence
+        list, sort + dedup, owner buckets packed into slots), issued on a side stream: call it for
+        batch i+1 *before* launching step i and it overlaps that step.  Returns the batch dict with
+        the result attached; ``forward`` picks it up and joins the side stream.  Without a
+        fixed capacity (or on the CPU stand-in backend) the batch is returned as it is."""
+        sparse = inputs["sparse"]
+        if not self.capacity or not sparse.is_cuda or "_rx_shard_prep" in inputs:
+            return inputs
+        dev = sparse.device
+        main = torch.cuda.current_stream(dev)
+        side = self._pos.get("side")
+        if side is None:
+            side = self._pos["side"] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)      # = the steps launched so far; the step launched next runs beside this
+        with torch.cuda.stream(side):
+            flat = self._flat(sparse)
+            si = self.ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
+            packed = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
+            done = torch.cuda.Event()
+            done.record(side)
+        out = dict(inputs)
+        out["_rx_shard_prep"] = (si, packed, done, flat)
+        return out
+
+    @staticmethod
+    def _join_prep(prep, device):
+        """Make the current stream wait for a prepare() result and own its tensors from here on."""
+        si, packed, done, flat = prep
+        main = torch.cuda.current_stream(device)
+        main.wait_event(done)
+        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], flat):
+            t.record_stream(main)
+        return si, packed
+
     def set_rule(self, kind, lr, eps=1e-10, clip_norm: Optional[float] = None):
         """``clip_norm``: clip the global gradient norm (all tables on all ranks, plus any dense
         gradients handed to ``finish_step``) as torch.nn.utils.clip_grad_norm_ does in
@@ -344,7 +384,9 @@ class ShardedFieldFM(torch.nn.Module):
 
     def forward(self, inputs):
         sparse = inputs["sparse"]
-        return _ShardedFM.apply(self._anchor, self, self._flat(sparse), sparse.shape[0], self.n_fields - 1)[0]
+        prep = inputs.get("_rx_shard_prep")
+        flat = prep[3] if prep is not None else self._flat(sparse)
+        return _ShardedFM.apply(self._anchor, self, flat, sparse.shape[0], self.n_fields - 1, None, None, prep)[0]
 
     def loss(self, inputs):
         if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
@@ -386,8 +428,10 @@ class ShardedFieldDeepFM(ShardedFieldFM):
         from .models.fields import _dense_input
         sparse = inputs["sparse"]
         B = sparse.shape[0]
-        logits, x = _ShardedFM.apply(self._anchor, self, self._flat(sparse), B, self.n_fields - 1, self.deep_cols,
-                                     _dense_input(inputs, self.n_dense, B, self.pad))
+        prep = inputs.get("_rx_shard_prep")
+        flat = prep[3] if prep is not None else self._flat(sparse)
+        logits, x = _ShardedFM.apply(self._anchor, self, flat, B, self.n_fields - 1, self.deep_cols,
+                                     _dense_input(inputs, self.n_dense, B, self.pad), prep)
         if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend: the tower as plain torch modules
             return logits + self.deep_mlp(x)
         from .models.base import run_tower
@@ -437,18 +481,22 @@ class _ShardedFM(torch.autograd.Function):
     Per step a rank sends ~rho * n indices and receives / returns ~rho * n rows instead of n."""
 
     @staticmethod
-    def forward(ctx, anchor, model, flat, B, F, deep_cols=None, extra=None):
+    def forward(ctx, anchor, model, flat, B, F, deep_cols=None, extra=None, prep=None):
         """``deep_cols``: also return the tower input [B, deep_cols] (gathered rows [item, field 0 ..
         F-1], then ``extra``, e.g. the dense features); its gradient comes back into the rows'."""
         ops, feat, bias = model.ops, model.feature, model.bias
         n = flat.numel()
         want_deep = deep_cols is not None
-        si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
+        packed = None
+        if prep is not None:        # prepared on the side stream (ShardedFieldFM.prepare)
+            si, packed = model._join_prep(prep, flat.device)
+        else:
+            si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
         if model.capacity:
             # nothing here waits for the host.  The rows stay in arrival (slot) order: occurrence ->
             # distinct row -> slot is composed on the index side, 8 bytes per occurrence instead of a
             # copy of every row
-            plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity)
+            plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity, packed)
             rows_p, bias_p = feat.gather_packed(plan), bias.gather_packed(plan)
             slot_of = plan["src_of"].to(torch.int64)
             occ_slot = slot_of[si.inverse.to(torch.int64)]
@@ -493,7 +541,7 @@ class _ShardedFM(torch.autograd.Function):
             ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, by_slot, _lib.RX_SEG_DENSE, sent, table=rows_u,
                              target2=sent2, deep=g_deep)
             feat.reduce_packed(sent, ctx.plan, bias, sent2)
-            return (None,) * 7
+            return (None,) * 8
         nu = ctx.nu
         # the received buffer is addressed by slot, so the reduce sees "row u = slot u"
         slots = ops.SortedIndex(si.n, max(nu, 1), si.sorted_pos, si.sorted_slot, model._iota(si.n, g.device), si.seg_off,
@@ -503,4 +551,4 @@ class _ShardedFM(torch.autograd.Function):
         ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, slots, _lib.RX_SEG_COMPACT, compact, table=rows_u,
                          target2=compact2, deep=g_deep)
         feat.scatter_grad(compact[:nu], ctx.plan, bias, compact2[:nu])
-        return (None,) * 7
+        return (None,) * 8

@@ -131,6 +131,32 @@ def test_sharded_fm_world1_clipped_step_matches_fused_optimizer(kind):
     assert_close(sh.bias.weight.cpu().numpy(), ref.bias_embedding.weight.detach().cpu().numpy(), what="bias")
 
 
+def test_sharded_prepare_on_side_stream_is_bitwise_neutral():
+    """The local index work of batch i+1 issued on a side stream before step i is launched gives the
+    same weights, bit for bit, as doing it inside the step."""
+    from recsys_amd.sharded import ShardedFieldFM
+    dims = [7, 1000, 13, 5000, 3, 211]
+    g = torch.Generator().manual_seed(9)
+    batches = [{"sparse": torch.stack([torch.randint(0, d, (500,), generator=g) for d in dims], 1).cuda(),
+                "label": (torch.rand(500, 1, generator=g) < 0.3).double().cuda()} for _ in range(3)]
+    torch.manual_seed(5)
+    state = {"feature_embedding.weight": torch.randn(sum(dims), 16), "bias_embedding.weight": torch.randn(sum(dims), 1)}
+    out = []
+    for piped in (False, True):
+        sh = ShardedFieldFM(dims, 16, "cuda", full_state=state)
+        sh.calibrate(batches)
+        sh.set_rule("sgd", 0.1, clip_norm=0.05)
+        nxt = sh.prepare(batches[0]) if piped else batches[0]
+        for i in range(6):
+            cur = nxt
+            nxt = sh.prepare(batches[(i + 1) % 3]) if piped else batches[(i + 1) % 3]
+            assert ("_rx_shard_prep" in cur) == piped
+            loss = sh.loss(cur); loss.backward(); sh.finish_step()
+        out.append((sh.feature.weight.clone(), sh.bias.weight.clone(), float(loss.item())))
+    assert out[0][2] == out[1][2]
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("fixed", [False, True])
 def test_sharded_deepfm_world1_matches_field_deepfm(fixed):
     """Sharded tables + replicated BatchNorm tower at world size 1 against the unsharded DeepFM,
