@@ -257,8 +257,7 @@ class GatherConcat(Function):
             o = 0
             for s, n in zip(mine, n_each):
                 _, idx, col, div, stride, k, base = s
-                ops_occ = ops.gather_concat_bwd(dout, col, dim, div)
-                occ[o:o + n].copy_(ops_occ)
+                ops.gather_concat_bwd(dout, col, dim, div, out=occ[o:o + n])
                 o += n
                 used = idx.reshape(-1, stride)[:n, k] if stride > 1 else idx.reshape(-1)[:n]
                 idx_parts.append(used + base if base else used)

@@ -508,11 +508,20 @@ gemm_bf16_pipe_kernel(GemmArgs g, int swizzle) {
 // out[i] = sum over the slabs of slabs[s][i], in a fixed order: four slab lanes per output
 // element (lane q adds slabs q, q+4, ... in increasing order), joined as (l0 + l1) + (l2 + l3).
 // Small weight matrices are cut into many slabs, so the lanes matter more than the columns.
+// A second array (slabs_b, ...) may ride in the same launch: blocks past the first array's share
+// reduce it.  Used for a layer's weight-gradient slabs and its bias-gradient partials.
 __global__ void __launch_bounds__(RX_BLOCK)
-slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, float* __restrict__ out) {
+slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, float* __restrict__ out,
+                   const float* __restrict__ slabs_b, int64_t n_b, int n_slabs_b, float* __restrict__ out_b) {
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  int64_t blk = blockIdx.x;
+  const int64_t blocks_a = (n + 63) / 64;
+  if (blk >= blocks_a) {   // block-uniform switch to the second array
+    blk -= blocks_a;
+    slabs = slabs_b; n = n_b; n_slabs = n_slabs_b; out = out_b;
+  }
+  const int64_t i = blk * 64 + e;
   float s = 0.f;
   if (i < n) {
     int z = q;
@@ -860,8 +869,11 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(X, ldx);
   if (gemm_launch<false, false>(g, n_slabs, bf16, st)) return 1;
   const int64_t nk = (int64_t)N * K;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, 64)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW);
-  RX_LAUNCH_CHECK();
+  if (!db) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, 64)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW,
+                       (const float*)nullptr, (int64_t)0, 0, (float*)nullptr);
+    RX_LAUNCH_CHECK();
+  }
   if (db) {
     // the bias gradient has its own, finer slabs: the column sums are a pure streaming read
     int64_t cs_rows = rx_cdiv(M, COLSUM_SLABS);
@@ -871,7 +883,9 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
     if (vec_ok(dY, ldd) && N % 4 == 0) hipLaunchKernelGGL(colsum_slab_kernel<true>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
     else hipLaunchKernelGGL(colsum_slab_kernel<false>, cgrid, dim3(RX_BLOCK), 0, st, dY, ldd, M, N, cs_rows, bpart);
     RX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, 64)), dim3(RX_BLOCK), 0, st, bpart, (int64_t)N, cs, db);
+    // one launch sums the weight-gradient slabs and the bias-gradient partials
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv(nk, 64) + rx_cdiv(N, 64))), dim3(RX_BLOCK), 0, st, slabs, nk,
+                       n_slabs, dW, (const float*)bpart, (int64_t)N, cs, db);
     RX_LAUNCH_CHECK();
   }
   return 0;

@@ -146,9 +146,14 @@ def gather_concat(segs: Sequence[Segment], out_rows: int, out_cols: int,
     return out
 
 
-def gather_concat_bwd(dout: Tensor, col: int, dim: int, div: int) -> Tensor:
+def gather_concat_bwd(dout: Tensor, col: int, dim: int, div: int, out: Optional[Tensor] = None) -> Tensor:
+    """``out``: a contiguous [rows // div, dim] destination (e.g. a slice of a larger buffer)."""
     _req(dout, torch.float32, "dout", 2)
-    occ = torch.empty(dout.shape[0] // div, dim, dtype=torch.float32, device=dout.device)
+    occ = out if out is not None else torch.empty(dout.shape[0] // div, dim, dtype=torch.float32, device=dout.device)
+    if out is not None:
+        _req(out, torch.float32, "out", 2)
+        if tuple(out.shape) != (dout.shape[0] // div, dim) or not out.is_contiguous():
+            raise ValueError("gather_concat_bwd: bad `out`")
     check(lib.rx_gather_concat_bwd(_p(dout), dout.shape[0], dout.shape[1], col, dim, div, _p(occ),
                                    _dev(dout), _stream(dout)), "rx_gather_concat_bwd")
     return occ
