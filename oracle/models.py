@@ -221,12 +221,29 @@ POINTWISE = ("GMF", "MLP", "NeuMF")
 DEFAULT_DROPOUT = 0.1
 
 
+class _MeanBCE(torch.autograd.Function):
+    """loss = mean(max(x, 0) - x y + log1p(exp(-|x|))), d loss / d x = (sigmoid(x) - y) / numel:
+    the derivative aten's binary_cross_entropy_with_logits uses.  Spelled out because autograd
+    through clamp / abs would give (1 - y) / numel at x == 0 exactly (a logit is exactly zero
+    whenever every ReLU in front of a zero-bias output layer is off)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        ctx.save_for_backward(x, y)
+        return (torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return (torch.sigmoid(x) - y) * (g / x.numel()), None
+
+
 def bce_with_logits(logits: Tensor, labels: Tensor) -> Tensor:
     """Mean binary cross entropy; fp32 logits against fp64 labels promote to an fp64 loss,
     as F.binary_cross_entropy_with_logits does at e.g. vanilla_mf.py:35-39 with the labels
     of recsys/dataset.py:184."""
     x = logits.to(labels.dtype) if labels.dtype == torch.float64 else logits
-    return (torch.clamp(x, min=0) - x * labels + torch.log1p(torch.exp(-x.abs()))).mean()
+    return _MeanBCE.apply(x, labels)
 
 
 # --------------------------------------------------------------------------- init

@@ -536,3 +536,17 @@ def test_segreduce_fm_matches_materialised_path(ops, mode):
     rt = 1e-4 if mode == "adagrad" else 1e-5
     assert_close(b.cpu().numpy(), a.cpu().numpy(), rtol=rt, what=f"{mode} rows", atol=1e-9)
     assert_close(b2.cpu().numpy(), a2.cpu().numpy(), rtol=rt, what=f"{mode} bias", atol=1e-9)
+
+
+def test_bce_gradient_at_exactly_zero_logits(ops):
+    """sigmoid(0) = 0.5: the logit gradient there is (0.5 - y) / M, as torch's op gives."""
+    g = _gen(3)
+    x = torch.randn(64, 3, generator=g)
+    x[::7] = 0.0
+    y = (torch.rand(64, 3, generator=g) < 0.4).double()
+    loss, dl = ops.bce_with_logits(x.cuda(), y.cuda())
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-7 * abs(ref.item())
+    assert torch.allclose(dl.cpu(), xr.grad, rtol=1e-6, atol=0)

@@ -69,3 +69,22 @@ def test_optimizer_steps(fixture, opt):
                         a, v = adagrad_well_conditioned(a, v, grads[k], gmax)
                     rtol = 1e-5 if s == 1 else (2e-5 if opt == "sgd" else 1e-4)
                     assert_close(a, v, rtol=rtol, what=f"{opt}{s} {k}")
+
+
+def test_oracle_bce_gradient_matches_torch_op_including_zero_logits():
+    """The restated loss must differentiate like aten's binary_cross_entropy_with_logits, also at
+    logits that are exactly zero (every ReLU in front of a zero-bias output layer off)."""
+    import torch
+    from oracle.models import bce_with_logits
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(7, 5, generator=g)
+    x[0, 0] = x[3, 2] = x[6, 4] = 0.0
+    y = (torch.rand(7, 5, generator=g) < 0.4).double()
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    la = bce_with_logits(a, y)
+    lb = torch.nn.functional.binary_cross_entropy_with_logits(b, y)
+    assert la.dtype == lb.dtype == torch.float64 and torch.allclose(la, lb, rtol=1e-7, atol=0)
+    la.backward(); lb.backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+    assert float(a.grad[0, 0]) == float(b.grad[0, 0])
