@@ -44,7 +44,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     from recsys_amd.optim import FusedOptimizer
 
     torch.manual_seed(1234)
-    n_batches = 8
+    n_batches = 10   # divides the usual step counts, so the timed region replays whole-round graphs only
     if name == "deepfm_criteo_sharded":
         # the Criteo-shaped DeepFM with its tables row-sharded and its BatchNorm tower data parallel
         # (tower gradients summed over the ranks by one all-reduce); 33 M rows x 16 per GPU
