@@ -391,6 +391,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RX_BENCH_SHARE_GPU") == "1":   # rehearsal on a one-GPU machine: every rank opens card 0
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
@@ -400,7 +402,11 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("RX_BENCH_BACKEND", "nccl")   # "gloo" only for the shared-card rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from recsys_amd import ops
     ops.set_index_check("deferred")
