@@ -390,6 +390,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("RX_BENCH_WATCHDOG"):   # seconds; a stuck run prints every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RX_BENCH_WATCHDOG"]), exit=True)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("RX_BENCH_SHARE_GPU") == "1":   # rehearsal on a one-GPU machine: every rank opens card 0
         local = 0
@@ -407,6 +410,15 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+            # gloo's device all-to-all stalls now and then with tens of MB in flight between two
+            # processes on one card; the rehearsal sends host copies instead
+            inner = dist.all_to_all_single
+
+            def staged(out, inp, *rest, **kw):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                inner(o, inp.cpu(), *rest, **kw)
+                out.copy_(o)
+            dist.all_to_all_single = staged
 
     from recsys_amd import ops
     ops.set_index_check("deferred")
@@ -496,6 +508,15 @@ def main():
         out["embedding_hbm"] = {"algorithmic_bytes_per_sample": bps, "achieved": bps * value / world / 1e9, "unit": "GB/s per GPU",
                                 "peak": HBM_PEAK_GBS, "frac": bps * value / world / 1e9 / HBM_PEAK_GBS,
                                 "note": "whole step (fwd + bwd + update), all kernels, at the measured distinct-row fraction"}
+    cap_slots = getattr(w["model"], "capacity", None)
+    if world > 1 and cap_slots:
+        # third bound of the sharded step: bytes a rank puts on its xGMI links per step (slot ids out,
+        # rows + bias entries back, gradients of both out), the share addressed to itself excluded
+        D = w["desc"]["dim"]
+        sent = (world - 1) * cap_slots * (8 + 2 * (4 * D + 4))
+        out["xgmi"] = {"bytes_sent_per_gpu_per_step": sent, "achieved": sent / (el / args.steps) / 1e9, "unit": "GB/s per GPU",
+                       "peak": 1070.0, "frac": sent / (el / args.steps) / 1e9 / 1070.0,
+                       "note": "egress per GPU against 7 links x 153 GB/s; exchanges are not overlapped with compute yet"}
     del w
     torch.cuda.empty_cache()
 
