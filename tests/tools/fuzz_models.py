@@ -2,7 +2,7 @@
 """Randomised model-level cross-checks: a random reference model class at random sizes (batch,
 items per row, embedding width, table sizes) on the GPU against the CPU restatement under oracle/:
 training loss, every parameter gradient, evaluation logits.  The oracle is the checker only.
-Usage: python profiles/fuzz_models.py [seconds] [seed]"""
+Usage: python tests/tools/fuzz_models.py [seconds] [seed]"""
 import inspect
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.models import OracleModel, init_state  # noqa: E402
 from recsys_amd.models import matrix_factorization as mf, neuralcf as ncf  # noqa: E402
