@@ -55,17 +55,35 @@ def test_fused_steps(name, kind, clip):
     from recsys_amd.optim import FusedOptimizer
     oracle, m, batch = _pair(name)
     dbatch = {k: v.cuda() for k, v in batch.items()}
-    opt = FusedOptimizer(m, kind=kind, lr=0.05, clip_norm=clip)
+    opt = FusedOptimizer(m, kind=kind, lr=0.05, clip_norm=clip, dense_kind="sgd" if kind == "rowwise_adagrad" else None)
     if kind == "rowwise_adagrad":
-        # no torch counterpart: check that it runs, moves only touched rows, and is reproducible
-        before = m.feature_embedding.weight.detach().clone()
-        opt.zero_grad(); m.loss(dbatch).backward(); opt.step()
-        after = m.feature_embedding.weight.detach()
-        touched = torch.zeros(before.shape[0], dtype=torch.bool)
+        # no torch counterpart (parity unpinned): the rule is restated here on the oracle's dense table
+        # gradients -- state[r] += mean_d g[r, d]^2, w[r] -= lr g[r] / (sqrt(state[r]) + eps) on touched
+        # rows -- with plain SGD on the tower (dense_kind above)
         offs = torch.tensor([0] + DIMS[:-1]).cumsum(0)
+        touched = torch.zeros(sum(DIMS), dtype=torch.bool)
         touched[(batch["sparse"] + offs[None, :]).reshape(-1)] = True
-        assert torch.equal(after.cpu()[~touched], before.cpu()[~touched])
-        assert not torch.equal(after.cpu()[touched], before.cpu()[touched])
+        before = m.feature_embedding.weight.detach().cpu().clone()
+        tables = {k: p for k, p in oracle.params.items() if k in ("feature_embedding.weight", "bias_embedding.weight")}
+        state = {k: torch.zeros(p.shape[0]) for k, p in tables.items()}
+        dense = [p for k, p in oracle.params.items() if k not in tables]
+        for _ in range(2):
+            opt.zero_grad(); lm = m.loss(dbatch); lm.backward(); opt.step()
+            for p in oracle.parameters():
+                p.grad = None
+            lo = oracle.loss(batch); lo.backward()
+            assert_close(lm.item(), lo.item(), rtol=1e-5, what="loss")
+            with torch.no_grad():
+                for k, p in tables.items():
+                    state[k] += (p.grad ** 2).mean(1)
+                    upd = 0.05 * p.grad / (state[k].sqrt()[:, None] + 1e-10)
+                    p -= torch.where(touched[:, None], upd, torch.zeros_like(upd))
+                for p in dense:
+                    p -= 0.05 * p.grad
+        sd = m.state_dict()
+        for k, p in tables.items():
+            assert_close(sd[k].cpu().numpy(), p.detach().numpy(), rtol=1e-4, what=k)
+        assert torch.equal(sd["feature_embedding.weight"].cpu()[~touched], before[~touched])
         return
     ref = (torch.optim.SGD if kind == "sgd" else torch.optim.Adagrad)(oracle.parameters(), lr=0.05)
     for _ in range(3):

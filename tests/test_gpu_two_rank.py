@@ -1,4 +1,4 @@
-"""Two ranks with the real HIP kernels.  A one-GPU machine cannot host two RCCL ranks, so both
+"""Two to four ranks with the real HIP kernels.  A one-GPU machine cannot host two RCCL ranks, so both
 processes open the same card and the collectives travel over gloo; everything else — owner
 buckets, fixed-capacity slots, owner-side sort / reduce / update, the global clip, the tower
 all-reduce — is the code that runs under RCCL on a multi-GPU node.  Checked against the CPU
@@ -62,6 +62,8 @@ def _stage_collectives_through_host():
 
 
 def _worker(rank, world, port, model, kind, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)     # a stuck collective names itself
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -118,11 +120,11 @@ def _worker(rank, world, port, model, kind, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("model,kind", [("fm", "sgd"), ("fm", "sgd+capacity+clip"), ("fm", "adagrad+capacity"),
-                                        ("deepfm", "sgd+capacity+clip")])
-def test_two_ranks_on_one_card_match_whole_batch_step(tmp_path, model, kind):
+@pytest.mark.parametrize("model,kind,world", [("fm", "sgd", 2), ("fm", "sgd+capacity+clip", 2), ("fm", "adagrad+capacity", 2),
+                                              ("fm", "rowwise_adagrad+capacity", 2), ("deepfm", "sgd+capacity+clip", 2),
+                                              ("fm", "sgd+capacity+clip", 4), ("deepfm", "sgd+capacity", 3)])
+def test_ranks_on_one_card_match_whole_batch_step(tmp_path, model, kind, world):
     from oracle.fields import FieldOracle
-    world = 2
     out = str(tmp_path / "shards.pt")
     mp.spawn(_worker, args=(world, _free_port(), model, kind, out), nprocs=world, join=True)
     shards = torch.load(out, weights_only=False)
@@ -139,6 +141,10 @@ def test_two_ranks_on_one_card_match_whole_batch_step(tmp_path, model, kind):
     opt = (torch.optim.Adagrad if rule == "adagrad" else torch.optim.SGD)(oracle.parameters(), lr=0.1)
     batch = _global_batch(world)
     halves = [{k: v[r * B_LOCAL:(r + 1) * B_LOCAL] for k, v in batch.items()} for r in range(world)]
+    offs = torch.tensor([0] + DIMS[:-1]).cumsum(0)
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[(batch["sparse"] + offs[None, :]).reshape(-1)] = True
+    row_state = {k: torch.zeros(n) for k in ("feature_embedding.weight", "bias_embedding.weight")}
     ref_losses = []
     for _ in range(2):
         opt.zero_grad()
@@ -146,7 +152,16 @@ def test_two_ranks_on_one_card_match_whole_batch_step(tmp_path, model, kind):
         (sum(per_rank) / world).backward()
         if clip is not None:
             torch.nn.utils.clip_grad_norm_(oracle.parameters(), clip)
-        opt.step()
+        if rule == "rowwise_adagrad":
+            # no torch counterpart: state[r] += mean_d g[r, d]^2, w[r] -= lr g[r] / (sqrt(state[r]) + eps), touched rows only
+            with torch.no_grad():
+                for k, st in row_state.items():
+                    p = oracle.params[k]
+                    st += (p.grad ** 2).mean(1)
+                    upd = 0.1 * p.grad / (st.sqrt()[:, None] + 1e-10)
+                    p -= torch.where(touched[:, None], upd, torch.zeros_like(upd))
+        else:
+            opt.step()
         ref_losses.append([l.item() for l in per_rank])
     got = torch.stack([s[2] for s in shards]).T          # [step, rank]
     assert torch.allclose(got, torch.tensor(ref_losses, dtype=got.dtype), rtol=1e-5)
