@@ -102,6 +102,21 @@ class ShardedTable:
             dist.all_to_all_single(recv_idx, packed, group=self.group)
         return dict(fixed=True, recv_idx=recv_idx, src_of=src_of, n_valid=n_valid, capacity=capacity, n=idx.numel())
 
+    def sort_received_ahead(self, plan, side) -> None:
+        """The owner-side sort of a fixed-capacity plan needs only the slot ids that arrived in the
+        forward pass: issue it on ``side`` right after the index exchange, so that the backward pass
+        finds it done instead of running it between the gradient exchange and the reduce."""
+        recv_idx = plan["recv_idx"]
+        if not recv_idx.is_cuda or recv_idx.numel() == 0:
+            return
+        side.wait_stream(torch.cuda.current_stream(recv_idx.device))      # the index exchange
+        recv_idx.record_stream(side)
+        with torch.cuda.stream(side):
+            si = self.ops.sort_dedup(recv_idx, self.local_rows)
+            done = torch.cuda.Event()
+            done.record(side)
+        plan["owner_sort"] = (si, done)
+
     def _swap(self, buf: torch.Tensor) -> torch.Tensor:
         """All-to-all of a [G * capacity, ...] buffer with equal splits."""
         if self.G == 1 and not self.force_exchange:
@@ -177,7 +192,16 @@ class ShardedTable:
         the duplicates in that fixed order, then accumulate (no rule) or update in place."""
         if got.shape[0] == 0:
             return
-        si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
+        ahead = plan.get("owner_sort")
+        if ahead is not None:       # sorted on a side stream while the forward pass ran (sort_received_ahead)
+            si, done = ahead
+            main = torch.cuda.current_stream(got.device)
+            main.wait_event(done)
+            for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            si = self.ops.sort_dedup(plan["recv_idx"], self.local_rows)
         if self.rule is None:
             g = torch.zeros_like(self.weight)
             g2 = torch.zeros_like(companion.weight) if companion is not None else None
@@ -497,6 +521,11 @@ class _ShardedFM(torch.autograd.Function):
             # distinct row -> slot is composed on the index side, 8 bytes per occurrence instead of a
             # copy of every row
             plan = feat.plan_fixed(si.uniq_rows, si.n_uniq, model.capacity, packed)
+            if flat.is_cuda and ctx.needs_input_grad[0]:     # a backward pass will follow
+                side = model._pos.get("owner_side")
+                if side is None:
+                    side = model._pos["owner_side"] = torch.cuda.Stream(device=flat.device)
+                feat.sort_received_ahead(plan, side)
             rows_p, bias_p = feat.gather_packed(plan), bias.gather_packed(plan)
             slot_of = plan["src_of"].to(torch.int64)
             occ_slot = slot_of[si.inverse.to(torch.int64)]

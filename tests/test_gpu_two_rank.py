@@ -49,7 +49,8 @@ def _global_batch(world, seed=1):
 
 
 def _stage_collectives_through_host():
-    """gloo builds without device all-to-all: same call, buffers staged through host memory."""
+    """gloo's own device all-to-all stalls now and then between processes that share a card (every
+    rank inside the same call, the device idle), so the buffers cross gloo as host tensors."""
     native = dist.all_to_all_single
 
     def staged(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
@@ -69,12 +70,7 @@ def _worker(rank, world, port, model, kind, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        try:
-            probe = torch.zeros(world, device="cuda")
-            dist.all_to_all_single(torch.empty_like(probe), probe)
-        except Exception as exc:
-            print("gloo device all-to-all unavailable, staging through the host:", type(exc).__name__, flush=True)
-            _stage_collectives_through_host()
+        _stage_collectives_through_host()
         from recsys_amd import ops
         from recsys_amd.sharded import ShardedFieldDeepFM, ShardedFieldFM, ShardedTable
         batch = _global_batch(world)
