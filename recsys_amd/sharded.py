@@ -346,21 +346,24 @@ class ShardedFieldFM(torch.nn.Module):
             flat = self._flat(sparse)
             si = self.ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
             packed = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
+            slot_of = packed[1].to(torch.int64)
+            occ_slot = slot_of[si.inverse.to(torch.int64)]       # occurrence -> distinct row -> slot
             done = torch.cuda.Event()
             done.record(side)
         out = dict(inputs)
-        out["_rx_shard_prep"] = (si, packed, done, flat)
+        out["_rx_shard_prep"] = (si, packed, done, flat, slot_of, occ_slot)
         return out
 
     @staticmethod
     def _join_prep(prep, device):
         """Make the current stream wait for a prepare() result and own its tensors from here on."""
-        si, packed, done, flat = prep
+        si, packed, done, flat, slot_of, occ_slot = prep
         main = torch.cuda.current_stream(device)
         main.wait_event(done)
-        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], flat):
+        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], flat,
+                  slot_of, occ_slot):
             t.record_stream(main)
-        return si, packed
+        return si, packed, slot_of, occ_slot
 
     def set_rule(self, kind, lr, eps=1e-10, clip_norm: Optional[float] = None):
         """``clip_norm``: clip the global gradient norm (all tables on all ranks, plus any dense
@@ -511,9 +514,9 @@ class _ShardedFM(torch.autograd.Function):
         ops, feat, bias = model.ops, model.feature, model.bias
         n = flat.numel()
         want_deep = deep_cols is not None
-        packed = None
+        packed = slot_of = occ_slot = None
         if prep is not None:        # prepared on the side stream (ShardedFieldFM.prepare)
-            si, packed = model._join_prep(prep, flat.device)
+            si, packed, slot_of, occ_slot = model._join_prep(prep, flat.device)
         else:
             si = ops.sort_dedup(flat, feat.n_rows, want_inverse=True)
         if model.capacity:
@@ -526,9 +529,15 @@ class _ShardedFM(torch.autograd.Function):
                 if side is None:
                     side = model._pos["owner_side"] = torch.cuda.Stream(device=flat.device)
                 feat.sort_received_ahead(plan, side)
+                with torch.cuda.stream(side):      # the zero-filled send buffers of the backward pass, off the critical path
+                    n_slots = plan["recv_idx"].numel()
+                    ctx.sent = (torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=flat.device),
+                                torch.zeros(n_slots, dtype=torch.float32, device=flat.device), torch.cuda.Event())
+                    ctx.sent[2].record(side)
             rows_p, bias_p = feat.gather_packed(plan), bias.gather_packed(plan)
-            slot_of = plan["src_of"].to(torch.int64)
-            occ_slot = slot_of[si.inverse.to(torch.int64)]
+            if occ_slot is None:
+                slot_of = plan["src_of"].to(torch.int64)
+                occ_slot = slot_of[si.inverse.to(torch.int64)]
             base = model._zero_base(F, flat.device)
             logits, deep, tsum = ops.fm2_fwd(rows_p, bias_p.reshape(-1), occ_slot[:B * F].reshape(B, F), base,
                                              occ_slot[B * F:].reshape(B, 1), 0, want_deep=want_deep, deep_cols=deep_cols,
@@ -565,8 +574,15 @@ class _ShardedFM(torch.autograd.Function):
             # reduce writes its gradient row straight into the send buffer's slot (unused slots stay 0)
             n_slots = rows_u.shape[0]
             by_slot = ops.SortedIndex(si.n, n_slots, si.sorted_pos, si.sorted_slot, ctx.slot_of, si.seg_off, si.n_uniq, None)
-            sent = torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=g.device)
-            sent2 = torch.zeros(n_slots, dtype=torch.float32, device=g.device)
+            ahead = getattr(ctx, "sent", None)
+            if ahead is not None:       # zero-filled on the side stream during the forward pass
+                sent, sent2, filled = ahead
+                main = torch.cuda.current_stream(g.device)
+                main.wait_event(filled)
+                sent.record_stream(main); sent2.record_stream(main)
+            else:
+                sent = torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=g.device)
+                sent2 = torch.zeros(n_slots, dtype=torch.float32, device=g.device)
             ops.segreduce_fm(tsum, g.reshape(-1).contiguous(), ctx.F, by_slot, _lib.RX_SEG_DENSE, sent, table=rows_u,
                              target2=sent2, deep=g_deep)
             feat.reduce_packed(sent, ctx.plan, bias, sent2)

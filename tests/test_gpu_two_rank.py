@@ -94,6 +94,7 @@ def _worker(rank, world, port, model, kind, out):
         m.set_rule(rule, lr=0.1, clip_norm=clip)
         losses = []
         for _ in range(2):
+            local = m.prepare(local) if fixed and "_rx_shard_prep" not in local else {k: v for k, v in local.items() if k != "_rx_shard_prep"}
             if model == "fm":
                 loss = m.loss(local)
                 (loss / world).backward()
