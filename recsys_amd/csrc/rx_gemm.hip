@@ -762,7 +762,12 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
     RX_LAUNCH_CHECK();
     return 0;
   }
-  if (!bf16 && g.N > 64 && pipe_ok_f32<A_KC, B_KC>(g)) {
+  // Short reductions (K <= 128) and short outputs (M <= 64) at N <= 128 are bound by memory and
+  // latency, not by MFMA rate: 64-row tiles of the single-buffered kernel put twice as many
+  // workgroups on the chip and beat the pipelined 128 x 128 kernel there (measured at M = 40960:
+  // grad-X of 128->64 23.7 -> 18.8 us, its grad-W 49 -> 37 us).
+  const bool skinny = !bf16 && g.N <= 128 && (g.k_per_slab <= 128 || g.M <= 64);
+  if (!bf16 && g.N > 64 && !skinny && pipe_ok_f32<A_KC, B_KC>(g)) {
     g.tiles_n = (int)rx_cdiv(g.N, G2_T);
     const int64_t blocks = tiles_m * g.tiles_n;
     RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");
@@ -773,20 +778,22 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
     RX_LAUNCH_CHECK();
     return 0;
   }
-#define RX_GEMM_GO(BN_, WM_, WN_)                                                                       \
+#define RX_GEMM_GO(BM_, BN_, WM_, WN_)                                                                  \
   do {                                                                                                  \
     g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
-    const int64_t blocks = tiles_m * g.tiles_n;                                                         \
+    const int64_t blocks = rx_cdiv(g.M, BM_) * g.tiles_n;                                               \
     RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");                                           \
     dim3 grid((unsigned)blocks, 1, (unsigned)n_slabs);                                                  \
     if (bf16)                                                                                           \
-      hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, 128, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g); \
+      hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, BM_, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g); \
     else                                                                                                \
-      hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 128, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g);  \
+      hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, BM_, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g);  \
   } while (0)
-  if (g.N <= 32) RX_GEMM_GO(32, 4, 1);
-  else if (g.N <= 64) RX_GEMM_GO(64, 2, 2);
-  else RX_GEMM_GO(128, 2, 2);
+  if (g.N <= 32) RX_GEMM_GO(128, 32, 4, 1);
+  else if (g.N <= 64 && !bf16) RX_GEMM_GO(64, 64, 2, 2);   // fwd 128->64 at M = 40960: 23.0 -> 15.7 us
+  else if (g.N <= 64) RX_GEMM_GO(128, 64, 2, 2);
+  else if (skinny) RX_GEMM_GO(64, 128, 2, 2);
+  else RX_GEMM_GO(128, 128, 2, 2);
 #undef RX_GEMM_GO
   RX_LAUNCH_CHECK();
   return 0;
@@ -833,7 +840,7 @@ static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
   // enough slabs to put >= ~768 blocks (three per CU) on the chip, each slab a multiple of the k-step
   const int64_t tiles = rx_cdiv(N, 128) * rx_cdiv(K, (K <= 32 ? 32 : (K <= 64 ? 64 : 128)));
   int64_t want = rx_cdiv(768, tiles);
-  int64_t max_by_rows = rx_cdiv(M, 256);
+  int64_t max_by_rows = rx_cdiv(M, 128);   // 128-row slabs: 64-row ones cost more in the slab sum than they gain
   if (want > max_by_rows) want = max_by_rows;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
