@@ -801,6 +801,143 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
 
 static inline int vec_ok(const float* p, int64_t ld) { return (ld % 4 == 0) && rx_aligned16(p); }
 
+
+// ---------------------------------------------------------------- one output column (N = 1)
+// The last layer of every tower is Linear(K, 1): a matrix-vector product per direction, bound by
+// the one streaming pass over X (or dX).  A tile of the MFMA kernels would carry one useful
+// column out of 32.  LPR lanes of 16 bytes cover a row (LPR = power of two >= K / 4, K <= 256).
+template <int LPR>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv_fwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                float* __restrict__ Y, int64_t ldy, int64_t M, int K, int act) {
+  constexpr int RL = RX_BLOCK / LPR;
+  const int cq = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int k0 = cq * 4;
+  const bool ok = k0 < K;
+  const float4 wv = ok ? *reinterpret_cast<const float4*>(w + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bv = b ? b[0] : 0.f;
+  const int kk = ok ? k0 : 0;
+  for (int64_t r0 = (int64_t)blockIdx.x * RL * 4; r0 < M; r0 += (int64_t)gridDim.x * RL * 4) {
+    float4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = r0 + u * RL + rl;
+      x[u] = *reinterpret_cast<const float4*>(X + (r < M ? r : 0) * ldx + kk);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s = ok ? ((x[u].x * wv.x + x[u].y * wv.y) + (x[u].z * wv.z + x[u].w * wv.w)) : 0.f;
+#pragma unroll
+      for (int d = LPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+      const int64_t r = r0 + u * RL + rl;
+      if (cq == 0 && r < M) {
+        float v = s + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        Y[r * ldy] = v;
+      }
+    }
+  }
+}
+
+// dX[m, k] (+)= dy[m] * w[k]
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv_bwd_x_kernel(const float* __restrict__ dY, int64_t ldd, const float* __restrict__ w, float* __restrict__ dX,
+                  int64_t ldx, int64_t M, int K, int accumulate) {
+  const int kq = K / 4;
+  const int64_t total = M * kq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / kq;
+    const int k0 = (int)(i - m * kq) * 4;
+    const float g = dY[m * ldd];
+    const float4 wv = *reinterpret_cast<const float4*>(w + k0);
+    float4* dst = reinterpret_cast<float4*>(dX + m * ldx + k0);
+    float4 v = make_float4(g * wv.x, g * wv.y, g * wv.z, g * wv.w);
+    if (accumulate) {
+      const float4 o = *dst;
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *dst = v;
+  }
+}
+
+// slab z: part_w[z][k] = sum over its rows of dy[m] * X[m, k], part_b[z] = sum of dy[m]; rows in
+// a fixed order per lane, lanes joined in a fixed order, so results are reproducible.
+template <int LPR>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv_bwd_w_kernel(const float* __restrict__ dY, int64_t ldd, const float* __restrict__ X, int64_t ldx, int64_t M, int K,
+                  int64_t rows_per_slab, float* __restrict__ part_w, float* __restrict__ part_b) {
+  constexpr int RL = RX_BLOCK / LPR;
+  __shared__ float red[RL][LPR * 4 + 1];
+  __shared__ float redb[RL];
+  const int cq = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int k0 = cq * 4;
+  const bool ok = k0 < K;
+  const int kk = ok ? k0 : 0;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  int64_t r = lo + rl;
+  for (; r + 3 * RL < hi; r += 4 * RL) {
+    float4 x[4];
+    float g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = *reinterpret_cast<const float4*>(X + (r + u * RL) * ldx + kk);
+      g[u] = dY[(r + u * RL) * ldd];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s[0] += g[u] * x[u].x; s[1] += g[u] * x[u].y; s[2] += g[u] * x[u].z; s[3] += g[u] * x[u].w;
+      sb += g[u];
+    }
+  }
+  for (; r < hi; r += RL) {
+    const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + kk);
+    const float g = dY[r * ldd];
+    s[0] += g * x.x; s[1] += g * x.y; s[2] += g * x.z; s[3] += g * x.w;
+    sb += g;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][k0 + e] = s[e];
+  if (cq == 0) redb[rl] = sb;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) t += red[q][threadIdx.x];
+    part_w[(int64_t)blockIdx.x * K + threadIdx.x] = t;
+  }
+  if (threadIdx.x == 0 && part_b) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) t += redb[q];
+    part_b[blockIdx.x] = t;
+  }
+}
+
+static inline int gemv_lpr(int K) {
+  int l = 1;
+  while (l * 4 < K) l <<= 1;
+  return l;
+}
+
+// N = 1 with 16-byte-addressable rows of at most 256 columns
+static inline bool gemv_ok(int32_t N, int32_t K, const float* X, int64_t ldx, const float* w, int bf16) {
+  return N == 1 && !bf16 && K % 4 == 0 && K >= 4 && K <= 256 && vec_ok(X, ldx) && rx_aligned16(w);
+}
+
+#define RX_GEMV_DISPATCH(KERNEL, lpr, ...)                                                    \
+  switch (lpr) {                                                                              \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), __VA_ARGS__); break;                              \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), __VA_ARGS__); break;                              \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), __VA_ARGS__); break;                              \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), __VA_ARGS__); break;                              \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), __VA_ARGS__); break;                            \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__); break;                            \
+    default: hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__); break;                            \
+  }
+
 extern "C" int rx_linear_fwd(const float* X, int64_t ldx, const float* W, const float* b, float* Y,
                              int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int bf16, int device,
                              void* stream) {
@@ -816,6 +953,15 @@ extern "C" int rx_linear_fwd(const float* X, int64_t ldx, const float* W, const 
   g.M = M; g.N = N; g.K = K; g.act = act; g.accumulate = 0;
   g.k_per_slab = K; g.c_slab_stride = 0;
   g.a_vec = vec_ok(X, ldx); g.b_vec = vec_ok(W, K);
+  if (gemv_ok(N, K, X, ldx, W, bf16)) {
+    const int lpr = gemv_lpr(K);
+    const int64_t rows_per_block = (RX_BLOCK / lpr) * 4;
+    int64_t grid = rx_cdiv(M, rows_per_block);
+    if (grid > 2048) grid = 2048;
+    RX_GEMV_DISPATCH(gemv_fwd_kernel, lpr, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, X, ldx, W, b, Y, ldy, M, (int)K, act);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   return gemm_launch<true, true>(g, 1, bf16, (hipStream_t)stream);
 }
 
@@ -833,6 +979,14 @@ extern "C" int rx_linear_bwd_x(const float* dY, int64_t ldd, const float* W, flo
   g.M = M; g.N = K; g.K = N; g.act = 0; g.accumulate = accumulate;
   g.k_per_slab = N; g.c_slab_stride = 0;
   g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(W, K);
+  if (gemv_ok(N, K, dX, ldx, W, bf16)) {
+    int64_t grid = rx_cdiv(M * (K / 4), RX_BLOCK);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gemv_bwd_x_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dY, ldd, W, dX, ldx, M, (int)K,
+                       accumulate);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   return gemm_launch<true, false>(g, 1, bf16, (hipStream_t)stream);
 }
 
@@ -850,7 +1004,8 @@ static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
 extern "C" size_t rx_linear_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K) {
   if (M <= 0 || N < 1 || K < 1) return 256;
   const int s = bwd_w_slabs(M, N, K);
-  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up((size_t)COLSUM_SLABS * N * sizeof(float), 256);
+  const size_t bslabs = (size_t)(s > COLSUM_SLABS ? s : COLSUM_SLABS);   // the N = 1 path keeps one bias partial per weight slab
+  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up(bslabs * N * sizeof(float), 256);
 }
 
 extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, float* dW,
@@ -867,6 +1022,16 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   const int n_slabs = (int)rx_cdiv(M, rows_per_slab);
   float* slabs = (float*)ws;
   float* bpart = (float*)((char*)ws + rx_align_up((size_t)s * N * K * sizeof(float), 256));
+  if (gemv_ok(N, K, X, ldx, dW, bf16)) {
+    const int lpr = gemv_lpr(K);
+    RX_GEMV_DISPATCH(gemv_bwd_w_kernel, lpr, dim3((unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY, ldd, X, ldx, M, (int)K, rows_per_slab,
+                     slabs, db ? bpart : (float*)nullptr);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv((int64_t)K, 64) + (db ? 1 : 0))), dim3(RX_BLOCK), 0, st, slabs,
+                       (int64_t)K, n_slabs, dW, (const float*)bpart, (int64_t)(db ? 1 : 0), n_slabs, db);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   GemmArgs g{};
   g.A = dY; g.a_rs = 1; g.a_cs = ldd;     // A(n, m) = dY[m, n]
   g.B = X; g.b_rs = ldx; g.b_cs = 1;      // B(m, k) = X[m, k]

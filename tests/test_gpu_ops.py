@@ -354,6 +354,31 @@ def test_linear_fp32_matches_cpu(ops, M, N, K, act):
     assert_close(db.cpu().numpy(), dy.double().sum(0).numpy(), what="linear bwd b")
 
 
+@pytest.mark.parametrize("M,K", [(1, 4), (37, 64), (1000, 108), (4099, 256), (40960, 64), (65536, 108), (300, 20)])
+def test_linear_single_output_column(ops, M, K):
+    """Linear(K, 1), the last layer of every tower, takes the matrix-vector kernels: forward with and
+    without ReLU / bias, grad-X plain and accumulating, grad-W + grad-b, on a column block of a wider
+    matrix as well (row stride > K)."""
+    g = _gen(M + K)
+    wide = torch.randn(M, K + 8, generator=g).cuda()
+    x = wide[:, 4:4 + K]                      # 16-byte aligned rows with a row stride of K + 8
+    w, b = (torch.randn(1, K, generator=g) / K ** 0.5).cuda(), torch.randn(1, generator=g).cuda()
+    xd, wd = x.double().cpu(), w.double().cpu()
+    for act in (0, 1):
+        y = ops.linear_fwd(x, w, b, act).cpu()
+        exp = xd @ wd.T + b.double().cpu()
+        assert_close(y.numpy(), (exp.relu() if act else exp).numpy(), what="fwd")
+    assert_close(ops.linear_fwd(x, w, None, 0).cpu().numpy(), (xd @ wd.T).numpy(), what="fwd without bias")
+    dy = torch.randn(M, 1, generator=g).cuda()
+    dx = ops.linear_bwd_x(dy, w)
+    assert_close(dx.cpu().numpy(), (dy.double().cpu() @ wd).numpy(), what="bwd x")
+    dw, db = ops.linear_bwd_w(dy, x)
+    assert_close(dw.cpu().numpy(), (dy.double().cpu().T @ xd).numpy(), what="bwd w")
+    assert_close(db.cpu().numpy(), dy.double().cpu().sum(0).numpy(), what="bwd b")
+    dw2, db2 = ops.linear_bwd_w(dy, x)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "run-to-run bits"
+
+
 def test_linear_tile_layout_asymmetric(ops):
     """A = I against an asymmetric B catches a transposed accumulator write."""
     n = 96
