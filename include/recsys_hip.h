@@ -405,6 +405,14 @@ int rx_cross_combine_fwd(const float* x0, int64_t ld0, const float* u, int64_t l
 int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u,
                          int64_t ldu, float* du, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl,
                          int64_t ldxl, int64_t rows, int32_t cols, int device, void* stream);
+/* The same pass for a stack of cross layers walked from the last to the first with ONE dX0 buffer:
+ * `accumulate` = 0 writes dX0 (last layer: no zero fill), != 0 adds to it; `identity` != 0 also adds
+ * dXn itself (first layer, whose x_l is x0); dxl may be NULL (inner layers: the grad-X GEMM then
+ * accumulates straight into the buffer dXn lives in). */
+int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u,
+                               int64_t ldu, float* du, int64_t lddu, float* dx0_acc, int64_t ldx0,
+                               float* dxl, int64_t ldxl, int64_t rows, int32_t cols, int accumulate,
+                               int identity, int device, void* stream);
 
 /* ------------------------------------------------------------------ row-sharded exchange helpers
  * No counterpart in the reference (single device).  Row r of a table lives on rank r % G at

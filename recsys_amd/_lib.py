@@ -95,6 +95,8 @@ PROTOTYPES = {
     "rx_relu_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "rx_cross_combine_fwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_cross_combine_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
+    "rx_cross_combine_bwd_stack": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, C.c_int,
+                                             C.c_int, vp]),
     "rx_bucketize_workspace_bytes": (sz, [i64, i32]),
     "rx_bucketize_by_owner": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_unpermute_rows": (C.c_int, [vp, vp, i64, vp, i32, vp, C.c_int, vp]),

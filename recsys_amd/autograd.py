@@ -334,6 +334,56 @@ class CrossLayer(Function):
         return dx0, dxl, dw, db, None
 
 
+class CrossStack(Function):
+    """A whole stack of cross layers, x_{l+1} = x0 * (x_l W_l^T + b_l) + x_l with x_0 = x0, as one
+    autograd node: the backward walk keeps ONE dX0 buffer for all layers (no zero fills, no
+    per-layer gradient sums by autograd) and lets the grad-X GEMM of an inner layer accumulate
+    straight into the buffer the incoming gradient lives in."""
+
+    @staticmethod
+    def forward(ctx, x0, bf16, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        xs, us, x = [], [], x0
+        for w, b in zip(ws, bs):
+            u = ops.linear_fwd(x, w, b, 0, bf16)
+            xs.append(x)
+            us.append(u)
+            x = ops.cross_combine_fwd(x0, u, x)
+        ctx.save_for_backward(x0, *xs[1:], *us, *ws)
+        ctx.bf16, ctx.L = bf16, len(ws)
+        return x
+
+    @staticmethod
+    def backward(ctx, dxn):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x0 = saved[0]
+        xs = (x0,) + tuple(saved[1:L])
+        us, ws = saved[L:2 * L], saved[2 * L:3 * L]
+        d = dxn if dxn.stride(-1) == 1 else dxn.contiguous()
+        dx0 = ops._padded(x0.shape[0], x0.shape[1], x0.device)
+        grads = [None] * (2 * L)
+        for l in range(L - 1, -1, -1):
+            last, first = l == L - 1, l == 0
+            # the incoming gradient of the last layer belongs to autograd: copy it (dxl) before the
+            # GEMM adds to it; further down `d` is this function's own buffer
+            du, dxl = ops.cross_combine_bwd_stack(d, x0, us[l], dx0, accumulate=not last, identity=first,
+                                                  want_dxl=last and not first)
+            target = dx0 if first else (dxl if last else d)
+            ops.linear_bwd_x(du, ws[l], ctx.bf16, out=target, accumulate=True)
+            grads[2 * l], grads[2 * l + 1] = ops.linear_bwd_w(du, xs[l], True, ctx.bf16)
+            d = target
+        return (dx0, None) + tuple(grads)
+
+
+def cross_stack(x0: Tensor, layers, bf16: bool = False) -> Tensor:
+    """``layers``: modules with ``weight`` [d, d] and ``bias`` [d] (nn.Linear), first layer first."""
+    wb = []
+    for m in layers:
+        wb += [m.weight, m.bias]
+    return CrossStack.apply(x0, bf16, *wb)
+
+
 # ------------------------------------------------------------------ loss
 class BatchNormAct(Function):
     """BatchNorm1d (+ ReLU) (+ Dropout) of the reference's BN towers in three launches forward

@@ -1100,15 +1100,18 @@ __global__ void __launch_bounds__(RX_BLOCK)
 cross_bwd_kernel(const float* __restrict__ dxn, int64_t ldd, const float* __restrict__ x0, int64_t ld0,
                  const float* __restrict__ u, int64_t ldu, float* __restrict__ du, int64_t lddu,
                  float* __restrict__ dx0_acc, int64_t ldx0, float* __restrict__ dxl, int64_t ldxl,
-                 int64_t rows, int cols) {
+                 int64_t rows, int cols, int accumulate, int identity) {
   const int64_t n = rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cols;
     const int c = (int)(i - r * cols);
     const float d = dxn[r * ldd + c];
     du[r * lddu + c] = d * x0[r * ld0 + c];
-    dx0_acc[r * ldx0 + c] += d * u[r * ldu + c];
-    dxl[r * ldxl + c] = d;
+    float g0 = d * u[r * ldu + c];
+    if (identity) g0 += d;                                   // x_l is x0 itself (first cross layer)
+    if (accumulate) g0 += dx0_acc[r * ldx0 + c];
+    dx0_acc[r * ldx0 + c] = g0;
+    if (dxl) dxl[r * ldxl + c] = d;
   }
 }
 
@@ -1126,17 +1129,36 @@ extern "C" int rx_cross_combine_fwd(const float* x0, int64_t ld0, const float* u
   return 0;
 }
 
+static int cross_combine_bwd_run(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u,
+                                 int64_t ldu, float* du, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl,
+                                 int64_t ldxl, int64_t rows, int32_t cols, int accumulate, int identity, int device,
+                                 void* stream, const char* who) {
+  RX_ENTER(device);
+  RX_REQUIRE(rows >= 0 && cols >= 1 && ldd >= cols && ld0 >= cols && ldu >= cols && lddu >= cols && ldx0 >= cols &&
+                 (!dxl || ldxl >= cols), "%s: bad shape", who);
+  if (rows == 0) return 0;
+  RX_REQUIRE(dxn && x0 && u && du && dx0_acc, "%s: null argument", who);
+  int64_t grid = rx_cdiv(rows * cols, RX_BLOCK);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cross_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, ldd, x0, ld0, u, ldu, du,
+                     lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols, accumulate, identity);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rx_cross_combine_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0,
                                     const float* u, int64_t ldu, float* du, int64_t lddu, float* dx0_acc,
                                     int64_t ldx0, float* dxl, int64_t ldxl, int64_t rows, int32_t cols,
                                     int device, void* stream) {
-  RX_ENTER(device);
-  RX_REQUIRE(rows >= 0 && cols >= 1 && ldd >= cols && ld0 >= cols && ldu >= cols && lddu >= cols && ldx0 >= cols && ldxl >= cols, "rx_cross_combine_bwd: bad shape");
-  if (rows == 0) return 0;
-  RX_REQUIRE(dxn && x0 && u && du && dx0_acc && dxl, "rx_cross_combine_bwd: null argument");
-  int64_t grid = rx_cdiv(rows * cols, RX_BLOCK);
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(cross_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, ldd, x0, ld0, u, ldu, du, lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols);
-  RX_LAUNCH_CHECK();
-  return 0;
+  RX_REQUIRE(dxl, "rx_cross_combine_bwd: null argument");
+  return cross_combine_bwd_run(dxn, ldd, x0, ld0, u, ldu, du, lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols, 1, 0, device, stream,
+                               "rx_cross_combine_bwd");
+}
+
+extern "C" int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const float* x0, int64_t ld0,
+                                          const float* u, int64_t ldu, float* du, int64_t lddu, float* dx0_acc,
+                                          int64_t ldx0, float* dxl, int64_t ldxl, int64_t rows, int32_t cols,
+                                          int accumulate, int identity, int device, void* stream) {
+  return cross_combine_bwd_run(dxn, ldd, x0, ld0, u, ldu, du, lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols, accumulate, identity,
+                               device, stream, "rx_cross_combine_bwd_stack");
 }

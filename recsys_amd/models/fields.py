@@ -155,7 +155,5 @@ class DCNv2(_FieldTable):
         _, x0 = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight, None, True, False,
                               d_emb + self.n_dense + self.pad, False,
                               _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
-        x = x0
-        for layer in self.cross:
-            x = rxa.CrossLayer.apply(x0, x, layer.weight, layer.bias, self.bf16)
+        x = rxa.cross_stack(x0, self.cross, self.bf16) if len(self.cross) else x0
         return run_tower(self.mlp, x, bf16=self.bf16)

@@ -789,6 +789,24 @@ def cross_combine_bwd(dxn, x0, u, dx0_acc):
     return du, dxl
 
 
+def cross_combine_bwd_stack(dxn, x0, u, dx0_acc, accumulate: bool, identity: bool, want_dxl: bool):
+    """One layer of a cross stack walked backwards with a single dX0 buffer (see
+    rx_cross_combine_bwd_stack).  Returns (du, dxl or None)."""
+    dxn, ldd = _mat(dxn, "dxn"); x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u")
+    dx0_acc, ldx0 = _mat(dx0_acc, "dx0")
+    rows, cols = dxn.shape
+    du = _padded(rows, cols, dxn.device)
+    _, lddu = _mat(du, "du")
+    dxl, ldxl = None, 0
+    if want_dxl:
+        dxl = _padded(rows, cols, dxn.device)
+        _, ldxl = _mat(dxl, "dxl")
+    check(lib.rx_cross_combine_bwd_stack(_p(dxn), ldd, _p(x0), ld0, _p(u), ldu, _p(du), lddu, _p(dx0_acc), ldx0,
+                                         _p(dxl), ldxl, rows, cols, int(accumulate), int(identity), _dev(dxn), _stream(dxn)),
+          "rx_cross_combine_bwd_stack")
+    return du, dxl
+
+
 # ------------------------------------------------------------------ exchange helpers / eval
 def bucketize_by_owner(idx: Tensor, world: int, n_rows_global: int, n_valid: Optional[Tensor] = None):
     """``n_valid``: device int32 count of the leading entries that are real (the rest is padding)."""

@@ -174,3 +174,36 @@ def test_pipelined_graph_steps_match_eager_bitwise():
     assert la == lb
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_cross_stack_matches_layer_by_layer(L, bf16):
+    """The whole-stack autograd node (one dX0 buffer, in-place grad-X accumulation) against the
+    per-layer nodes whose gradients autograd sums, and against plain torch in fp64."""
+    import recsys_amd.autograd as rxa
+    from torch import nn
+    torch.manual_seed(L)
+    rows, d = 333, 40
+    layers = nn.ModuleList([nn.Linear(d, d) for _ in range(L)]).cuda()
+    x0 = torch.randn(rows, d, device="cuda", requires_grad=True)
+    gy = torch.randn(rows, d, device="cuda")
+    y = rxa.cross_stack(x0, layers, bf16)
+    got = torch.autograd.grad(y, [x0] + list(layers.parameters()), gy)
+    x = x0
+    for m in layers:
+        x = rxa.CrossLayer.apply(x0, x, m.weight, m.bias, bf16)
+    ref = torch.autograd.grad(x, [x0] + list(layers.parameters()), gy)
+    assert torch.equal(x, y)
+    for a, b in zip(got, ref):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, what="stack vs per-layer gradient")
+    if not bf16:
+        xd = x0.detach().double().requires_grad_(True)
+        ld = [nn.Linear(d, d).double().cuda() for _ in range(L)]
+        z = xd
+        for m, src in zip(ld, layers):
+            m.load_state_dict(src.state_dict())
+            z = xd * m(z) + z
+        exp = torch.autograd.grad(z, [xd] + [p for m in ld for p in m.parameters()], gy.double())
+        for a, b in zip(got, exp):
+            assert_close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, what="stack vs fp64 torch")
