@@ -531,6 +531,8 @@ def main():
         for name in extras:
             # the 64 GB-table workloads need a longer warm-up (allocator growth, first touches)
             n2, wu2 = (96, 24) if name in ("fm_wide_d128", "fm_criteo_sharded") else (30, 5)
+            if name in ("mf_ml1m", "neumf_ml1m"):
+                n2, wu2 = 200, 20      # steps of 0.1-0.4 ms: a 30-step region is a few ms and one hiccup doubles it
             w2, el2, _, _ = run(name, n2, wu2)
             entry = {"workload": name, "samples_per_s": w2["B"] * n2 / el2, "ms_per_step": 1e3 * el2 / n2,
                      "dtype": workload_dtype(name)}
