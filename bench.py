@@ -57,7 +57,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
             model.feature.force_exchange = model.bias.force_exchange = True
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
-        cap = model.calibrate(batches)
+        cap = model.calibrate(batches, slack=1.1)
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank; tower: all-reduce + dense SGD",
                 "clip_norm": clip, "launch": f"eager, asynchronous ({cap} exchange slots per owner)"}
@@ -85,7 +85,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
             model.feature.force_exchange = model.bias.force_exchange = True
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
-        cap = model.calibrate(batches)   # fixed-capacity exchange: equal all-to-all splits, no host read in the step
+        cap = model.calibrate(batches, slack=1.1)   # fixed-capacity exchange: equal all-to-all splits, no host read in the step
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD at the owning rank", "clip_norm": clip,
                 "launch": f"eager, asynchronous (distinct rows only, {cap} exchange slots per owner)"}
