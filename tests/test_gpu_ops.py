@@ -372,9 +372,15 @@ def test_linear_single_output_column(ops, M, K):
     dy = torch.randn(M, 1, generator=g).cuda()
     dx = ops.linear_bwd_x(dy, w)
     assert_close(dx.cpu().numpy(), (dy.double().cpu() @ wd).numpy(), what="bwd x")
+    acc = torch.randn(M, K, generator=g).cuda()
+    exp_acc = acc.double().cpu() + dy.double().cpu() @ wd
+    ops.linear_bwd_x(dy, w, out=acc, accumulate=True)
+    assert_close(acc.cpu().numpy(), exp_acc.numpy(), what="bwd x accumulating")
     dw, db = ops.linear_bwd_w(dy, x)
     assert_close(dw.cpu().numpy(), (dy.double().cpu().T @ xd).numpy(), what="bwd w")
     assert_close(db.cpu().numpy(), dy.double().cpu().sum(0).numpy(), what="bwd b")
+    dw_only, none = ops.linear_bwd_w(dy, x, want_bias=False)
+    assert none is None and torch.equal(dw_only, dw)
     dw2, db2 = ops.linear_bwd_w(dy, x)
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "run-to-run bits"
 
