@@ -456,6 +456,9 @@ def main():
         ops_ms = timer.summary()
         if timed_op and timed_op in timer.last_call:
             ops_ms[timed_op] = back_to_back_ms(timed_op, timer.last_call[timed_op])
+            if timed_op == "linear_bwd_w":      # dW[N, K] = dY[M, N]^T X[M, K]: the shape prices the launch
+                dy_, x_ = timer.last_call[timed_op][0][:2]
+                ops_ms["_gemm_shape"] = (int(dy_.shape[0]), int(dy_.shape[1]), int(x_.shape[1]))
         return w, el, ops_ms, float(loss.item())
 
     if args.op_profile and rank == 0:
@@ -507,6 +510,15 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": measured_traffic(dominant) if args.workload == "fm_criteo" else None, "avg_us": ms * 1e3, "launches_timed": cnt,
                     "algorithmic_bytes_per_launch": ab, "distinct_row_fraction": rho}
+    if roof is None and dominant == "linear_bwd_w" and "_gemm_shape" in ops_ms and dominant in ops_ms:
+        ms, cnt = ops_ms[dominant]
+        M_, N_, K_ = ops_ms["_gemm_shape"]
+        bf = workload_dtype(args.workload) == "bf16"
+        peak = 2500.0 if bf else 157.0        # dense MFMA peaks, TFLOP/s
+        ach = 2.0 * M_ * N_ * K_ / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "linear_bwd_w (the grad-W launched last in the step, i.e. the first layer's, with its slab and bias sums)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "avg_us": ms * 1e3,
+                "launches_timed": cnt, "algorithmic_flops_per_launch": 2.0 * M_ * N_ * K_, "shape_M_N_K": [M_, N_, K_]}
     out["roofline"] = roof
     if args.workload in ("fm_criteo", "fm_wide_d128", "fm_criteo_sharded"):
         bps = embedding_bytes_per_sample(w["desc"], rho)
