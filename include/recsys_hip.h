@@ -202,6 +202,16 @@ int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int6
                double* d_loss, float* d_dlogits, void* ws, size_t ws_bytes, int device,
                void* stream);
 
+/* rx_bce_fwd for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference and none of its own in
+ * the op list above: same inputs, outputs and results as rx_bce_fwd, but the per-block partial sums
+ * live in an 8 KiB device array inside the library (one copy per GPU, held until the process ends)
+ * instead of a caller workspace, and the call issues no hipMalloc / hipFree.  M is limited to
+ * 2^28 logits; a larger M is rejected with an error.  All calls on one GPU share that array: calls
+ * that overlap on one GPU (different streams) race and must be ordered by the caller. */
+int rx_bce_fwd_noalloc(const float* d_logits, const void* d_labels, int labels_f64, int64_t M,
+                       double* d_loss, float* d_dlogits, int device, void* stream);
+
 /* ------------------------------------------------------------------ index sort / dedup
  * First stage of the deterministic backward that replaces aten embedding_dense_backward /
  * index_put_(accumulate=True) (what autograd runs for every nn.Embedding and 1-D bias

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "rx_fm2_flat_indices": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp]),
     "rx_bce_workspace_bytes": (sz, [i64]),
     "rx_bce_fwd": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, sz, C.c_int, vp]),
+    "rx_bce_fwd_noalloc": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, C.c_int, vp]),
     "rx_sort_dedup_workspace_bytes": (sz, [i64]),
     "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_sort_dedup_fm": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),

@@ -637,3 +637,52 @@ extern "C" int rx_bce_fwd(const float* d_logits, const void* d_labels, int label
   RX_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- the same op for callers that may not allocate (HIP graph capture, tight serving loops): the
+// per-block partial sums live in a file-scope device array instead of a caller workspace.  Every
+// GPU holds its own copy of the array at its own address; the address is looked up once per device
+// and only that pointer is handed to kernels (the array's name is a host-side stand-in, not a
+// device address).  bce_kernel overwrites partial[0 .. grid) and bce_final_kernel reads exactly those
+// entries, so nothing has to start at zero.  Calls that overlap on one GPU share the array and race.
+#include <mutex>
+
+#define RX_BCE_NOALLOC_MAX_M (1ll << 28)
+#define RX_MAX_DEVICES 64
+
+static __device__ __align__(256) double bce_scratch[RX_BCE_MAX_BLOCKS];  // 8 KiB per GPU, for the life of the process
+
+static std::mutex bce_scratch_mutex;
+static double* bce_scratch_ptr[RX_MAX_DEVICES];  // device address of bce_scratch on each GPU, filled on first use
+
+static int bce_scratch_for(int device, double** out) {
+  RX_REQUIRE(device < RX_MAX_DEVICES, "rx_bce_fwd_noalloc: device ordinal %d beyond %d", device, RX_MAX_DEVICES - 1);
+  std::lock_guard<std::mutex> lock(bce_scratch_mutex);
+  if (!bce_scratch_ptr[device]) {
+    double* p = nullptr;
+    RX_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(bce_scratch)));  // `device` is current (RX_ENTER)
+    RX_REQUIRE(p, "rx_bce_fwd_noalloc: hipGetSymbolAddress returned a null address");
+    bce_scratch_ptr[device] = p;
+  }
+  *out = bce_scratch_ptr[device];
+  return 0;
+}
+
+extern "C" int rx_bce_fwd_noalloc(const float* d_logits, const void* d_labels, int labels_f64, int64_t M,
+                                  double* d_loss, float* d_dlogits, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(d_logits && d_labels && d_loss, "rx_bce_fwd_noalloc: null argument");
+  RX_REQUIRE(M >= 1, "rx_bce_fwd_noalloc: empty input");
+  RX_REQUIRE(M <= RX_BCE_NOALLOC_MAX_M, "rx_bce_fwd_noalloc: M=%lld beyond the supported maximum of %lld logits", (long long)M, (long long)RX_BCE_NOALLOC_MAX_M);
+  double* partial = nullptr;
+  if (bce_scratch_for(device, &partial)) return 1;
+  const int grid = (int)std::min<int64_t>(rx_cdiv(M, RX_BLOCK), RX_BCE_MAX_BLOCKS);
+  hipStream_t st = (hipStream_t)stream;
+  if (labels_f64)
+    hipLaunchKernelGGL(bce_kernel<true>, dim3(grid), dim3(RX_BLOCK), 0, st, d_logits, d_labels, M, partial, d_dlogits);
+  else
+    hipLaunchKernelGGL(bce_kernel<false>, dim3(grid), dim3(RX_BLOCK), 0, st, d_logits, d_labels, M, partial, d_dlogits);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, grid, M, d_loss);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
