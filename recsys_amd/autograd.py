@@ -45,25 +45,43 @@ def presort(idx: Tensor, n_rows: int, out=None):
     return si
 
 
+_CAPTURE_CACHE: list = []
+
+
+def clear_sort_cache() -> None:
+    """Forget every memoised sort.  ``graph.GraphedTrainStep`` calls this before it records a step, so
+    that the recording contains its own sort kernels writing to buffers of the graph's pool."""
+    _SORT_CACHE.clear()
+    _CAPTURE_CACHE.clear()
+
+
 def sorted_index(idx: Tensor, n_rows: int):
     """``ops.sort_dedup`` with a small memo: NeuMF-style models look the same index tensor up in
     several tables of equal height (GMF and MLP embeddings), and one sort serves them all.  An
     entry is keyed by storage address, length and version counter and keeps its index tensor
     alive, so a hit can only be the same, unmodified data.  Results pinned by ``presort`` are
-    found first."""
+    found first.
+
+    While a stream is being captured into a HIP graph the eager memo is neither read nor written: a
+    hit there would leave the sort out of the recording, and a replay after the indices were
+    refreshed in place would scatter gradients with the old batch's order.  A separate memo, emptied
+    by ``clear_sort_cache`` before each recording, still shares one sort between the tables of one
+    recorded step."""
     flat = idx.reshape(-1)
     key = _sort_key(flat, n_rows)
+    capturing = flat.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _PRESORTED.get(key)
     if hit is not None:
         return hit[1]
-    for k, _, si in _SORT_CACHE:
+    cache = _CAPTURE_CACHE if capturing else _SORT_CACHE
+    for k, _, si in cache:
         if k == key:
             return si
     si = ops.sort_dedup(flat.contiguous() if not flat.is_contiguous() else flat, n_rows)
     if flat.is_contiguous():
-        _SORT_CACHE.append((key, flat, si))
-        if len(_SORT_CACHE) > 8:
-            _SORT_CACHE.pop(0)
+        cache.append((key, flat, si))
+        if len(cache) > (64 if capturing else 8):
+            cache.pop(0)
     return si
 
 

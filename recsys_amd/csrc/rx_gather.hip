@@ -127,6 +127,10 @@ permute_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ 
   const int c = (int)(gid % dim);
   if (j >= n || (n_valid && j >= n_valid[0])) return;
   const int64_t p = perm[j];
+  if (p < 0) {  // an entry that found no exchange slot (rx_pack_by_owner overflow): reads as a zero row, writes nothing
+    if (!SCATTER) out[j * dim + c] = 0.f;
+    return;
+  }
   if (SCATTER)
     out[p * dim + c] = rows[j * dim + c];
   else
@@ -192,7 +196,10 @@ pack_by_owner_kernel(const int64_t* __restrict__ send_local, const int32_t* __re
   }
   const int64_t off = j - starts[lo];
   if (off >= capacity) {
+    // no slot for this entry: mark it, so that everything addressed through src_of skips it
+    // (rx_permute_rows / rx_unpermute_rows below; the bounds checks of rx_fm2_fwd and the reduces)
     if (err_flag) atomicOr(err_flag, RX_ERR_CAPACITY);
+    src_of[perm[j]] = -1;
     return;
   }
   const int64_t dest = (int64_t)lo * capacity + off;

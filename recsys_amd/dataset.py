@@ -168,15 +168,19 @@ def synthetic_ml1m_data(seed: int = 0, n_users: int = 6040, n_items: int = 3706,
             "user_infos": user_infos}
 
 
-def load_ml1m_data(path):
+def load_ml1m_data(path, trust_pickle: bool = False):
     """Read the ``ml1m.npz`` written by the reference's own split (recsys/dataset.py:143-156).  That
-    file stores a pickled dict, so only load one you produced yourself."""
+    file stores a pickled dict, and unpickling runs code from the file: it is only read when the
+    caller says so (``trust_pickle=True``) for a file they produced themselves."""
+    if not trust_pickle:
+        raise ValueError(f"{path}: the reference's ml1m.npz holds a pickled dict; pass trust_pickle=True "
+                         "to load a file you wrote yourself")
     return np.load(path, allow_pickle=True)["data"].item()
 
 
 def load_implicit_data(device="cpu", train_batch_size: int = 512, test_batch_size: int = 1024, path=None,
-                       sampler: str = "device") -> ImplicitData:
+                       sampler: str = "device", trust_pickle: bool = False) -> ImplicitData:
     """``path`` to a user-built ml1m.npz, or ML-1M-shaped synthetic data when None."""
-    data = load_ml1m_data(path) if path is not None else synthetic_ml1m_data()
+    data = load_ml1m_data(path, trust_pickle) if path is not None else synthetic_ml1m_data()
     return ImplicitData(data, device=device, train_batch_size=train_batch_size, test_batch_size=test_batch_size,
                         sampler=sampler)

@@ -31,7 +31,7 @@ from typing import Dict, List
 import torch
 
 from . import ops
-from .autograd import backward_from_loss
+from .autograd import backward_from_loss, clear_sort_cache
 
 
 class GraphedTrainStep:
@@ -78,6 +78,7 @@ class GraphedTrainStep:
         for i, b in enumerate(prepared):
             g = torch.cuda.CUDAGraph()
             self.opt.zero_grad()
+            clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
                 fork = torch.cuda.Stream(device=dev)
@@ -98,6 +99,7 @@ class GraphedTrainStep:
         K = len(prepared)
         g = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
+        clear_sort_cache()
         with torch.cuda.graph(g, pool=self._pool):
             main = torch.cuda.current_stream(dev)
             fork = torch.cuda.Stream(device=dev)
@@ -145,8 +147,10 @@ class GraphedTrainStep:
             torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
+        clear_sort_cache()   # the recording must hold its own sort kernels (see autograd.sorted_index)
         with torch.cuda.graph(g, pool=self._pool):
             loss = self._eager(batch)
+        clear_sort_cache()   # memo entries made while recording point into the graph's pool
         if self._pool is None:
             self._pool = g.pool()
         self.graphs.append(g)

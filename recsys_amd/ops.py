@@ -859,6 +859,9 @@ def pack_by_owner(send_local: Tensor, perm: Tensor, counts: Tensor, capacity: in
     return packed, src_of
 
 
+TOPK_MAX_CANDIDATES = 1024   # widest score row rx_topk_codes takes (one wavefront per row, candidates in registers)
+
+
 def topk_codes(scores: Tensor, codes: Optional[Tensor], k: int) -> Tensor:
     _req(scores, torch.float32, "scores", 2)
     if codes is not None:

@@ -212,15 +212,17 @@ class FusedOptimizer:
                 dev = (self.dense[0] if self.dense else self.sparse[0]).device
                 scale, self.last_total_norm = ops.clip_scale(torch.zeros(1, dtype=torch.float64, device=dev),
                                                              float(self.clip_norm))
-            for (rule, param, compact, si, _, comp) in self._pending:
-                if comp is not None:
-                    rule2, param2, compact2 = comp
-                    ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                                   eps=rule.eps, scale=scale, compact2=compact2, table2=param2.data,
-                                   state2=rule2._state_for(param2))
-                else:
-                    ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                                   eps=rule.eps, scale=scale)
-            self._pending.clear()
-            self._sq_used = 0
+        # Row updates left pending by a backward pass that ran with a clip set: applied here with the
+        # clip factor, or unscaled when the clip was switched off between backward and step.
+        for (rule, param, compact, si, _, comp) in self._pending:
+            if comp is not None:
+                rule2, param2, compact2 = comp
+                ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                               eps=rule.eps, scale=scale, compact2=compact2, table2=param2.data,
+                               state2=rule2._state_for(param2))
+            else:
+                ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                               eps=rule.eps, scale=scale)
+        self._pending.clear()
+        self._sq_used = 0
         self._dense_step_all(scale)

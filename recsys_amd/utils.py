@@ -29,6 +29,11 @@ def topk(scores, array=None, subset=None, k=10):
             scores = torch.gather(scores, 1, subset)
             array = subset
         codes = None if array is None else torch.as_tensor(array, device=scores.device).long().contiguous()
+        if scores.shape[1] > ops.TOPK_MAX_CANDIDATES:
+            # wider than the one-wavefront-per-row kernel takes (e.g. full-catalogue scores): a stable
+            # ascending sort read backwards, which is the reference's tie order (larger column first)
+            order = torch.sort(scores.float(), dim=1, stable=True).indices.flip(1)[:, :k].contiguous()
+            return order if codes is None else torch.gather(codes, 1, order)
         return ops.topk_codes(scores.float().contiguous(), codes, k)
     scores = np.asarray(scores)
     if subset is not None:
@@ -57,12 +62,14 @@ def eval_loop(model, data, k, epoch=None, num_epochs=None, epoch_loss=None):
 
 def train_step(model, optimizer, inputs, clip_norm):
     """One batch of recsys/utils.py:96-103.  Returns the loss tensor (still on the device)."""
+    if isinstance(optimizer, FusedOptimizer):
+        # the backward pass reads the clip setting (one-phase in-place update without a clip,
+        # compact gradients + norm partials with one), so it has to be in place before the loss
+        optimizer.clip_norm = clip_norm
     optimizer.zero_grad()
     loss = model.loss(inputs)
     backward_from_loss(loss)
-    if isinstance(optimizer, FusedOptimizer):
-        optimizer.clip_norm = clip_norm
-    elif clip_norm is not None:
+    if clip_norm is not None and not isinstance(optimizer, FusedOptimizer):
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return loss.detach()

@@ -345,3 +345,137 @@ def test_sharded_fm_one_rank_through_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["VanillaMF", "NeuMF"])
+def test_graph_replay_after_copy_batch_matches_eager_on_the_new_batch(name):
+    """A recorded step must hold its own sort kernels: after warm-up steps on a batch (which leave
+    memoised sorts behind), record with add_batch, refresh the batch in place with copy_batch and
+    replay — the weights must equal, bit for bit, eager steps on the same batch sequence."""
+    from recsys_amd import ops, synthetic
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(9)
+        with torch.device("cuda"):
+            m = VanillaMF(d["n_users"], d["n_items"], 16) if name == "VanillaMF" else NeuMF(d["n_users"], d["n_items"], 16, dropout=0.0)
+        m.train()
+        first = synthetic.ml1m_batch(256, seed=70, device="cuda")
+        later = [synthetic.ml1m_batch(256, seed=71 + i, device="cuda") for i in range(3)]
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=2)
+                slot = gs.add_batch({k: v.clone() for k, v in first.items()})   # 2 eager warm-up steps on `first`
+                gs(slot)
+                for b in later:
+                    gs.copy_batch(slot, b)
+                    loss = gs(slot)
+            else:
+                for b in [first, first, first] + later:
+                    opt.zero_grad(); loss = m.loss(b); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("ctor_clip,loop_clip", [(None, 1.0), (1.0, None)])
+def test_train_step_clip_overrides_the_optimizers_own_setting(ctor_clip, loop_clip):
+    """recsys/utils.py:101: the clip belongs to the train loop.  A FusedOptimizer built with another
+    setting must behave, from the first step on, like one built with the loop's value."""
+    from recsys_amd import synthetic
+    from recsys_amd.models.matrix_factorization import BiasMF
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.utils import train_step
+    d = synthetic.ML1M
+    states = []
+    for clip_at_ctor in (ctor_clip, loop_clip):
+        torch.manual_seed(11)
+        with torch.device("cuda"):
+            m = BiasMF(d["n_users"], d["n_items"], 16)
+        m.train()
+        opt = FusedOptimizer(m, kind="sgd", lr=0.5, clip_norm=clip_at_ctor)
+        for i in range(2):
+            train_step(m, opt, synthetic.ml1m_batch(128, seed=90 + i, device="cuda"), loop_clip)
+        states.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
+
+
+def test_pending_row_updates_are_applied_when_the_clip_is_dropped_before_step():
+    from recsys_amd import synthetic
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    torch.manual_seed(12)
+    with torch.device("cuda"):
+        m = VanillaMF(d["n_users"], d["n_items"], 16)
+    ref = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    b = synthetic.ml1m_batch(128, seed=5, device="cuda")
+    opt = FusedOptimizer(m, kind="sgd", lr=0.5, clip_norm=1e9)     # a clip that never binds: compact + pending path
+    opt.zero_grad(); m.loss(b).backward()
+    opt.clip_norm = None
+    opt.step()
+    after_dropped = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(ref)
+    opt2 = FusedOptimizer(m, kind="sgd", lr=0.5, clip_norm=None)
+    opt2.zero_grad(); m.loss(b).backward(); opt2.step()
+    for k, v in m.state_dict().items():
+        assert not torch.equal(v, ref[k]) or "bias" in k
+        assert torch.equal(v, after_dropped[k]), k
+
+
+def test_pack_by_owner_overflow_raises_and_leaves_tables_untouched():
+    """A group larger than the exchange capacity: the entries without a slot are marked, nothing is
+    read or written through them, and the deferred check reports the overflow."""
+    from recsys_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, G, dim = 600, 2, 8
+    idx = torch.unique(torch.randint(0, 5000, (n,), generator=g)).cuda()
+    n = idx.numel()
+    counts, send_local, perm = ops.bucketize_by_owner(idx, G, 5000)
+    cap = int(counts.max().item()) - 7          # too small for the larger group
+    ops.set_index_check("deferred")
+    try:
+        packed, src_of = ops.pack_by_owner(send_local, perm, counts, cap, pad_rows=16)
+        assert int((src_of < 0).sum().item()) >= 7
+        assert int(src_of.max().item()) < G * cap
+        rows = torch.randn(G * cap, dim, device="cuda")
+        got = ops.permute_rows(rows, src_of, None)
+        ok = src_of >= 0
+        assert torch.equal(got[ok], rows[src_of[ok].long()])
+        assert torch.count_nonzero(got[~ok]) == 0
+        sent = torch.full((G * cap, dim), 7.0, device="cuda")
+        ops.unpermute_rows(torch.randn(n, dim, device="cuda"), src_of, None, out=sent)
+        untouched = torch.ones(G * cap, dtype=torch.bool, device="cuda")
+        untouched[src_of[ok].long()] = False
+        assert torch.all(sent[untouched] == 7.0)
+        with pytest.raises(RuntimeError, match="capacity"):
+            ops.raise_if_index_error()
+    finally:
+        ops.set_index_check("sync")
+
+
+def test_topk_wider_than_the_kernel_limit_follows_the_reference_order():
+    from recsys_amd.utils import topk
+    g = torch.Generator().manual_seed(8)
+    scores = torch.randint(0, 50, (37, 3706), generator=g).float()     # many ties
+    codes = torch.stack([torch.randperm(3706, generator=g) for _ in range(37)])
+    # the documented tie order: a stable ascending argsort read backwards (numpy's default argsort is
+    # not stable on rows this wide, so the host mirror is only compared where scores are distinct)
+    order = np.argsort(scores.numpy(), axis=1, kind="stable")[:, ::-1][:, :10]
+    dev = topk(scores.cuda(), array=codes.cuda(), k=10).cpu().numpy()
+    assert np.array_equal(dev, np.take_along_axis(codes.numpy(), order, axis=1))
+    assert np.array_equal(topk(scores.cuda(), k=10).cpu().numpy(), order)
+    distinct = torch.stack([torch.randperm(3706, generator=g) for _ in range(5)]).float()
+    assert np.array_equal(topk(distinct.cuda(), k=10).cpu().numpy(), topk(distinct.numpy(), k=10))
