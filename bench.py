@@ -238,7 +238,8 @@ def back_to_back_ms(op_name, call, reps=30):
     return s.elapsed_time(e) / reps, reps
 
 
-ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", "segreduce_fm", "row_update", "bce_with_logits",
+ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "fm_sort_dedup", "fg_group", "segreduce", "segreduce_fm", "fg_reduce",
+           "row_update", "fg_row_update", "bce_with_logits",
            "mf_score_fwd", "mf_score_bwd", "gather_concat", "gather_concat_bwd", "gmf_mul_fwd", "gmf_mul_bwd",
            "linear_fwd", "linear_bwd_x", "linear_bwd_w", "relu_bwd", "sumsq_accumulate", "sum_accumulate",
            "clip_scale", "reduce_sum", "cross_combine_fwd", "cross_combine_bwd"]
@@ -246,6 +247,8 @@ ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "segreduce", 
 
 # kernels behind each timed op (names as rocprofv3 prints them), for the roofline line and the PMC lookup
 OP_KERNELS = {
+    "fg_reduce": ["fg_reduce_kernel<4, 8, 1, false>", "fg_combine_kernel<4, 8, 1>"],
+    "fg_row_update": ["fg_row_update_kernel<4, 2>"],
     "segreduce_fm": ["segreduce_chunk_kernel<4, 1, 1, true>", "segreduce_combine_kernel<4, 1, 1, true>"],
     "fm2_fwd": ["fm2_fwd_kernel<4, 1>"],
     "row_update": ["row_update_kernel<4, 1, 2, false>"],
@@ -275,9 +278,9 @@ def algo_bytes(desc, op, rho=1.0):
             return B * (4 + F * (8 + 4 * D) + F * (4 * D + 4))
         if op == "segreduce":  # sorted positions + per-occurrence rows in; distinct rows read + written
             return B * F * (8 + 4 * D) + rho * B * F * 2 * 4 * D
-        if op == "segreduce_fm":  # backward + the read-modify-write of the distinct rows, in one op
+        if op in ("segreduce_fm", "fg_reduce"):  # backward + the read-modify-write of the distinct rows, in one op
             return B * (4 + F * 4 * D + F * 8) + rho * B * F * 2 * 4 * D
-        if op == "row_update":  # compact gradient in, row in, row out
+        if op in ("row_update", "fg_row_update"):  # compact gradient in, row in, row out
             return rho * B * F * 3 * 4 * D
     return None
 
@@ -472,7 +475,9 @@ def main():
             print(f"[op-profile] {n:22s} {ms * 1e3:9.1f} us x {cnt / 20:.1f}/step", file=sys.stderr)
         del w
 
-    dominant = {"fm_criteo": "segreduce_fm", "fm_wide_d128": "segreduce_fm", "fm_criteo_sharded": "segreduce_fm",
+    fg_on = os.environ.get("RX_NO_FIELD_GROUPS") != "1"   # the unsharded field models take the field-grouped backward
+    dominant = {"fm_criteo": "fg_reduce" if fg_on else "segreduce_fm", "fm_wide_d128": "fg_reduce" if fg_on else "segreduce_fm",
+                "fm_criteo_sharded": "segreduce_fm",
                 "deepfm_criteo_sharded": "linear_bwd_w", "deepfm_criteo": "linear_bwd_w",
                 "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]

@@ -294,6 +294,59 @@ int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, const floa
                     float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
                     float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
 
+/* ------------------------------------------------------------------ field-grouped backward (N == 1 field models)
+ * The same two stages for the models whose samples name exactly one row in each of n_fields
+ * DISJOINT, ascending row ranges of one table (the 26-field FM / DeepFM / DCN-v2 that generalise
+ * recsys/models/matrix_factorization/factorization_machine.py:33-38 to one item per sample): what
+ * autograd would do there is embedding_dense_backward over B * n_fields occurrences.
+ *
+ * rx_fg_group orders the occurrences without a full-width sort.  Position p = f * B + j holds the
+ * j-th occurrence of field f in the order (row & 255, row >> 8, sample):
+ *   srow [B * n_fields] uint32   table row of the occurrence (field base added)
+ *   sb   [B * n_fields] uint32   its sample
+ * Equal rows are adjacent, their samples ascend, a run never crosses a field.  The distinct rows of
+ * the batch are the srow[p] with p the last position of a run (srow[p] != srow[p + 1]); as a set they
+ * equal torch.unique of the flat row list.  Indices are field-local: an index outside
+ * [0, field_base[f + 1] - field_base[f]) sets RX_ERR_INDEX and is clamped into its field (stricter
+ * than nn.Embedding, which only checks the whole table: here the fields must not alias).
+ * field_base holds HOST values.  Limits: B <= 65536, n_fields <= RX_FG_MAX_FIELDS, table rows
+ * <= 2^32 - 16, bits(B - 1) + bits((largest field - 1) >> 8) <= 32 (rx_fg_supported tells).
+ * ex_idx [B, n_fields - 1] / item_idx [B, 1] with their row strides, as in rx_fm_args. */
+#define RX_FG_MAX_FIELDS 64
+typedef struct {
+  const int64_t* ex_idx;   /* device [B, n_fields - 1], row stride ex_ld */
+  const int64_t* item_idx; /* device [B, 1], row stride item_ld: the last field */
+  int64_t ex_ld, item_ld;
+  int64_t B;
+  int32_t n_fields;
+  int32_t pad_;
+  int64_t field_base[RX_FG_MAX_FIELDS + 1]; /* host: first table row of field f; [n_fields] = rows of the table */
+} rx_fg_args;
+int rx_fg_supported(const rx_fg_args* a);
+int rx_fg_dim_supported(int32_t dim); /* row widths rx_fg_reduce takes: 16, 32, 64, 128 */
+size_t rx_fg_workspace_bytes(int64_t B, int32_t n_fields);
+int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb, void* ws, size_t ws_bytes,
+                int32_t* err_flag, int device, void* stream);
+
+/* Reduce + consume over that order; arguments as rx_segreduce_fm (T, g, optional tower-input
+ * gradient d_deep laid out [last field | field 0 .. n_fields-2 | extra columns], modes, companion
+ * [rows,1] table, clip factor, per-block sums of squares) with two differences: RX_SEG_COMPACT
+ * writes the gradient of a run to target[p, :] / target2[p] with p the run's LAST position (buffers
+ * of B * n_fields rows), and d_sq_part has rx_fg_reduce_grid(n, dim) entries.  One lane group per
+ * position, segmented scan by row inside a wavefront, fixed tree: bitwise reproducible. */
+int64_t rx_fg_reduce_grid(int64_t n, int32_t dim);
+size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim);
+int rx_fg_reduce(const float* d_T, int64_t ld_T, const float* d_g, const float* d_deep, int64_t deep_ld,
+                 int64_t B, int32_t n_fields, int32_t dim, const uint32_t* d_srow, const uint32_t* d_sb,
+                 int mode, float* d_target, float* d_state, const float* d_table, float* d_target2,
+                 float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
+                 float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
+/* Second phase of a clipped step: every run's row moves by its compact gradient (at the run's last
+ * position) times *d_scale; mode SGD / ADAGRAD / ROWWISE_ADAGRAD; companion table in the same launch. */
+int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
+                     float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                     int64_t n_rows, float lr, float eps, const float* d_scale, int device, void* stream);
+
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above
  * (SGD / ADAGRAD / ROWWISE_ADAGRAD).  d_compact2 [*n_uniq] / d_w2 / d_state2: compact gradient,

@@ -36,6 +36,14 @@ class FMArgs(C.Structure):
                 ("dim", i32), ("flags", i32)]
 
 
+RX_FG_MAX_FIELDS = 64
+
+
+class FGArgs(C.Structure):
+    _fields_ = [("ex_idx", vp), ("item_idx", vp), ("ex_ld", i64), ("item_ld", i64), ("B", i64),
+                ("n_fields", i32), ("pad_", i32), ("field_base", i64 * (RX_FG_MAX_FIELDS + 1))]
+
+
 RX_FM_NO_SECOND_ORDER = 1
 RX_MULTI_MAX = 24
 
@@ -71,6 +79,15 @@ PROTOTYPES = {
     "rx_segreduce_workspace_bytes": (sz, [i64, i32]),
     "rx_segreduce": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
     "rx_segreduce_fm": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, vp, vp, sz, C.c_int, vp]),
+    "rx_fg_supported": (C.c_int, [C.POINTER(FGArgs)]),
+    "rx_fg_dim_supported": (C.c_int, [i32]),
+    "rx_fg_workspace_bytes": (sz, [i64, i32]),
+    "rx_fg_group": (C.c_int, [C.POINTER(FGArgs), vp, vp, vp, sz, vp, C.c_int, vp]),
+    "rx_fg_reduce_grid": (i64, [i64, i32]),
+    "rx_fg_reduce_workspace_bytes": (sz, [i64, i32]),
+    "rx_fg_reduce": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp,
+                               vp, vp, sz, C.c_int, vp]),
+    "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
     "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),

@@ -17,7 +17,9 @@ import torch
 from torch.autograd import Function
 
 from . import _lib, ops
-from .ops import Segment, SortedIndex
+import os
+
+from .ops import FieldGroups, Segment, SortedIndex
 
 Tensor = torch.Tensor
 
@@ -157,23 +159,43 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _side_streams[key]
 
 
+def use_field_groups(feat, ex_idx, item_idx, field_base) -> bool:
+    """The field-grouped backward (rx_fg_*) serves one-item-per-sample batches over disjoint field
+    ranges; ``RX_NO_FIELD_GROUPS=1`` keeps everything on the general sort (for A/B timing)."""
+    if field_base is None or os.environ.get("RX_NO_FIELD_GROUPS") == "1":
+        return False
+    return ops.fg_supported(ex_idx, item_idx, field_base, feat.shape[1])
+
+
+def index_prep(feat, ex_idx, ex_base, item_idx, item_base, field_base=None, out=None):
+    """Index work of an FM batch's backward: the field-grouped order when the batch qualifies
+    (``field_base``: host row offsets of the fields + table height), else the general sort + dedup."""
+    if use_field_groups(feat, ex_idx, item_idx, field_base):
+        return ops.fg_group(ex_idx, item_idx, field_base, out=out if isinstance(out, FieldGroups) else None)
+    return ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base, out=out if isinstance(out, SortedIndex) else None)
+
+
 class _AsyncSort:
     """Index preparation for the backward (flat row ids -> sort -> dedup) depends on the batch's
     indices only, so it is issued on a side HIP stream at forward time and overlaps the forward,
     loss and interaction-backward kernels; the backward joins the stream before it reduces."""
 
-    def __init__(self, feat, ex_idx, ex_base, item_idx, item_base):
+    def __init__(self, feat, ex_idx, ex_base, item_idx, item_base, field_base=None):
         dev = feat.device
         self.main = torch.cuda.current_stream(dev)
         self.side = _side_stream(dev)
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
-            self.si = ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base)
+            self.si = index_prep(feat, ex_idx, ex_base, item_idx, item_base, field_base)
 
-    def join(self) -> SortedIndex:
-        main = torch.cuda.current_stream(self.si.seg_off.device)
+    def join(self):
+        main = torch.cuda.current_stream(self.si.srow.device if isinstance(self.si, FieldGroups) else self.si.seg_off.device)
         main.wait_stream(self.side)
-        for t in (self.si.sorted_pos, self.si.sorted_slot, self.si.uniq_rows, self.si.seg_off, self.si.n_uniq):
+        if isinstance(self.si, FieldGroups):
+            held = (self.si.srow, self.si.sb)
+        else:
+            held = (self.si.sorted_pos, self.si.sorted_slot, self.si.uniq_rows, self.si.seg_off, self.si.n_uniq)
+        for t in held:
             t.record_stream(main)
         return self.si
 
@@ -182,22 +204,26 @@ class Presort:
     """Index preparation done ahead of the step (see HotPathModule.prepare): the sort / dedup
     result of a batch's row list, in buffers that can be refreshed in place."""
 
-    def __init__(self, si: SortedIndex):
+    def __init__(self, si):
         self.si = si
 
-    def join(self) -> SortedIndex:
+    def join(self):
         return self.si
 
 
-def table_backward_fm(feat, bias_table, si: SortedIndex, tsum, g, n_fields_ex: int, deep=None):
-    """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm); ``deep``: gradient of the
-    tower input, whose per-field slices join the rows' gradients in the same walk."""
+def table_backward_fm(feat, bias_table, si, tsum, g, n_fields_ex: int, deep=None):
+    """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm, or rx_fg_reduce when ``si``
+    is a field-grouped list); ``deep``: gradient of the tower input, whose per-field slices join the
+    rows' gradients in the same pass."""
     rule = getattr(feat, "_rx_sparse", None)
     if rule is not None:
         rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex, deep)
         return None, None
     grad = torch.zeros_like(feat)
     grad2 = torch.zeros_like(bias_table) if bias_table is not None else None
+    if isinstance(si, FieldGroups):
+        ops.fg_reduce(tsum, g, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep)
+        return grad, grad2
     ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep)
     return grad, grad2
 
@@ -210,7 +236,7 @@ class FM2(Function):
 
     @staticmethod
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True,
-                deep_cols=None, want_logits=True, extra=None, presort=None):
+                deep_cols=None, want_logits=True, extra=None, presort=None, field_base=None):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         n_items = item_idx.shape[1] if item_idx.dim() == 2 else 1
         # with one item per sample the backward needs only T_b = sum of the sample's rows (plus the
@@ -223,8 +249,11 @@ class FM2(Function):
         ctx.second_order = second_order
         ctx.tsum = out[2] if fused else None
         ctx.sort = presort
-        if presort is None and ctx.needs_input_grad[4] and feat.is_cuda:
-            ctx.sort = _AsyncSort(feat, ex_idx, ex_base, item_idx, item_base)
+        ctx.field_base = field_base if fused else None   # the field-grouped order serves the fused backward only
+        if presort is not None and isinstance(presort.join(), FieldGroups) and not fused:
+            ctx.sort = None
+        if ctx.sort is None and ctx.needs_input_grad[4] and feat.is_cuda:
+            ctx.sort = _AsyncSort(feat, ex_idx, ex_base, item_idx, item_base, ctx.field_base)
         return out[0], out[1]
 
     @staticmethod
@@ -234,9 +263,9 @@ class FM2(Function):
             g = g.contiguous()
         if g_deep is not None and g_deep.stride(-1) != 1:
             g_deep = g_deep.contiguous()
-        none_tail = (None,) * 6
+        none_tail = (None,) * 7
         if ctx.tsum is not None and (g is not None or g_deep is not None):
-            s = ctx.sort.join() if ctx.sort is not None else ops.fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base)
+            s = ctx.sort.join() if ctx.sort is not None else index_prep(feat, ex_idx, ex_base, item_idx, item_base, ctx.field_base)
             gl = g.reshape(-1) if g is not None else torch.zeros(ctx.tsum.shape[0], dtype=torch.float32, device=feat.device)
             gfeat, gbias = table_backward_fm(feat, bias_table, s, ctx.tsum, gl, ex_idx.shape[1], g_deep)
             return (None, None, None, None, gfeat, gbias) + none_tail

@@ -30,6 +30,7 @@ class _FieldTable(HotPathModule):
         for d in self.field_dims[:-1]:
             offs.append(offs[-1] + d)
         self._offsets = offs
+        self._field_base = tuple(offs) + (self.n_features,)   # host row offsets of every field + table height
 
     def _split(self, inputs):
         sparse = as_index(inputs["sparse"], "sparse")
@@ -47,7 +48,7 @@ class _FieldTable(HotPathModule):
         ex, base, item, item_base = self._split(inputs)
         feat = self.feature_embedding.weight
         old = out.get("_rx_presort") if out is not None else None
-        si = ops.fm_sort_dedup(feat, ex, base, item, item_base, out=old.si if old else None)
+        si = rxa.index_prep(feat, ex, base, item, item_base, self._field_base, out=old.si if old else None)
         if out is not None and old is not None:
             return out
         prepared = dict(inputs)
@@ -69,7 +70,7 @@ class FieldFM(_FieldTable):
         ex, base, item, item_base = self._split(inputs)
         logits, _ = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
                                   self.bias_embedding.weight, False, True, None, True, None,
-                                  inputs.get("_rx_presort"))
+                                  inputs.get("_rx_presort"), self._field_base)
         return logits
 
 
@@ -103,7 +104,8 @@ class FieldDeepFM(_FieldTable):
         d_emb = self.n_fields * self.embedding_dim
         fm, x = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight,
                               self.bias_embedding.weight, True, True, d_emb + self.n_dense + self.pad, True,
-                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
+                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"),
+                              self._field_base)
         return fm + run_tower(self.deep_mlp, x, bf16=self.bf16)
 
 
@@ -154,6 +156,7 @@ class DCNv2(_FieldTable):
         d_emb = self.n_fields * self.embedding_dim
         _, x0 = rxa.FM2.apply(ex, base, item, item_base, self.feature_embedding.weight, None, True, False,
                               d_emb + self.n_dense + self.pad, False,
-                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"))
+                              _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"),
+                              self._field_base)
         x = rxa.cross_stack(x0, self.cross, self.bf16) if len(self.cross) else x0
         return run_tower(self.mlp, x, bf16=self.bf16)

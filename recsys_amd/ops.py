@@ -545,6 +545,119 @@ def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mod
     return sq
 
 
+# ------------------------------------------------------------------ field-grouped backward (N == 1 field models)
+@dataclass
+class FieldGroups:
+    """Result of rx_fg_group: the occurrences of an [B, n_fields] index matrix, field after field,
+    each field ordered by (row & 255, row >> 8, sample).  ``srow`` / ``sb`` are int32 tensors holding
+    uint32 values (table row and sample of every position)."""
+    n: int
+    n_rows: int
+    B: int
+    n_fields: int
+    srow: Tensor
+    sb: Tensor
+
+    def distinct_rows(self) -> Tensor:
+        """The batch's distinct table rows (int64, in list order): the last position of every run."""
+        r = self.srow.to(torch.int64) & 0xFFFFFFFF
+        end = torch.ones_like(r, dtype=torch.bool)
+        end[:-1] = r[:-1] != r[1:]
+        return r[end]
+
+
+def _fg_args(ex_idx: Tensor, item_idx: Tensor, field_base: Sequence[int]):
+    ex_idx, F, ex_ld = _idx_matrix(ex_idx, "ex_idx")
+    item_idx, N, item_ld = _idx_matrix(item_idx, "item_idx")
+    nf = F + 1
+    if N != 1 or ex_idx.dim() != 2 or item_idx.shape[0] != ex_idx.shape[0]:
+        raise ValueError("field grouping needs ex_idx [B, F] and item_idx [B, 1]")
+    if len(field_base) != nf + 1 or nf > _lib.RX_FG_MAX_FIELDS:
+        raise ValueError(f"field_base: expected {nf + 1} row offsets (at most {_lib.RX_FG_MAX_FIELDS} fields)")
+    a = _lib.FGArgs()
+    a.ex_idx, a.item_idx, a.ex_ld, a.item_ld = ex_idx.data_ptr(), item_idx.data_ptr(), ex_ld, item_ld
+    a.B, a.n_fields = ex_idx.shape[0], nf
+    for k, v in enumerate(field_base):
+        a.field_base[k] = int(v)
+    return a
+
+
+def fg_supported(ex_idx: Tensor, item_idx: Tensor, field_base: Sequence[int], dim: int) -> bool:
+    """Whether the field-grouped backward takes this batch shape, field layout and row width."""
+    if item_idx.dim() != 2 or item_idx.shape[1] != 1 or ex_idx.dim() != 2 or ex_idx.shape[0] == 0:
+        return False
+    if len(field_base) != ex_idx.shape[1] + 2 or len(field_base) - 1 > _lib.RX_FG_MAX_FIELDS:
+        return False
+    if not lib.rx_fg_dim_supported(int(dim)):
+        return False
+    return bool(lib.rx_fg_supported(C.byref(_fg_args(ex_idx, item_idx, field_base))))
+
+
+def fg_group(ex_idx: Tensor, item_idx: Tensor, field_base: Sequence[int], out: Optional[FieldGroups] = None) -> FieldGroups:
+    """rx_fg_group.  ``field_base``: host ints, first table row of every field plus the table height.
+    ``out``: a FieldGroups of the same shape whose tensors are overwritten in place."""
+    _same_device(ex_idx, item_idx)
+    a = _fg_args(ex_idx, item_idx, field_base)
+    B, nf, dev = int(a.B), int(a.n_fields), ex_idx.device
+    n, n_rows = B * nf, int(field_base[-1])
+    if out is not None:
+        if out.n != n or out.n_rows != n_rows or out.B != B:
+            raise ValueError("fg_group: `out` was made for a different batch shape")
+        srow, sb = out.srow, out.sb
+    else:
+        srow = torch.empty(n, dtype=torch.int32, device=dev)
+        sb = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _ws(int(lib.rx_fg_workspace_bytes(B, nf)), dev)
+    check(lib.rx_fg_group(C.byref(a), _p(srow), _p(sb), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(ex_idx),
+                          _stream(ex_idx)), "rx_fg_group")
+    return out if out is not None else FieldGroups(n, n_rows, B, nf, srow, sb)
+
+
+def fg_reduce_grid(n: int, dim: int) -> int:
+    return max(int(lib.rx_fg_reduce_grid(n, dim)), 1)
+
+
+def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tensor, *, table: Optional[Tensor] = None,
+              state: Optional[Tensor] = None, target2: Optional[Tensor] = None, state2: Optional[Tensor] = None,
+              lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None, want_sq: bool = False,
+              sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None) -> Optional[Tensor]:
+    """rx_fg_reduce: the N == 1 FM backward over a field-grouped occurrence list (see FieldGroups).
+    In RX_SEG_COMPACT mode ``target`` / ``target2`` have one row per POSITION (fg.n rows)."""
+    _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
+    B, dim = tsum.shape
+    deep_ld = 0
+    if deep is not None:
+        deep, deep_ld = _mat(deep, "deep")
+        if deep.shape[0] != B or deep.shape[1] < fg.n_fields * dim:
+            raise ValueError("deep: expected [B, >= n_fields * dim]")
+    if g.numel() != B or fg.B != B:
+        raise ValueError("fg_reduce: shapes disagree with the grouped occurrence list")
+    if mode == _lib.RX_SEG_COMPACT and target.shape[0] < fg.n:
+        raise ValueError("fg_reduce: the compact gradient needs one row per position")
+    sq = None
+    if want_sq:
+        need = fg_reduce_grid(fg.n, dim)
+        if sq_out is None:
+            sq = torch.empty(need, dtype=torch.float32, device=tsum.device)
+        else:
+            _req(sq_out, torch.float32, "sq_out")
+            if sq_out.numel() != need:
+                raise ValueError(f"sq_out: expected {need} contiguous floats")
+            sq = sq_out
+    ws = _ws(int(lib.rx_fg_reduce_workspace_bytes(fg.n, dim)), tsum.device)
+    check(lib.rx_fg_reduce(_p(tsum), tsum.stride(0), _p(g), _p(deep), deep_ld, B, fg.n_fields, dim, _p(fg.srow), _p(fg.sb),
+                           mode, _p(target), _p(state), _p(table), _p(target2), _p(state2), fg.n_rows, lr, eps,
+                           _p(scale), _p(sq), _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_fg_reduce")
+    return sq
+
+
+def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
+                  scale=None, compact2=None, table2=None, state2=None) -> None:
+    check(lib.rx_fg_row_update(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
+                               _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(scale), _dev(table),
+                               _stream(table)), "rx_fg_row_update")
+
+
 def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
                scale=None, compact2=None, table2=None, state2=None) -> None:
     """``compact2`` [n] / ``table2`` / ``state2``: the companion scalar table, updated in the same launch."""

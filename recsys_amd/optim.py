@@ -66,6 +66,19 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None):
         raise RuntimeError("companion table must carry a sparse rule when its main table does")
     table2 = bias_table.data if bias_table is not None else None
     state2 = rule2._state_for(bias_table) if rule2 is not None else None
+    if isinstance(si, ops.FieldGroups):
+        # field-grouped occurrence list: compact gradients live at the last position of each run
+        if self.owner.clip_norm is None:
+            ops.fg_reduce(tsum, g, si, self.mode, table, state=state, target2=table2, state2=state2,
+                          lr=self.lr, eps=self.eps, deep=deep)
+            return
+        compact = torch.empty(si.n, tsum.shape[1], dtype=torch.float32, device=table.device)
+        compact2 = torch.empty(si.n, dtype=torch.float32, device=table.device) if bias_table is not None else None
+        sq = ops.fg_reduce(tsum, g, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2, want_sq=True,
+                           sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device, ops.fg_reduce_grid(si.n, tsum.shape[1])),
+                           deep=deep)
+        self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
+        return
     if self.owner.clip_norm is None:
         ops.segreduce_fm(tsum, g, n_fields_ex, si, self.mode, table, state=state, target2=table2, state2=state2,
                          lr=self.lr, eps=self.eps, deep=deep)
@@ -125,10 +138,12 @@ class FusedOptimizer:
         self._pending.clear()
         self._sq_used = 0
 
-    def _sq_slice(self, n: int, dim: int, device):
+    def _sq_slice(self, n: int, dim: int, device, need: Optional[int] = None):
         """Room for one reduce's norm partials in the step's shared buffer (None when it is full: the
-        reduce then allocates its own and the step adds it separately)."""
-        need = ops.segreduce_grid(n, dim)
+        reduce then allocates its own and the step adds it separately).  ``need``: number of partials
+        when the reduce is not rx_segreduce."""
+        if need is None:
+            need = ops.segreduce_grid(n, dim)
         if self._sq_buf is None or self._sq_buf.device != device:
             if torch.cuda.is_current_stream_capturing():
                 return None
@@ -215,7 +230,13 @@ class FusedOptimizer:
         # Row updates left pending by a backward pass that ran with a clip set: applied here with the
         # clip factor, or unscaled when the clip was switched off between backward and step.
         for (rule, param, compact, si, _, comp) in self._pending:
-            if comp is not None:
+            if isinstance(si, ops.FieldGroups):
+                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+                ops.fg_row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                                  eps=rule.eps, scale=scale, compact2=compact2,
+                                  table2=param2.data if param2 is not None else None,
+                                  state2=rule2._state_for(param2) if rule2 is not None else None)
+            elif comp is not None:
                 rule2, param2, compact2 = comp
                 ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
                                eps=rule.eps, scale=scale, compact2=compact2, table2=param2.data,

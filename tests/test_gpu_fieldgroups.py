@@ -1,0 +1,215 @@
+"""Field-grouped backward (rx_fg_group / rx_fg_reduce / rx_fg_row_update) against torch restatements:
+the grouping order bit for bit, the distinct-row set against torch.unique, gradients and updated rows
+against an fp64 scatter-add."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close as _assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_close(a, e, **kw):
+    _assert_close(a.detach().cpu().numpy(), e.detach().cpu().numpy(), **kw)
+
+
+def _bases(dims):
+    out = [0]
+    for d in dims:
+        out.append(out[-1] + int(d))
+    return out
+
+
+def _expected_order(sparse, dims):
+    """Per field: positions ordered by (bin, row >> 8, sample), bin = row for the field's first 256
+    rows and 256 + (row & 255) beyond — numpy lexsort, stable."""
+    B, nf = sparse.shape
+    base = _bases(dims)
+    srow, sb = [], []
+    s = sparse.cpu().numpy()
+    for f in range(nf):
+        r = s[:, f]
+        order = np.lexsort((np.arange(B), r >> 8, np.where(r < 256, r, 256 + (r & 255))))
+        srow.append(r[order] + base[f])
+        sb.append(order)
+    return np.concatenate(srow), np.concatenate(sb)
+
+
+def _group(sparse, dims):
+    from recsys_amd import ops
+    F = sparse.shape[1] - 1
+    return ops.fg_group(sparse[:, :F], sparse[:, F:], _bases(dims))
+
+
+CASES = [
+    ([7, 1000, 13, 5000, 3, 211], 300, "zipf"),
+    ([300, 70000, 257, 256, 2, 1 << 20], 4096 + 17, "zipf"),
+    ([5, 40000], 1, "uniform"),
+    ([100000, 9, 3000000], 9000, "uniform"),
+    ([1 << 24, 50], 20000, "uniform"),
+    ([600, 90000], 30000, "one_row"),          # a single row (id >= 256) holds the whole field: beyond the small bucket kernel
+]
+
+
+@pytest.mark.parametrize("dims,B,dist", CASES)
+def test_grouping_order_is_exact(dims, B, dist):
+    from recsys_amd import ops, synthetic
+    g = torch.Generator(device="cuda").manual_seed(B)
+    if dist == "zipf":
+        sparse = synthetic.criteo_batch(dims, B, seed=B, device="cuda")["sparse"]
+    elif dist == "uniform":
+        sparse = torch.stack([torch.randint(0, d, (B,), generator=g, device="cuda") for d in dims], 1).contiguous()
+    else:
+        sparse = torch.stack([torch.full((B,), min(d - 1, 300 + 7 * k), device="cuda", dtype=torch.int64) for k, d in enumerate(dims)], 1).contiguous()
+    fg = _group(sparse, dims)
+    ops.raise_if_index_error()
+    exp_row, exp_b = _expected_order(sparse, dims)
+    got_row = (fg.srow.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+    got_b = (fg.sb.to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+    assert np.array_equal(got_row, exp_row)
+    assert np.array_equal(got_b, exp_b)
+    flat = (sparse + torch.tensor(_bases(dims)[:-1], device="cuda")[None, :]).reshape(-1)
+    assert torch.equal(torch.sort(fg.distinct_rows()).values, torch.unique(flat))
+
+
+def test_grouping_at_the_largest_supported_batch_and_a_quarter_batch_row():
+    """B = 65536 with Criteo-like fields; one field has a row that a third of the samples name and
+    that sits above id 255, so its bucket exceeds the LDS budget and is sorted through global memory."""
+    from recsys_amd import ops, synthetic
+    dims = [26361, 262552, 3483, 8129362, 27, 9995165, 70000]
+    B = 65536
+    sparse = synthetic.criteo_batch(dims, B, seed=3, device="cuda")["sparse"]
+    hot = torch.rand(B, device="cuda") < 0.34
+    sparse[hot, 6] = 40001
+    fg = _group(sparse, dims)
+    ops.raise_if_index_error()
+    exp_row, exp_b = _expected_order(sparse, dims)
+    assert np.array_equal((fg.srow.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), exp_row)
+    assert np.array_equal((fg.sb.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), exp_b)
+    again = _group(sparse, dims)
+    assert torch.equal(again.srow, fg.srow) and torch.equal(again.sb, fg.sb)
+
+
+def test_grouping_flags_an_index_outside_its_field():
+    from recsys_amd import ops
+    dims = [10, 300]
+    sparse = torch.tensor([[1, 5], [10, 7], [3, 299]], device="cuda")    # 10 is one past field 0
+    ops.set_index_check("deferred")
+    try:
+        _group(sparse, dims)
+        with pytest.raises(IndexError):
+            ops.raise_if_index_error()
+    finally:
+        ops.set_index_check("sync")
+
+
+def _reference_grads(table, bias, sparse, dims, T, g, deep, dim):
+    """fp64: G_r = sum_b g_b (T_b - e_r) + tower slices; bias gradient sum_b g_b."""
+    B, nf = sparse.shape
+    base = torch.tensor(_bases(dims)[:-1], device=sparse.device)
+    rows = sparse + base[None, :]
+    G = torch.zeros(table.shape, dtype=torch.float64, device=table.device)
+    G2 = torch.zeros(table.shape[0], dtype=torch.float64, device=table.device)
+    for f in range(nf):
+        r = rows[:, f]
+        occ = g.double()[:, None] * (T.double() - table.double()[r])
+        if deep is not None:
+            sl = 0 if f == nf - 1 else 1 + f
+            occ = occ + deep.double()[:, sl * dim:(sl + 1) * dim]
+        G.index_add_(0, r, occ)
+        G2.index_add_(0, r, g.double())
+    return G, G2
+
+
+@pytest.mark.parametrize("dim", [16, 32, 64, 128])
+@pytest.mark.parametrize("with_deep", [False, True])
+def test_reduce_modes_match_an_fp64_scatter_add(dim, with_deep):
+    from recsys_amd import _lib, ops, synthetic
+    dims = [7, 1000, 13, 5000, 3, 211, 40000]
+    B = 1500
+    torch.manual_seed(dim)
+    nf = len(dims)
+    n_rows = sum(dims)
+    table = torch.randn(n_rows, dim, device="cuda")
+    bias = torch.randn(n_rows, device="cuda")
+    sparse = synthetic.criteo_batch(dims, B, seed=dim, device="cuda")["sparse"]
+    T = torch.randn(B, dim, device="cuda")
+    g = torch.randn(B, device="cuda") / B
+    deep = (torch.randn(B, nf * dim + 12, device="cuda") / B) if with_deep else None
+    fg = _group(sparse, dims)
+    Gref, G2ref = _reference_grads(table, bias, sparse, dims, T, g, deep, dim)
+
+    # dense gradients
+    grad, grad2 = torch.zeros_like(table), torch.zeros_like(bias)
+    ops.fg_reduce(T, g, fg, _lib.RX_SEG_DENSE, grad, table=table, target2=grad2, deep=deep)
+    assert_close(grad, Gref.float(), rtol=1e-5, what="dense grad")
+    assert_close(grad2, G2ref.float(), rtol=1e-5, what="dense bias grad")
+    again, again2 = torch.zeros_like(table), torch.zeros_like(bias)
+    ops.fg_reduce(T, g, fg, _lib.RX_SEG_DENSE, again, table=table, target2=again2, deep=deep)
+    assert torch.equal(again, grad) and torch.equal(again2, grad2)          # run-to-run bitwise
+
+    # compact gradients at the runs' last positions + sum of squares
+    comp = torch.full((fg.n, dim), float("nan"), device="cuda")
+    comp2 = torch.full((fg.n,), float("nan"), device="cuda")
+    sq = ops.fg_reduce(T, g, fg, _lib.RX_SEG_COMPACT, comp, table=table, target2=comp2, want_sq=True, deep=deep)
+    r = fg.srow.to(torch.int64) & 0xFFFFFFFF
+    end = torch.ones_like(r, dtype=torch.bool)
+    end[:-1] = r[:-1] != r[1:]
+    assert torch.equal(comp[end], grad[r[end]]) and torch.equal(comp2[end], grad2[r[end]])
+    total = float(sq.double().sum().item())
+    ref_total = float((Gref ** 2).sum().item() + (G2ref ** 2).sum().item())
+    assert abs(total - ref_total) <= 1e-5 * ref_total
+
+    # fused SGD in place == dense SGD on the touched rows, untouched rows bit-identical
+    lr = 0.3
+    w, w2 = table.clone(), bias.clone()
+    ops.fg_reduce(T, g, fg, _lib.RX_SEG_SGD, w, target2=w2, lr=lr, deep=deep)
+    assert_close(w, (table.double() - lr * Gref).float(), rtol=1e-5, what="sgd rows")
+    assert_close(w2, (bias.double() - lr * G2ref).float(), rtol=1e-5, what="sgd bias")
+    touched = torch.zeros(n_rows, dtype=torch.bool, device="cuda")
+    touched[r] = True
+    assert torch.equal(w[~touched], table[~touched]) and torch.equal(w2[~touched], bias[~touched])
+
+    # two-phase: compact + row update with a scale == one-phase with the same scale
+    scale = torch.tensor([0.37], device="cuda")
+    for mode, name in ((_lib.RX_SEG_SGD, "sgd"), (_lib.RX_SEG_ADAGRAD, "adagrad"), (_lib.RX_SEG_ROWWISE_ADAGRAD, "rowwise")):
+        shape = (n_rows, dim) if mode == _lib.RX_SEG_ADAGRAD else (n_rows,)
+        st_a = torch.rand(shape, device="cuda") if mode != _lib.RX_SEG_SGD else None
+        st2_a = torch.rand(n_rows, device="cuda") if mode != _lib.RX_SEG_SGD else None
+        st_b = st_a.clone() if st_a is not None else None
+        st2_b = st2_a.clone() if st2_a is not None else None
+        wa, wa2 = table.clone(), bias.clone()
+        ops.fg_reduce(T, g, fg, mode, wa, state=st_a, target2=wa2, state2=st2_a, lr=lr, eps=1e-10, scale=scale, deep=deep)
+        wb, wb2 = table.clone(), bias.clone()
+        ops.fg_row_update(comp, fg, mode, wb, state=st_b, lr=lr, eps=1e-10, scale=scale, compact2=comp2, table2=wb2, state2=st2_b)
+        assert torch.equal(wa, wb) and torch.equal(wa2, wb2), name
+        if st_a is not None:
+            assert torch.equal(st_a, st_b) and torch.equal(st2_a, st2_b), name
+        assert torch.equal(wa[~touched], table[~touched]), name
+        if mode == _lib.RX_SEG_SGD:
+            assert_close(wa, (table.double() - lr * 0.37 * Gref).float(), rtol=1e-5, what="scaled sgd")
+
+
+def test_reduce_agrees_with_the_sorted_path_on_hot_rows():
+    """Runs of thousands of positions (tiny fields) cross many wavefront windows: compare with the
+    position-ordered reduce over the fully sorted list (rx_segreduce_fm)."""
+    from recsys_amd import _lib, ops, synthetic
+    dims = [3, 11, 600, 90000]
+    B, dim = 20000, 16
+    torch.manual_seed(1)
+    n_rows = sum(dims)
+    table = torch.randn(n_rows, dim, device="cuda")
+    sparse = synthetic.criteo_batch(dims, B, seed=5, device="cuda")["sparse"]
+    T = torch.randn(B, dim, device="cuda")
+    g = torch.randn(B, device="cuda") / B
+    fg = _group(sparse, dims)
+    grad, grad2 = torch.zeros_like(table), torch.zeros(n_rows, device="cuda")
+    ops.fg_reduce(T, g, fg, _lib.RX_SEG_DENSE, grad, table=table, target2=grad2)
+    F = len(dims) - 1
+    base = torch.tensor(_bases(dims)[:F], device="cuda")
+    si = ops.fm_sort_dedup(table, sparse[:, :F], base, sparse[:, F:], _bases(dims)[F])
+    old, old2 = torch.zeros_like(table), torch.zeros(n_rows, device="cuda")
+    ops.segreduce_fm(T, g, F, si, _lib.RX_SEG_DENSE, old, table=table, target2=old2)
+    assert_close(grad, old, rtol=1e-5, what="grad vs sorted path")
+    assert_close(grad2, old2, rtol=1e-5, what="bias grad vs sorted path")
