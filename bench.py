@@ -238,7 +238,7 @@ def back_to_back_ms(op_name, call, reps=30):
     return s.elapsed_time(e) / reps, reps
 
 
-ALL_OPS = ["fm2_fwd", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "fm_sort_dedup", "fg_group", "segreduce", "segreduce_fm", "fg_reduce",
+ALL_OPS = ["fm2_fwd", "fm2_fwd_bce", "fm2_bwd", "fm2_flat_indices", "sort_dedup", "fm_sort_dedup", "fg_group", "segreduce", "segreduce_fm", "fg_reduce",
            "row_update", "fg_row_update", "bce_with_logits",
            "mf_score_fwd", "mf_score_bwd", "gather_concat", "gather_concat_bwd", "gmf_mul_fwd", "gmf_mul_bwd",
            "linear_fwd", "linear_bwd_x", "linear_bwd_w", "relu_bwd", "sumsq_accumulate", "sum_accumulate",

@@ -181,6 +181,17 @@ typedef struct {
 int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, float* d_tsum,
                int32_t* err_flag, int device, void* stream);
 
+/* rx_fm2_fwd followed by the loss of recsys/models/matrix_factorization/factorization_machine.py:68-72
+ * (F.binary_cross_entropy_with_logits, mean, fp64) in one launch, for N == 1: d_loss [1] fp64,
+ * d_logits [B] (may be NULL), and per sample the record the field-grouped backward reads:
+ * d_gt[b, 0:dim] = g_b * T_b, d_gt[b, dim] = g_b with g_b = (sigmoid(x_b) - y_b) / B (row stride ld_gt
+ * >= dim + 1, a multiple of 4).  Two launches: the forward with per-block loss sums, and the
+ * one-block sum of those.  ws: rx_fm2_fwd_bce_workspace_bytes bytes. */
+size_t rx_fm2_fwd_bce_workspace_bytes(int64_t B, int32_t dim);
+int rx_fm2_fwd_bce(const rx_fm_args* a, const void* d_labels, int labels_f64, float* d_logits,
+                   float* d_gt, int64_t ld_gt, double* d_loss, void* ws, size_t ws_bytes,
+                   int32_t* err_flag, int device, void* stream);
+
 /* Backward given g [B,N] (and optionally d_deep [B*N,(1+F)*dim]):
  *   d_occ [(B*F + B*N), dim]: rows 0..B*F-1 = gradient of e_(b,f); then B*N item rows
  *   d_bias_occ [(B*F + B*N)]: gradient of the bias entries in the same order (NULL ok)
@@ -328,19 +339,31 @@ size_t rx_fg_workspace_bytes(int64_t B, int32_t n_fields);
 int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb, void* ws, size_t ws_bytes,
                 int32_t* err_flag, int device, void* stream);
 
-/* Reduce + consume over that order; arguments as rx_segreduce_fm (T, g, optional tower-input
- * gradient d_deep laid out [last field | field 0 .. n_fields-2 | extra columns], modes, companion
- * [rows,1] table, clip factor, per-block sums of squares) with two differences: RX_SEG_COMPACT
- * writes the gradient of a run to target[p, :] / target2[p] with p the run's LAST position (buffers
- * of B * n_fields rows), and d_sq_part has rx_fg_reduce_grid(n, dim) entries.  One lane group per
- * position, segmented scan by row inside a wavefront, fixed tree: bitwise reproducible. */
+/* Reduce + consume over that order; meaning of the fields as in rx_segreduce_fm (T, g, optional
+ * tower-input gradient `deep` laid out [last field | field 0 .. n_fields-2 | extra columns], modes,
+ * companion [rows,1] table, clip factor, per-block sums of squares) with these differences:
+ * RX_SEG_COMPACT writes the gradient of a run to target[p, :] / target2[p] with p the run's LAST
+ * position (buffers of B * n_fields rows); sq_part has rx_fg_reduce_grid(n, dim) entries; g is read
+ * as g[b * ld_g]; with premultiplied != 0, T[b, :] already holds g_b * T_b (what rx_fm2_fwd_bce
+ * leaves).
+ * One lane group per 8 consecutive positions, one segmented scan per wavefront, fixed tree:
+ * bitwise reproducible. */
+typedef struct {
+  const float* T; int64_t ld_T;
+  const float* g; int64_t ld_g;
+  const float* deep; int64_t deep_ld;     /* NULL: no tower */
+  int64_t B;
+  int32_t n_fields, dim, mode, premultiplied;
+  const uint32_t* srow; const uint32_t* sb;
+  float* target; float* state; const float* table; float* target2; float* state2;
+  int64_t n_rows;
+  float lr, eps;
+  const float* scale;                      /* NULL: 1 */
+  float* sq_part;                          /* NULL: no sums of squares */
+} rx_fg_reduce_args;
 int64_t rx_fg_reduce_grid(int64_t n, int32_t dim);
 size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim);
-int rx_fg_reduce(const float* d_T, int64_t ld_T, const float* d_g, const float* d_deep, int64_t deep_ld,
-                 int64_t B, int32_t n_fields, int32_t dim, const uint32_t* d_srow, const uint32_t* d_sb,
-                 int mode, float* d_target, float* d_state, const float* d_table, float* d_target2,
-                 float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
-                 float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
+int rx_fg_reduce(const rx_fg_reduce_args* a, void* ws, size_t ws_bytes, int device, void* stream);
 /* Second phase of a clipped step: every run's row moves by its compact gradient (at the run's last
  * position) times *d_scale; mode SGD / ADAGRAD / ROWWISE_ADAGRAD; companion table in the same launch. */
 int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,

@@ -51,7 +51,13 @@ sq = torch.empty(ops.fg_reduce_grid(B * nf, D), device=dev)
 timed("fg_reduce", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=table, target2=comp2, want_sq=True, sq_out=sq))
 scale = torch.zeros(1, device=dev)
 timed("fg_row_update", lambda i: ops.fg_row_update(comp, fgs[i % 4], _lib.RX_SEG_SGD, table, lr=0.05, scale=scale, compact2=comp2, table2=bias))
+timed("fg_row_update/nobias", lambda i: ops.fg_row_update(comp, fgs[i % 4], _lib.RX_SEG_SGD, table, lr=0.05, scale=scale))
+timed("fg_reduce/nobias", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=table, want_sq=True, sq_out=sq))
+timed("fm2_fwd/nobias", lambda i: ops.fm2_fwd(table, None, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], want_tsum=True))
 timed("fm2_fwd", lambda i: ops.fm2_fwd(table, bias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], want_tsum=True))
+labels = (torch.rand(B, 1, device=dev) < 0.25).double()
+timed("fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(table, bias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
+timed("bce", lambda i: ops.bce_with_logits(T[:, :1].contiguous(), labels))
 if os.environ.get("OLD") == "1":
     sis = [ops.fm_sort_dedup(table, sp[:, :nf - 1], ex_base, sp[:, nf - 1:], base[nf - 1]) for sp in batches]
     timed("fm_sort_dedup", lambda i: ops.fm_sort_dedup(table, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], out=sis[i % 4]))

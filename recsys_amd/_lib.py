@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librecsys_hip.so")
+# RX_LIB_PATH: another build of the same library (A/B timing of kernel variants); never a different implementation
+LIB_PATH = os.environ.get("RX_LIB_PATH") or os.path.join(_HERE, "librecsys_hip.so")
 
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
 vp, sz = C.c_void_p, C.c_size_t
@@ -42,6 +43,13 @@ RX_FG_MAX_FIELDS = 64
 class FGArgs(C.Structure):
     _fields_ = [("ex_idx", vp), ("item_idx", vp), ("ex_ld", i64), ("item_ld", i64), ("B", i64),
                 ("n_fields", i32), ("pad_", i32), ("field_base", i64 * (RX_FG_MAX_FIELDS + 1))]
+
+
+class FGReduceArgs(C.Structure):
+    _fields_ = [("T", vp), ("ld_T", i64), ("g", vp), ("ld_g", i64), ("deep", vp), ("deep_ld", i64), ("B", i64),
+                ("n_fields", i32), ("dim", i32), ("mode", i32), ("premultiplied", i32), ("srow", vp), ("sb", vp),
+                ("target", vp), ("state", vp), ("table", vp), ("target2", vp), ("state2", vp), ("n_rows", i64),
+                ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp)]
 
 
 RX_FM_NO_SECOND_ORDER = 1
@@ -85,8 +93,9 @@ PROTOTYPES = {
     "rx_fg_group": (C.c_int, [C.POINTER(FGArgs), vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_fg_reduce_grid": (i64, [i64, i32]),
     "rx_fg_reduce_workspace_bytes": (sz, [i64, i32]),
-    "rx_fg_reduce": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, vp, vp, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp,
-                               vp, vp, sz, C.c_int, vp]),
+    "rx_fg_reduce": (C.c_int, [C.POINTER(FGReduceArgs), vp, sz, C.c_int, vp]),
+    "rx_fm2_fwd_bce_workspace_bytes": (sz, [i64, i32]),
+    "rx_fm2_fwd_bce": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp, vp, i64, vp, vp, sz, vp, C.c_int, vp]),
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),

@@ -211,18 +211,21 @@ class Presort:
         return self.si
 
 
-def table_backward_fm(feat, bias_table, si, tsum, g, n_fields_ex: int, deep=None):
+def table_backward_fm(feat, bias_table, si, tsum, g, n_fields_ex: int, deep=None, premultiplied: bool = False):
     """N == 1 FM backward without per-occurrence rows (rx_segreduce_fm, or rx_fg_reduce when ``si``
     is a field-grouped list); ``deep``: gradient of the tower input, whose per-field slices join the
     rows' gradients in the same pass."""
     rule = getattr(feat, "_rx_sparse", None)
+    if premultiplied and not isinstance(si, FieldGroups):
+        raise RuntimeError("premultiplied rows are read by the field-grouped reduce only")
     if rule is not None:
-        rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex, deep)
+        rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex, deep, premultiplied)
         return None, None
     grad = torch.zeros_like(feat)
     grad2 = torch.zeros_like(bias_table) if bias_table is not None else None
     if isinstance(si, FieldGroups):
-        ops.fg_reduce(tsum, g, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep)
+        ops.fg_reduce(tsum, g, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep,
+                      premultiplied=premultiplied)
         return grad, grad2
     ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep)
     return grad, grad2
@@ -278,6 +281,37 @@ class FM2(Function):
         else:
             gfeat, gbias = table_backward(feat, s, occ), None
         return (None, None, None, None, gfeat, gbias) + none_tail
+
+
+class FMLoss(Function):
+    """Forward + BCE loss of the one-item-per-sample FM as one launch (rx_fm2_fwd_bce), backward over
+    the field-grouped occurrence list.  Used by FieldFM.loss when the batch qualifies for field
+    groups; the forward leaves g_b * T_b and g_b per sample, so the backward starts at the reduce."""
+
+    @staticmethod
+    def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, labels, presort, field_base):
+        bias_flat = None if bias_table is None else bias_table.reshape(-1)
+        loss, gt, _ = ops.fm2_fwd_bce(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, labels.contiguous())
+        ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
+        ctx.gt, ctx.field_base = gt, field_base
+        ctx.sort = presort
+        if presort is not None and not isinstance(presort.join(), FieldGroups):
+            ctx.sort = None
+        if ctx.sort is None and ctx.needs_input_grad[4]:
+            ctx.sort = _AsyncSort(feat, ex_idx, ex_base, item_idx, item_base, field_base)
+        return loss if labels.dtype == torch.float64 else loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        ex_idx, ex_base, item_idx, item_base, feat, bias_table = ctx.args
+        gt = ctx.gt
+        if not _UNIT_LOSS_GRAD:   # an upstream factor other than 1 (loss * c): scale the saved records
+            gt = gt * g.to(torch.float32)
+        fg = ctx.sort.join()
+        dim = feat.shape[1]
+        gfeat, gbias = table_backward_fm(feat, bias_table, fg, gt[:, :dim], gt[:, dim], ex_idx.shape[1], None,
+                                         premultiplied=True)
+        return (None, None, None, None, gfeat, gbias, None, None, None)
 
 
 # ------------------------------------------------------------------ tower-input assembly
@@ -493,7 +527,7 @@ def backward_from_loss(loss: Tensor) -> None:
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ == "BCEWithLogitsBackward"):
+    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward")):
         loss.backward(gradient=one)
         return
     _UNIT_LOSS_GRAD = True

@@ -588,7 +588,7 @@ extern "C" int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb
 
 struct FgRed {
   const float* T; int64_t ldT;
-  const float* g;
+  const float* g; int64_t ldg; int premul;   // g[b * ldg]; premul: T already holds g_b * T_b
   const float* deep; int64_t deep_ld;
   const uint32_t* srow; const uint32_t* sb;
   int64_t n; int B; int nf; int dim;
@@ -669,6 +669,9 @@ __device__ __forceinline__ void fg_block_sq_store(float sq, float* sq_part, floa
 // meta[window] describes the run that enters from the left: the number of leading positions it
 // holds in this window, bit 31 set when it goes on past the window's end.
 #define FG_META_GOES_ON 0x80000000u
+#ifndef FG_ABLATE
+#define FG_ABLATE 0
+#endif
 template <int GROUP, int S, int MODE, bool DEEP>
 __global__ void __launch_bounds__(RX_BLOCK)
 fg_reduce_kernel(FgRed a) {
@@ -714,7 +717,7 @@ fg_reduce_kernel(FgRed a) {
       endf[s] = rw[s + 1] != FG_NONE && rw[s + 2] != rw[s + 1] && (int64_t)rw[s + 1] < a.n_rows;
       e[s] = make_float4(0.f, 0.f, 0.f, 0.f);
       old2[s] = 0.f;
-      if (endf[s]) {
+      if (endf[s] && !(FG_ABLATE & 2)) {
         e[s] = *reinterpret_cast<const float4*>(tab + (int64_t)rw[s + 1] * DIM + lg * 4);
         if (MODE == RX_SEG_SGD && has2 && lg == 0) old2[s] = a.target2[rw[s + 1]];
       }
@@ -722,10 +725,11 @@ fg_reduce_kernel(FgRed a) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const bool valid = rw[s + 1] != FG_NONE;
-      const float gb = a.g[bb[s]];
-      const float4 t = *reinterpret_cast<const float4*>(a.T + (int64_t)bb[s] * a.ldT + lg * 4);
+      const float gb = (FG_ABLATE & 1) ? 1.f : a.g[(int64_t)bb[s] * a.ldg];
+      const float4 t = (FG_ABLATE & 1) ? make_float4(1.f, 2.f, 3.f, (float)bb[s]) : *reinterpret_cast<const float4*>(a.T + (int64_t)bb[s] * a.ldT + lg * 4);
       const float gv = valid ? gb : 0.f;
-      v[s] = make_float4(gv * t.x, gv * t.y, gv * t.z, gv * t.w);
+      const float mv = valid ? (a.premul ? 1.f : gb) : 0.f;   // times one is exact: premultiplied rows pass through
+      v[s] = make_float4(mv * t.x, mv * t.y, mv * t.z, mv * t.w);
       w2[s] = gv;
       if constexpr (DEEP) {
         // the occurrence's slice of the tower-input gradient: [last field | field 0 .. nf-2 | ...]
@@ -750,6 +754,8 @@ fg_reduce_kernel(FgRed a) {
       if (endf[s]) {
         if (cont_in && !seen_end) {  // needs what the groups before this one hold: kept for after the scan
           hsum = acc; h2 = acc2; he = e[s]; hold2 = old2[s]; hs = s; hrow = rw[s + 1];
+        } else if (FG_ABLATE & 4) {
+          sq += acc.x + acc2 + e[s].x;
         } else {
           sq += fg_finish<GROUP, MODE>(a, acc, acc2, e[s], old2[s], rw[s + 1], gbase + s, lg, scale);
         }
@@ -1017,33 +1023,34 @@ extern "C" size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim) {
     }                                                                                  \
   } while (0)
 
-extern "C" int rx_fg_reduce(const float* d_T, int64_t ld_T, const float* d_g, const float* d_deep, int64_t deep_ld,
-                            int64_t B, int32_t n_fields, int32_t dim, const uint32_t* d_srow, const uint32_t* d_sb,
-                            int mode, float* d_target, float* d_state, const float* d_table, float* d_target2,
-                            float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
-                            float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream) {
+extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_bytes, int device, void* stream) {
   RX_ENTER(device);
+  RX_REQUIRE(r, "rx_fg_reduce: null args");
+  const int64_t B = r->B;
+  const int n_fields = r->n_fields, dim = r->dim, mode = r->mode;
   RX_REQUIRE(B >= 0 && n_fields >= 1 && n_fields <= RX_FG_MAX_FIELDS, "rx_fg_reduce: bad shape");
   RX_REQUIRE(fg_group_of(dim), "rx_fg_reduce: dim %d unsupported (16, 32, 64 or 128)", dim);
   RX_REQUIRE(mode >= RX_SEG_DENSE && mode <= RX_SEG_ROWWISE_ADAGRAD, "rx_fg_reduce: unknown mode %d", mode);
   const int64_t n = B * n_fields;
   if (n == 0) return 0;
   RX_REQUIRE(n < (1ll << 31), "rx_fg_reduce: too many occurrences");
-  RX_REQUIRE(d_T && d_g && d_srow && d_sb && d_target && ws, "rx_fg_reduce: null argument");
-  RX_REQUIRE(rx_aligned16(d_srow) && rx_aligned16(d_sb), "rx_fg_reduce: the grouped arrays must be 16-byte aligned");
-  RX_REQUIRE(ld_T >= dim && ld_T % 4 == 0 && rx_aligned16(d_T) && rx_aligned16(d_target), "rx_fg_reduce: T / target must be 16-byte aligned with a row stride that is a multiple of 4");
+  RX_REQUIRE(r->T && r->g && r->srow && r->sb && r->target && ws, "rx_fg_reduce: null argument");
+  RX_REQUIRE(rx_aligned16(r->srow) && rx_aligned16(r->sb), "rx_fg_reduce: the grouped arrays must be 16-byte aligned");
+  RX_REQUIRE(r->ld_T >= dim && r->ld_T % 4 == 0 && rx_aligned16(r->T) && rx_aligned16(r->target), "rx_fg_reduce: T / target must be 16-byte aligned with a row stride that is a multiple of 4");
+  RX_REQUIRE(r->ld_g >= 1, "rx_fg_reduce: ld_g must be positive");
   const bool grad_mode = mode == RX_SEG_DENSE || mode == RX_SEG_COMPACT;
-  RX_REQUIRE(!grad_mode || (d_table && rx_aligned16(d_table)), "rx_fg_reduce: gradient modes need the (16-byte aligned) table to read rows from");
-  RX_REQUIRE(!(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || (d_state && (!d_target2 || d_state2)), "rx_fg_reduce: Adagrad needs its state buffers");
-  RX_REQUIRE(mode != RX_SEG_ADAGRAD || rx_aligned16(d_state), "rx_fg_reduce: state must be 16-byte aligned");
-  RX_REQUIRE(n_rows >= 1 && n_rows <= (1ll << 32) - 16, "rx_fg_reduce: n_rows out of range");
+  RX_REQUIRE(!grad_mode || (r->table && rx_aligned16(r->table)), "rx_fg_reduce: gradient modes need the (16-byte aligned) table to read rows from");
+  RX_REQUIRE(!(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || (r->state && (!r->target2 || r->state2)), "rx_fg_reduce: Adagrad needs its state buffers");
+  RX_REQUIRE(mode != RX_SEG_ADAGRAD || rx_aligned16(r->state), "rx_fg_reduce: state must be 16-byte aligned");
+  RX_REQUIRE(r->n_rows >= 1 && r->n_rows <= (1ll << 32) - 16, "rx_fg_reduce: n_rows out of range");
   RX_REQUIRE(ws_bytes >= rx_fg_reduce_workspace_bytes(n, dim) && rx_aligned16(ws), "rx_fg_reduce: workspace too small or unaligned");
-  const bool deep = d_deep != nullptr;
-  if (deep) RX_REQUIRE(deep_ld >= (int64_t)n_fields * dim && deep_ld % 4 == 0 && rx_aligned16(d_deep), "rx_fg_reduce: tower gradient must be 16-byte aligned, row stride a multiple of 4 and >= n_fields * dim");
+  const bool deep = r->deep != nullptr;
+  if (deep) RX_REQUIRE(r->deep_ld >= (int64_t)n_fields * dim && r->deep_ld % 4 == 0 && rx_aligned16(r->deep), "rx_fg_reduce: tower gradient must be 16-byte aligned, row stride a multiple of 4 and >= n_fields * dim");
   FgRed a{};
-  a.T = d_T; a.ldT = ld_T; a.g = d_g; a.deep = d_deep; a.deep_ld = deep_ld; a.srow = d_srow; a.sb = d_sb;
-  a.n = n; a.B = (int)B; a.nf = n_fields; a.dim = dim; a.target = d_target; a.state = d_state; a.table = d_table;
-  a.target2 = d_target2; a.state2 = d_state2; a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale; a.sq_part = d_sq_part;
+  a.T = r->T; a.ldT = r->ld_T; a.g = r->g; a.ldg = r->ld_g; a.premul = r->premultiplied; a.deep = r->deep; a.deep_ld = r->deep_ld;
+  a.srow = r->srow; a.sb = r->sb;
+  a.n = n; a.B = (int)B; a.nf = n_fields; a.dim = dim; a.target = r->target; a.state = r->state; a.table = r->table;
+  a.target2 = r->target2; a.state2 = r->state2; a.n_rows = r->n_rows; a.lr = r->lr; a.eps = r->eps; a.scale = r->scale; a.sq_part = r->sq_part;
   const size_t nw = (size_t)fg_windows(n, dim);
   char* w = (char*)ws;
   a.partials = (float*)w; w += rx_align_up(nw * 2 * dim * sizeof(float), 256);

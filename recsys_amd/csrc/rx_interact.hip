@@ -549,6 +549,132 @@ extern "C" int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_ou
   return 0;
 }
 
+__global__ void bce_final_kernel(const double* __restrict__ partial, int n, int64_t M, double* __restrict__ loss);
+
+// ---- forward + loss of the one-item-per-sample FM: the lane group that has just formed a
+// sample's logit also forms its BCE term and dL/dlogit g_b (fp64, as bce_kernel does), and leaves
+// what the field-grouped backward reads per occurrence in one 128-byte-aligned record:
+// gt[b, 0:dim] = g_b * T_b (T_b = sum of the sample's rows) and gt[b, dim] = g_b.  Every block stores
+// the fp64 sum of its terms; bce_final_kernel adds the block sums in a fixed order.  (Letting the
+// last block to finish do that sum behind a ticket was measured: the ticket's two memory round
+// trips at the end of every block cost 12 us per launch, the separate one-block launch 4.)
+template <int VEC, int CH, bool F64>
+__global__ void __launch_bounds__(RX_BLOCK)
+fm2_fwd_bce_kernel(rx_fm_args a, const void* __restrict__ labels, float* __restrict__ logits,
+                   float* __restrict__ gt, int64_t ld_gt, double* __restrict__ partial, int group,
+                   int32_t* err_flag) {
+  extern __shared__ int64_t lds_idx[];  // [spb][F]
+  __shared__ double wsum[RX_BLOCK / 64];
+  const int spb = blockDim.x / group;
+  const int64_t b0 = (int64_t)blockIdx.x * spb;
+  const int F = a.F, dim = a.dim;
+  {
+    const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
+    const int n_here = (int)rows_here * F;
+    const int64_t* src = a.ex_idx + b0 * a.ex_ld;
+    for (int j = threadIdx.x; j < n_here; j += blockDim.x) {
+      const int r = j / F, f = j - r * F;
+      lds_idx[j] = src[r * a.ex_ld + f] + a.ex_base[f];
+    }
+  }
+  __syncthreads();
+  const int my = threadIdx.x / group;
+  const int lg = threadIdx.x % group;
+  const int64_t b = b0 + my;
+  const bool active = b < a.B;
+  int32_t* ef = lg == 0 ? err_flag : nullptr;
+  double term = 0.0;
+  if (active) {
+    RowRegs<VEC, CH> S = row_zero<VEC, CH>(), Q = row_zero<VEC, CH>();
+    float bsum = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const int64_t row = lds_idx[my * F + f];
+      const bool ok = rx_row_ok(row, a.n_feat, ef);
+      RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+      if (a.bias && ok) bsum += a.bias[row];
+      ROW_FOREACH(k, i) {
+        S.p[k].v[i] += e.p[k].v[i];
+        Q.p[k].v[i] += e.p[k].v[i] * e.p[k].v[i];
+      }
+    }
+    const int64_t row = a.item_idx[b * a.item_ld] + a.item_base;
+    const bool ok = rx_row_ok(row, a.n_feat, ef);
+    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    float acc = 0.f;
+    RowRegs<VEC, CH> t;
+    ROW_FOREACH(k, i) {
+      const float s = S.p[k].v[i] + v.p[k].v[i];
+      const float q = Q.p[k].v[i] + v.p[k].v[i] * v.p[k].v[i];
+      acc += s * s - q;
+      t.p[k].v[i] = s;
+    }
+    acc = rx_group_sum(acc, group);
+    float bt = bsum;
+    if (a.bias && ok) bt += a.bias[row];
+    const float xf = (a.flags & RX_FM_NO_SECOND_ORDER) ? bt : bt + 0.5f * acc;
+    float g = 0.f;
+    if (lg == 0) {
+      const double x = (double)xf;
+      const double y = F64 ? reinterpret_cast<const double*>(labels)[b] : (double)reinterpret_cast<const float*>(labels)[b];
+      const double e = exp(-fabs(x));
+      term = fmax(x, 0.0) - x * y + log1p(e);
+      const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+      g = (float)((sig - y) * (1.0 / (double)a.B));
+      if (logits) logits[b] = xf;
+      gt[b * ld_gt + dim] = g;
+    }
+    g = __shfl(g, (int)(threadIdx.x & 63) - lg, 64);
+    ROW_FOREACH(k, i) t.p[k].v[i] *= g;
+    row_store<VEC, CH>(gt + b * ld_gt, t, lg, group, dim);
+  }
+  term = rx_wave_sum_f64(term);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < RX_BLOCK / 64; ++w) s += wsum[w];
+    partial[blockIdx.x] = s;
+  }
+}
+
+// workspace: one fp64 partial per block
+extern "C" size_t rx_fm2_fwd_bce_workspace_bytes(int64_t B, int32_t dim) {
+  RxRowShape sh = rx_row_shape(dim > 0 ? dim : 1);
+  if (sh.chunks == 3) sh.chunks = 4;
+  const int64_t grid = rx_cdiv(B > 0 ? B : 1, RX_BLOCK / sh.group);
+  return rx_align_up((size_t)grid * sizeof(double), 256);
+}
+
+extern "C" int rx_fm2_fwd_bce(const rx_fm_args* a, const void* d_labels, int labels_f64, float* d_logits,
+                              float* d_gt, int64_t ld_gt, double* d_loss, void* ws, size_t ws_bytes,
+                              int32_t* err_flag, int device, void* stream) {
+  RX_ENTER(device);
+  if (fm_check(a, "rx_fm2_fwd_bce")) return 1;
+  RX_REQUIRE(a->N == 1, "rx_fm2_fwd_bce: one item per sample only (N == 1)");
+  RX_REQUIRE(a->B >= 1, "rx_fm2_fwd_bce: empty batch");
+  RX_REQUIRE(d_labels && d_gt && d_loss && ws, "rx_fm2_fwd_bce: null argument");
+  RX_REQUIRE(ws_bytes >= rx_fm2_fwd_bce_workspace_bytes(a->B, a->dim) && ((uintptr_t)ws & 15) == 0, "rx_fm2_fwd_bce: workspace too small or unaligned");
+  RxRowShape sh;
+  size_t lds;
+  if (fm_launch_shape(a, &sh, &lds, "rx_fm2_fwd_bce")) return 1;
+  RX_REQUIRE(ld_gt >= a->dim + 1 && (sh.vec == 1 || (ld_gt % 4 == 0 && rx_aligned16(d_gt))), "rx_fm2_fwd_bce: gt needs a row stride >= dim + 1, a multiple of 4 floats, 16-byte aligned");
+  const unsigned grid = (unsigned)rx_cdiv(a->B, RX_BLOCK / sh.group);
+  double* partial = (double*)ws;
+  hipStream_t st = (hipStream_t)stream;
+#define FWD_BCE(V, C)                                                                                                          do {                                                                                                                           if (labels_f64) hipLaunchKernelGGL((fm2_fwd_bce_kernel<V, C, true>), dim3(grid), dim3(RX_BLOCK), lds, st, *a, d_labels, d_logits, d_gt, ld_gt, partial, sh.group, err_flag);     else hipLaunchKernelGGL((fm2_fwd_bce_kernel<V, C, false>), dim3(grid), dim3(RX_BLOCK), lds, st, *a, d_labels, d_logits, d_gt, ld_gt, partial, sh.group, err_flag);   } while (0)
+  if (sh.vec == 4 && sh.chunks == 1) FWD_BCE(4, 1);
+  else if (sh.vec == 4 && sh.chunks == 2) FWD_BCE(4, 2);
+  else if (sh.vec == 4) FWD_BCE(4, 4);
+  else if (sh.chunks == 1) FWD_BCE(1, 1);
+  else if (sh.chunks == 2) FWD_BCE(1, 2);
+  else FWD_BCE(1, 4);
+#undef FWD_BCE
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B, d_loss);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rx_fm2_bwd(const rx_fm_args* a, const float* d_g, const float* d_deep, float* d_occ,
                           float* d_bias_occ, int device, void* stream) {
   RX_ENTER(device);

@@ -73,6 +73,18 @@ class FieldFM(_FieldTable):
                                   inputs.get("_rx_presort"), self._field_base)
         return logits
 
+    def loss(self, inputs):
+        """BCE loss.  With field groups in use the logits, the loss and the per-sample backward
+        records come out of one launch (autograd.FMLoss); otherwise the generic two-step path."""
+        ex, base, item, item_base = self._split(inputs)
+        feat = self.feature_embedding.weight
+        labels = inputs["label"]
+        if (feat.is_cuda and labels.is_cuda and labels.numel() == ex.shape[0] and labels.dtype in (torch.float32, torch.float64)
+                and rxa.use_field_groups(feat, ex, item, self._field_base)):
+            return rxa.FMLoss.apply(ex, base, item, item_base, feat, self.bias_embedding.weight, labels,
+                                    inputs.get("_rx_presort"), self._field_base)
+        return super().loss(inputs)
+
 
 def _bn_stack(input_dim, hidden_dims, dropout):
     layers = []

@@ -620,10 +620,17 @@ def fg_reduce_grid(n: int, dim: int) -> int:
 def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tensor, *, table: Optional[Tensor] = None,
               state: Optional[Tensor] = None, target2: Optional[Tensor] = None, state2: Optional[Tensor] = None,
               lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None, want_sq: bool = False,
-              sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None) -> Optional[Tensor]:
+              sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None, premultiplied: bool = False) -> Optional[Tensor]:
     """rx_fg_reduce: the N == 1 FM backward over a field-grouped occurrence list (see FieldGroups).
-    In RX_SEG_COMPACT mode ``target`` / ``target2`` have one row per POSITION (fg.n rows)."""
-    _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
+    In RX_SEG_COMPACT mode ``target`` / ``target2`` have one row per POSITION (fg.n rows).
+    ``tsum`` [B, dim] and ``g`` [B] may be column blocks of one wider matrix (unit inner stride for
+    ``tsum``, any stride for ``g``); ``premultiplied``: ``tsum`` already holds g_b * T_b."""
+    for t, name in ((tsum, "T"), (g, "g")):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+            raise TypeError(f"{name}: expected an fp32 tensor on the GPU")
+    _req(target, torch.float32, "target")
+    if tsum.dim() != 2 or tsum.stride(1) != 1 or g.dim() != 1:
+        raise ValueError("fg_reduce: T must be [B, dim] with unit inner stride, g a vector")
     B, dim = tsum.shape
     deep_ld = 0
     if deep is not None:
@@ -644,11 +651,44 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
             if sq_out.numel() != need:
                 raise ValueError(f"sq_out: expected {need} contiguous floats")
             sq = sq_out
+    a = _lib.FGReduceArgs()
+    a.T, a.ld_T = tsum.data_ptr(), tsum.stride(0) if B > 1 else max(dim, tsum.stride(0))
+    a.g, a.ld_g = g.data_ptr(), (g.stride(0) if B > 1 else 1)
+    a.deep, a.deep_ld = (deep.data_ptr() if deep is not None else 0), deep_ld
+    a.B, a.n_fields, a.dim, a.mode, a.premultiplied = B, fg.n_fields, dim, mode, int(premultiplied)
+    a.srow, a.sb = fg.srow.data_ptr(), fg.sb.data_ptr()
+    for name, t in (("target", target), ("state", state), ("table", table), ("target2", target2), ("state2", state2),
+                    ("scale", scale), ("sq_part", sq)):
+        setattr(a, name, 0 if t is None else t.data_ptr())
+    a.n_rows, a.lr, a.eps = fg.n_rows, lr, eps
     ws = _ws(int(lib.rx_fg_reduce_workspace_bytes(fg.n, dim)), tsum.device)
-    check(lib.rx_fg_reduce(_p(tsum), tsum.stride(0), _p(g), _p(deep), deep_ld, B, fg.n_fields, dim, _p(fg.srow), _p(fg.sb),
-                           mode, _p(target), _p(state), _p(table), _p(target2), _p(state2), fg.n_rows, lr, eps,
-                           _p(scale), _p(sq), _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_fg_reduce")
+    check(lib.rx_fg_reduce(C.byref(a), _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_fg_reduce")
     return sq
+
+
+def fm2_fwd_bce(feat, bias, ex_idx, ex_base, item_idx, item_base: int, labels: Tensor, want_logits: bool = False):
+    """rx_fm2_fwd_bce: logits, BCE loss and the per-sample backward record from one forward kernel (N == 1).
+    Returns (loss fp64 scalar, gt [B, ld] fp32 with gt[:, :dim] = g_b * T_b and gt[:, dim] = g_b,
+    logits [B, 1] or None)."""
+    a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base)
+    if N != 1:
+        raise ValueError("fm2_fwd_bce: one item per sample only")
+    if labels.dtype not in (torch.float64, torch.float32):
+        raise TypeError(f"label: expected float64 or float32, got {labels.dtype}")
+    _req(labels, labels.dtype, "label")
+    if labels.numel() != B:
+        raise ValueError(f"label: expected {B} elements")
+    _same_device(feat, labels)
+    dim, dev = feat.shape[1], feat.device
+    ld = (dim + 1 + 31) // 32 * 32          # whole 128-byte lines per sample
+    gt = torch.empty(B, ld, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float64, device=dev)
+    logits = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_logits else None
+    ws = _ws(int(lib.rx_fm2_fwd_bce_workspace_bytes(B, dim)), dev)
+    check(lib.rx_fm2_fwd_bce(C.byref(a), _p(labels), int(labels.dtype == torch.float64), _p(logits), _p(gt), ld, _p(loss),
+                             _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(feat), _stream(feat)), "rx_fm2_fwd_bce")
+    _after_index_op(dev)
+    return loss, gt, logits
 
 
 def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,

@@ -58,7 +58,7 @@ class SparseRule:
         self.owner._pending.append((self, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
 
 
-def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None):
+def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, premultiplied=False):
     """N == 1 FM: reduce + update straight from T and g (rx_segreduce_fm)."""
     table, state = feat.data, self._state_for(feat)
     rule2 = getattr(bias_table, "_rx_sparse", None) if bias_table is not None else None
@@ -70,13 +70,13 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None):
         # field-grouped occurrence list: compact gradients live at the last position of each run
         if self.owner.clip_norm is None:
             ops.fg_reduce(tsum, g, si, self.mode, table, state=state, target2=table2, state2=state2,
-                          lr=self.lr, eps=self.eps, deep=deep)
+                          lr=self.lr, eps=self.eps, deep=deep, premultiplied=premultiplied)
             return
         compact = torch.empty(si.n, tsum.shape[1], dtype=torch.float32, device=table.device)
         compact2 = torch.empty(si.n, dtype=torch.float32, device=table.device) if bias_table is not None else None
         sq = ops.fg_reduce(tsum, g, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2, want_sq=True,
                            sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device, ops.fg_reduce_grid(si.n, tsum.shape[1])),
-                           deep=deep)
+                           deep=deep, premultiplied=premultiplied)
         self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
         return
     if self.owner.clip_norm is None:
