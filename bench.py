@@ -44,7 +44,10 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     from recsys_amd.optim import FusedOptimizer
 
     torch.manual_seed(1234)
-    n_batches = 10   # divides the usual step counts, so the timed region replays whole-round graphs only
+    # resident batches: enough that the rows a round touches exceed the 256 MiB Infinity Cache several
+    # times over for the D = 16 tables (64 batches name about 1 GB of distinct rows), so that the
+    # step's table traffic comes from HBM; RX_BENCH_BATCHES overrides (10 = the round-1 figure)
+    n_batches = int(os.environ.get("RX_BENCH_BATCHES", 64 if name in ("fm_criteo",) else 10))
     if name == "deepfm_criteo_sharded":
         # the Criteo-shaped DeepFM with its tables row-sharded and its BatchNorm tower data parallel
         # (tower gradients summed over the ranks by one all-reduce); 33 M rows x 16 per GPU
@@ -132,12 +135,13 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None, dims=dims if "fields" in desc else None)
     if use_graph:
         from recsys_amd.graph import GraphedTrainStep
-        gs = GraphedTrainStep(model, opt, pipeline=True, cycle=True)
+        gs = GraphedTrainStep(model, opt, pipeline=True, cycle=os.environ.get("RX_BENCH_NO_CYCLE") != "1", cycle_len=10)
         gs.add_batches(batches)
         w["graphed"] = gs
-        desc["launch"] = (f"HIP graph replays: one graph per round over the {n_batches} resident batches where the step "
-                          "count allows, one graph per step otherwise; the indices of batch i+1 are sorted on a side "
-                          "stream while batch i trains (one sort per step, off the critical path)")
+        desc["resident_batches"] = n_batches
+        desc["launch"] = (f"HIP graph replays over {n_batches} resident batches: one graph per 10 consecutive steps where "
+                          "the step count allows, one graph per step otherwise; the indices of batch i+1 are grouped on a "
+                          "side stream while batch i trains (one index preparation per step, off the critical path)")
     else:
         desc["launch"] = "eager"
     return w
@@ -149,9 +153,10 @@ def run_steps(w, first: int, count: int):
     gs, K = w.get("graphed"), len(w["batches"])
     i, end, loss = first, first + count, None
     while i < end:
-        if gs is not None and gs.cycle_graph is not None and i % K == 0 and end - i >= K:
-            loss = gs.run_cycle()[-1]
-            i += K
+        seg = gs.segment_at(i % K) if gs is not None else 0
+        if seg and end - i >= seg:
+            loss = gs.run_cycle(i % K)[-1]
+            i += seg
         else:
             loss = one_step(w, i)
             i += 1
@@ -255,14 +260,19 @@ OP_KERNELS = {
 }
 
 
-def unique_fraction(batches, dims):
-    """rho = distinct table rows / occurrences, averaged over the synthetic batches."""
+def unique_fraction(batches, dims, want_round=False):
+    """rho = distinct table rows / occurrences, averaged over the synthetic batches.  ``want_round``:
+    also the number of distinct rows over ALL resident batches (what a round of the timed region touches)."""
     offs = torch.tensor([0] + list(dims[:-1]), device=batches[0]["sparse"].device).cumsum(0)
-    fr = []
+    fr, seen = [], None
     for b in batches:
         flat = (b["sparse"] + offs[None, :]).reshape(-1)
-        fr.append(torch.unique(flat).numel() / flat.numel())
-    return sum(fr) / len(fr)
+        u = torch.unique(flat)
+        fr.append(u.numel() / flat.numel())
+        if want_round:
+            seen = u if seen is None else torch.unique(torch.cat([seen, u]))
+    rho = sum(fr) / len(fr)
+    return (rho, int(seen.numel())) if want_round else rho
 
 
 def algo_bytes(desc, op, rho=1.0):
@@ -312,13 +322,29 @@ def dense_flops_per_sample(name):
     return None
 
 
+def kernel_source_sha():
+    """sha256 over the HIP sources and the C header: identifies the kernels a PMC measurement was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "recsys_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "recsys_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "include", "recsys_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(op):
     """HBM bytes per launch from committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, summed
-    over the op's kernels), or None when no measurement is on file."""
+    over the op's kernels), or None when no measurement is on file — or when the file was taken on
+    other kernel sources than the ones in the tree (its ``_source_sha`` stamp)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path) or op not in OP_KERNELS:
         return None
     table = json.load(open(path))
+    if table.get("_source_sha") != kernel_source_sha():
+        print("[bench] profiles/pmc_traffic.json was measured on other kernel sources: roofline.traffic omitted", file=sys.stderr)
+        return None
     total = 0.0
     for k in OP_KERNELS[op]:
         if k not in table:
@@ -328,8 +354,10 @@ def measured_traffic(op):
 
 
 # ----------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(name, desc, clip, budget_s=25.0):
-    """The oracle's train step (dense gradients, clip_grad_norm_, torch SGD) on the host cores."""
+def cpu_baseline(name, desc, clip, budget_s=25.0, optimizer="sgd"):
+    """The oracle's train step (dense gradients, clip_grad_norm_, torch optimizer) on the host cores.
+    ``optimizer``: "sgd" matches the GPU step's update rule; "adam" is what the reference's pipelines
+    build (Adam(lr=1e-3), e.g. recsys/pipelines/matrix_factorization/vanilla_mf.py:10)."""
     from oracle.fields import FieldOracle
     from oracle.models import OracleModel, init_state
     from recsys_amd import synthetic
@@ -352,7 +380,7 @@ def cpu_baseline(name, desc, clip, budget_s=25.0):
                         embedding_dim=desc["dim"], seed=0)
         oracle = OracleModel(mname, st, n_users=synthetic.ML1M["n_users"], n_items=synthetic.ML1M["n_items"])
         batches = [synthetic.ml1m_batch(B, seed=i, device="cpu") for i in range(2)]
-    opt = torch.optim.SGD(oracle.parameters(), lr=0.05)
+    opt = torch.optim.SGD(oracle.parameters(), lr=0.05) if optimizer == "sgd" else torch.optim.Adam(oracle.parameters(), lr=1e-3)
 
     def step(i):
         opt.zero_grad()
@@ -373,7 +401,7 @@ def cpu_baseline(name, desc, clip, budget_s=25.0):
             break
     return {"value": B * n / el, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"{n} steps of the same workload (batch {B}) after 1 warm-up step, dense gradients + "
-                      f"clip_grad_norm_ + torch.optim.SGD, {el:.1f} s"}
+                      f"clip_grad_norm_ + torch.optim.{'SGD' if optimizer == 'sgd' else 'Adam(lr=1e-3)'}, {el:.1f} s"}
 
 
 # ----------------------------------------------------------------------------- main
@@ -383,6 +411,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="fm_criteo")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median one is reported")
     ap.add_argument("--no-clip", action="store_true", help="skip the global grad-norm clip (one-phase fused update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
@@ -427,7 +456,10 @@ def main():
     ops.set_index_check("deferred")
     clip = None if args.no_clip else 1.0
 
-    def run(name, steps, warmup, timed_op=None, use_graph=True):
+    def run(name, steps, warmup, timed_op=None, use_graph=True, repeats=1):
+        """Builds the workload, runs `warmup` untimed steps, then times `repeats` regions of EXACTLY `steps`
+        steps each (barrier + synchronize on both sides, maximum over the ranks); returns the median
+        region's time, and the list of all of them in w["region_s"]."""
         w = build_workload(name, device, rank, world, clip, use_graph)
         # the timed region starts on resident batch 0, where a whole-round graph may begin (any slot
         # can go first: all were prepared when they were registered)
@@ -438,24 +470,35 @@ def main():
             run_steps(w, 0, 24 - warmup)
             w.pop("prepared", None)
         run_steps(w, first, warmup)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
         timer = OpTimer([timed_op] if timed_op else [])
-        t0 = time.perf_counter()
-        with timer:
-            loss = run_steps(w, first + warmup, steps)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        pos, regions = first + warmup, []
+        gs, K = w.get("graphed"), len(w["batches"])
+        for _ in range(repeats):
+            # (between repeats: untimed steps up to the next slot where a multi-step graph starts)
+            while regions and gs is not None and gs.segments and not gs.segment_at(pos % K):
+                run_steps(w, pos, 1)
+                pos += 1
             torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with timer:
+                loss = run_steps(w, pos, steps)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            regions.append(el)
+            pos += steps
         ops.raise_if_index_error()
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        w["region_s"] = regions
+        el = sorted(regions)[len(regions) // 2]
         ops_ms = timer.summary()
         if timed_op and timed_op in timer.last_call:
             ops_ms[timed_op] = back_to_back_ms(timed_op, timer.last_call[timed_op])
@@ -486,7 +529,8 @@ def main():
         args.workload = "fm_criteo_sharded"
     if args.workload in ("fm_criteo_sharded", "deepfm_criteo_sharded"):
         use_graph = False
-    w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph)
+    w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph,
+                                   repeats=args.repeats)
     if use_graph:
         # the dominant kernel is timed with HIP events on the launch stream after a short eager pass of
         # the same steps (events cannot bracket a single node of a replayed graph)
@@ -496,15 +540,18 @@ def main():
     out = {
         "metric": "train samples/sec (fwd+bwd+update)", "value": value, "unit": "samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+        "timed_regions": {"count": len(w["region_s"]), "steps_each": args.steps, "reported": "median",
+                          "ms_per_step": [round(1e3 * x / args.steps, 5) for x in w["region_s"]],
+                          "min": 1e3 * min(w["region_s"]) / args.steps, "max": 1e3 * max(w["region_s"]) / args.steps},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": workload_dtype(args.workload), "data": "synthetic",
         "config": dict(w["desc"], global_batch=B * world, parallelism=f"dp{world}" if world > 1 else "single"),
         "final_loss": last_loss,
     }
     roof = None
-    rho = 1.0
+    rho, round_rows = 1.0, None
     if "fields" in w["desc"]:
         from recsys_amd import synthetic
-        rho = unique_fraction(w["batches"], w.get("dims") or synthetic.criteo_field_dims())
+        rho, round_rows = unique_fraction(w["batches"], w.get("dims") or synthetic.criteo_field_dims(), want_round=True)
     if dominant in ops_ms:
         ms, cnt = ops_ms[dominant]
         ab = algo_bytes(w["desc"], dominant, rho)
@@ -529,7 +576,11 @@ def main():
         bps = embedding_bytes_per_sample(w["desc"], rho)
         out["embedding_hbm"] = {"algorithmic_bytes_per_sample": bps, "achieved": bps * value / world / 1e9, "unit": "GB/s per GPU",
                                 "peak": HBM_PEAK_GBS, "frac": bps * value / world / 1e9 / HBM_PEAK_GBS,
-                                "note": "whole step (fwd + bwd + update), all kernels, at the measured distinct-row fraction"}
+                                "note": "whole step (fwd + bwd + update), all kernels, at the measured distinct-row fraction",
+                                "distinct_row_fraction": rho, "resident_batches": len(w["batches"]),
+                                "distinct_rows_per_round": round_rows,
+                                "table_bytes_touched_per_round": None if round_rows is None else round_rows * (4 * w["desc"]["dim"] + 4),
+                                "infinity_cache_bytes": 256 * 1024 * 1024}
     cap_slots = getattr(w["model"], "capacity", None)
     if world > 1 and cap_slots:
         # third bound of the sharded step: bytes a rank puts on its xGMI links per step (slot ids out,
@@ -568,8 +619,22 @@ def main():
             del w2
             torch.cuda.empty_cache()
 
+    if rank == 0 and world == 1 and args.workload == "fm_criteo" and os.environ.get("RX_BENCH_BATCHES") is None:
+        # the same workload cycling over 10 resident batches (the round-1 protocol): the rows a round
+        # touches then fit the 256 MiB Infinity Cache, so part of the table traffic never reaches HBM
+        os.environ["RX_BENCH_BATCHES"] = "10"
+        w10, el10, _, _ = run(args.workload, args.steps, args.warmup, None, use_graph, repeats=3)
+        del os.environ["RX_BENCH_BATCHES"]
+        r10, rows10 = unique_fraction(w10["batches"], w10["dims"], want_round=True)
+        b10 = embedding_bytes_per_sample(w10["desc"], r10)
+        out["embedding_hbm"]["with_10_resident_batches"] = {
+            "ms_per_step": 1e3 * el10 / args.steps, "frac": b10 * w10["B"] * args.steps / el10 / 1e9 / HBM_PEAK_GBS,
+            "table_bytes_touched_per_round": rows10 * (4 * w10["desc"]["dim"] + 4)}
+        del w10
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, out["config"], clip)
+        out["cpu_baseline_adam"] = cpu_baseline(args.workload, out["config"], clip, budget_s=12.0, optimizer="adam")
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -36,6 +36,10 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[short(k)] = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "traffic_bytes": round((2 * f + w) * 1024)}
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha: bench.py refuses a file taken on other kernel sources)
+out["_source_sha"] = bench.kernel_source_sha()
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+del out["_source_sha"]
 for k, v in out.items():
     print(f"{k[:70]:70s} fetch {v['fetch_kib'] / 1024:9.2f} MiB  write {v['write_kib'] / 1024:9.2f} MiB")

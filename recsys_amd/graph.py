@@ -14,11 +14,13 @@ instead of sitting on its critical path.  Every replay still performs exactly on
 replays must then follow the cyclic slot order 0, 1, ..., K-1, 0, ... (``copy_batch`` of slot i+1 has
 to happen before slot i is replayed).
 
-``cycle=True`` additionally records ONE graph holding a whole round over the resident batches
-(slots 0..K-1 in order).  Replaying it (``run_cycle``) removes the host's launch gap between steps,
-and the index preparation runs ahead freely on its side stream: step i only waits for the
-preparation of slot i, and the preparation of slot 0 for the next round waits for this round's
-step 0.  A round must start when slot 0 is next in the cyclic order.
+``cycle=True`` additionally records graphs that hold SEVERAL consecutive steps: one graph for the
+whole round over the resident batches (slots 0..K-1 in order), or, with ``cycle_len`` < K, one graph
+per segment of ``cycle_len`` consecutive slots (the last segment may be shorter).  Replaying one
+(``run_cycle``) removes the host's launch gap between steps, and the index preparation runs ahead on
+its side stream: step i only waits for the preparation of slot i; the preparation of a slot that the
+same graph has already consumed (a whole-round graph preparing slot 0 again) waits for that step.
+A segment must be replayed when its first slot is next in the cyclic order.
 
 Limits: the batch tensors are captured by address, so a graph is tied to its batch object
 (``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place);
@@ -35,7 +37,8 @@ from .autograd import backward_from_loss, clear_sort_cache
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False):
+    def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False,
+                 cycle_len: int = 0):
         if getattr(optimizer, "dense_kind", None) == "adam" and optimizer.dense:
             raise ValueError("dense Adam keeps its step count on the host and cannot be captured")
         self.model, self.opt, self.warmup = model, optimizer, warmup
@@ -45,8 +48,10 @@ class GraphedTrainStep:
         self._pool = None
         self.pipeline = pipeline
         self.cycle = cycle
-        self.cycle_graph = None
+        self.cycle_len = cycle_len
+        self.cycle_graph = None                       # the graph of the segment that starts at slot 0
         self.cycle_losses: List[torch.Tensor] = []
+        self.segments: Dict[int, tuple] = {}          # first slot -> (graph, number of steps, losses)
 
     def _eager(self, batch):
         self.opt.zero_grad()
@@ -97,38 +102,50 @@ class GraphedTrainStep:
 
     def _record_cycle(self, prepared, dev) -> None:
         K = len(prepared)
-        g = torch.cuda.CUDAGraph()
-        self.opt.zero_grad()
-        clear_sort_cache()
-        with torch.cuda.graph(g, pool=self._pool):
-            main = torch.cuda.current_stream(dev)
-            fork = torch.cuda.Stream(device=dev)
-            fork.wait_stream(main)
-            ready = None          # preparation of the slot the next step consumes
-            step0_done = None
-            for i, b in enumerate(prepared):
-                if ready is not None:
-                    main.wait_event(ready)
-                nxt = (i + 1) % K
-                with torch.cuda.stream(fork):
-                    if nxt == 0:
-                        fork.wait_event(step0_done)   # slot 0's sort result was read by this round's step 0
-                    self.model.prepare(prepared[nxt], out=prepared[nxt])
-                    ready = torch.cuda.Event()
-                    ready.record(fork)
-                self.cycle_losses.append(self._eager(b))
-                if i == 0:
-                    step0_done = torch.cuda.Event()
-                    step0_done.record(main)
-            main.wait_stream(fork)
-        self.cycle_graph = g
+        seg = self.cycle_len if 0 < self.cycle_len < K else K
+        for first in range(0, K, seg):
+            slots = list(range(first, min(first + seg, K)))
+            g = torch.cuda.CUDAGraph()
+            losses: List[torch.Tensor] = []
+            self.opt.zero_grad()
+            clear_sort_cache()
+            with torch.cuda.graph(g, pool=self._pool):
+                main = torch.cuda.current_stream(dev)
+                fork = torch.cuda.Stream(device=dev)
+                fork.wait_stream(main)
+                ready = None          # preparation of the slot the next step consumes
+                done = {}             # slot -> event recorded after this graph's step on it
+                for i in slots:
+                    if ready is not None:
+                        main.wait_event(ready)
+                    nxt = (i + 1) % K
+                    with torch.cuda.stream(fork):
+                        if nxt in done:
+                            fork.wait_event(done[nxt])   # its sort result was read by a step of this graph
+                        self.model.prepare(prepared[nxt], out=prepared[nxt])
+                        ready = torch.cuda.Event()
+                        ready.record(fork)
+                    losses.append(self._eager(prepared[i]))
+                    done[i] = torch.cuda.Event()
+                    done[i].record(main)
+                main.wait_stream(fork)
+            self.segments[first] = (g, len(slots), losses)
+        self.cycle_graph = self.segments[0][0]
+        self.cycle_losses = self.segments[0][2]
 
-    def run_cycle(self) -> List[torch.Tensor]:
-        """One step on every resident batch, slots 0..K-1 in order, as a single graph launch."""
-        if self.cycle_graph is None:
-            raise RuntimeError("no cycle graph: construct with pipeline=True, cycle=True and >= 2 batches")
-        self.cycle_graph.replay()
-        return self.cycle_losses
+    def segment_at(self, slot: int) -> int:
+        """Number of steps of the multi-step graph that starts at ``slot`` (0: none starts there)."""
+        entry = self.segments.get(slot)
+        return entry[1] if entry else 0
+
+    def run_cycle(self, first: int = 0) -> List[torch.Tensor]:
+        """The steps of the segment that starts at slot ``first`` (the whole round when there is one
+        segment), in slot order, as a single graph launch."""
+        entry = self.segments.get(first)
+        if entry is None:
+            raise RuntimeError("no multi-step graph starts at this slot: construct with pipeline=True, cycle=True and >= 2 batches")
+        entry[0].replay()
+        return entry[2]
 
     def add_batch(self, batch: Dict[str, torch.Tensor]) -> int:
         """Record one graph bound to ``batch``'s tensors.  Before the first recording the step is
