@@ -385,6 +385,13 @@ int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_row
 int rx_dense_adam(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, const float* d_scale,
                   int device, void* stream);
+/* The same step with the step count t read from device memory (d_step[0] >= 1; the caller advances
+ * it on the stream before the call), so that a HIP graph recorded around the step does not freeze
+ * t: torch.optim.Adam's ``capturable`` form of the step the pipelines build at
+ * recsys/pipelines/neuralcf/neumf.py:10.  A counter below 1 leaves the weights untouched. */
+int rx_dense_adam_dstep(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr,
+                        float beta1, float beta2, float eps, const int32_t* d_step,
+                        const float* d_scale, int device, void* stream);
 int rx_dense_sgd(float* d_w, const float* d_g, int64_t n, float lr, const float* d_scale,
                  int device, void* stream);
 int rx_dense_adagrad(float* d_w, const float* d_g, float* d_state, int64_t n, float lr, float eps,

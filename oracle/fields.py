@@ -52,17 +52,44 @@ def field_deepfm_logits(P, inputs, field_dims, train=False, dropout=0.0, buffers
     return bias + fm + _bn_tower(P, "deep_mlp", x, train, buffers_out, dropout)
 
 
-def dcnv2_logits(P, inputs, field_dims, **_):
+def _r16(t):
+    """Round to bfloat16 (nearest even) and widen back: the value a matrix-core operand carries."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBf16Operands(torch.autograd.Function):
+    """y = r(x) r(w)^T + b with r = round-to-bf16 and fp32 accumulation; the backward GEMMs round
+    their operands the same way (dx = r(dy) r(w), dw = r(dy)^T r(x)), the bias gradient sums the
+    unrounded dy.  This is the arithmetic of a bf16-operand tower with fp32 master weights, not the
+    straight-through gradient autograd would derive from the rounding."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return F.linear(_r16(x), _r16(w), b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = _r16(dy)
+        return d @ _r16(w), d.t() @ _r16(x), dy.sum(0)
+
+
+def _linear(x, w, b, bf16):
+    return _LinearBf16Operands.apply(x, w, b) if bf16 else F.linear(x, w, b)
+
+
+def dcnv2_logits(P, inputs, field_dims, bf16=False, **_):
     e, _ = _rows(P, "feature_embedding.weight", inputs["sparse"], field_dims)
     x0 = _tower_input(e, inputs.get("dense"), P["cross.0.weight"].shape[1])
     x = x0
     l = 0
     while f"cross.{l}.weight" in P:
-        x = x0 * F.linear(x, P[f"cross.{l}.weight"], P[f"cross.{l}.bias"]) + x
+        x = x0 * _linear(x, P[f"cross.{l}.weight"], P[f"cross.{l}.bias"], bf16) + x
         l += 1
     i = 0
     while f"mlp.{i}.weight" in P:
-        x = F.linear(x, P[f"mlp.{i}.weight"], P[f"mlp.{i}.bias"])
+        x = _linear(x, P[f"mlp.{i}.weight"], P[f"mlp.{i}.bias"], bf16)
         if f"mlp.{i + 2}.weight" in P:
             x = F.relu(x)
         i += 2
@@ -74,8 +101,9 @@ class FieldOracle:
 
     FN = {"FieldFM": field_fm_logits, "FieldDeepFM": field_deepfm_logits, "DCNv2": dcnv2_logits}
 
-    def __init__(self, name, state, field_dims, dropout=0.0):
+    def __init__(self, name, state, field_dims, dropout=0.0, bf16=False):
         self.fn, self.field_dims, self.dropout, self.training = self.FN[name], list(field_dims), dropout, True
+        self.bf16 = bf16          # DCNv2 only: GEMM operands rounded to bfloat16
         self.params, self.buffers = {}, {}
         for k, v in state.items():
             t = torch.as_tensor(v).detach().clone()
@@ -102,7 +130,7 @@ class FieldOracle:
     def __call__(self, inputs):
         new_buf = {}
         out = self.fn({**self.params, **self.buffers}, inputs, self.field_dims, train=self.training,
-                      dropout=self.dropout, buffers_out=new_buf)
+                      dropout=self.dropout, buffers_out=new_buf, bf16=self.bf16)
         for k, v in new_buf.items():
             self.buffers[k] = v.detach()
         return out

@@ -669,9 +669,6 @@ __device__ __forceinline__ void fg_block_sq_store(float sq, float* sq_part, floa
 // meta[window] describes the run that enters from the left: the number of leading positions it
 // holds in this window, bit 31 set when it goes on past the window's end.
 #define FG_META_GOES_ON 0x80000000u
-#ifndef FG_ABLATE
-#define FG_ABLATE 0
-#endif
 template <int GROUP, int S, int MODE, bool DEEP>
 __global__ void __launch_bounds__(RX_BLOCK)
 fg_reduce_kernel(FgRed a) {
@@ -717,7 +714,7 @@ fg_reduce_kernel(FgRed a) {
       endf[s] = rw[s + 1] != FG_NONE && rw[s + 2] != rw[s + 1] && (int64_t)rw[s + 1] < a.n_rows;
       e[s] = make_float4(0.f, 0.f, 0.f, 0.f);
       old2[s] = 0.f;
-      if (endf[s] && !(FG_ABLATE & 2)) {
+      if (endf[s]) {
         e[s] = *reinterpret_cast<const float4*>(tab + (int64_t)rw[s + 1] * DIM + lg * 4);
         if (MODE == RX_SEG_SGD && has2 && lg == 0) old2[s] = a.target2[rw[s + 1]];
       }
@@ -725,8 +722,8 @@ fg_reduce_kernel(FgRed a) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const bool valid = rw[s + 1] != FG_NONE;
-      const float gb = (FG_ABLATE & 1) ? 1.f : a.g[(int64_t)bb[s] * a.ldg];
-      const float4 t = (FG_ABLATE & 1) ? make_float4(1.f, 2.f, 3.f, (float)bb[s]) : *reinterpret_cast<const float4*>(a.T + (int64_t)bb[s] * a.ldT + lg * 4);
+      const float gb = a.g[(int64_t)bb[s] * a.ldg];
+      const float4 t = *reinterpret_cast<const float4*>(a.T + (int64_t)bb[s] * a.ldT + lg * 4);
       const float gv = valid ? gb : 0.f;
       const float mv = valid ? (a.premul ? 1.f : gb) : 0.f;   // times one is exact: premultiplied rows pass through
       v[s] = make_float4(mv * t.x, mv * t.y, mv * t.z, mv * t.w);
@@ -754,8 +751,6 @@ fg_reduce_kernel(FgRed a) {
       if (endf[s]) {
         if (cont_in && !seen_end) {  // needs what the groups before this one hold: kept for after the scan
           hsum = acc; h2 = acc2; he = e[s]; hold2 = old2[s]; hs = s; hrow = rw[s + 1];
-        } else if (FG_ABLATE & 4) {
-          sq += acc.x + acc2 + e[s].x;
         } else {
           sq += fg_finish<GROUP, MODE>(a, acc, acc2, e[s], old2[s], rw[s + 1], gbase + s, lg, scale);
         }

@@ -759,11 +759,20 @@ static inline unsigned dense_grid(int64_t n) {
   return (unsigned)(g < 2048 ? g : 2048);
 }
 
+// The step count t enters through the bias corrections 1 - beta^t only.  It comes either by value or
+// from device memory (a counter the caller advances on the stream, so that a recorded graph of the
+// step stays valid from one replay to the next); both forms run the same arithmetic in the kernel.
 __global__ void __launch_bounds__(RX_BLOCK)
 dense_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                  float* __restrict__ v, int64_t n, float beta1, float beta2, float eps,
-                  float step_size, float inv_sqrt_bc2, const float* __restrict__ scale) {
+                  float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  int32_t step, const int32_t* __restrict__ d_step, const float* __restrict__ scale) {
   const float sc = scale ? scale[0] : 1.f;
+  const int32_t t = d_step ? d_step[0] : step;
+  if (t < 1) return;                                   // a counter that was never advanced: leave the weights alone
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * sc;
     const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
@@ -775,20 +784,31 @@ dense_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __r
   }
 }
 
+static int dense_adam_run(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, int32_t step, const int32_t* d_step, const float* d_scale,
+                          hipStream_t st) {
+  if (n == 0) return 0;
+  RX_REQUIRE(d_w && d_g && d_m && d_v, "rx_dense_adam: null argument");
+  hipLaunchKernelGGL(dense_adam_kernel, dim3(dense_grid(n)), dim3(RX_BLOCK), 0, st, d_w, d_g, d_m, d_v, n, lr, beta1,
+                     beta2, eps, step, d_step, d_scale);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rx_dense_adam(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr,
                              float beta1, float beta2, float eps, int32_t step, const float* d_scale,
                              int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && step >= 1, "rx_dense_adam: bad n or step");
-  if (n == 0) return 0;
-  RX_REQUIRE(d_w && d_g && d_m && d_v, "rx_dense_adam: null argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  hipLaunchKernelGGL(dense_adam_kernel, dim3(dense_grid(n)), dim3(RX_BLOCK), 0, (hipStream_t)stream, d_w, d_g, d_m, d_v, n, beta1, beta2, eps, step_size, inv_sqrt_bc2, d_scale);
-  RX_LAUNCH_CHECK();
-  return 0;
+  return dense_adam_run(d_w, d_g, d_m, d_v, n, lr, beta1, beta2, eps, step, nullptr, d_scale, (hipStream_t)stream);
+}
+
+extern "C" int rx_dense_adam_dstep(float* d_w, const float* d_g, float* d_m, float* d_v, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, const int32_t* d_step,
+                                   const float* d_scale, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0 && d_step, "rx_dense_adam_dstep: bad n or null step counter");
+  return dense_adam_run(d_w, d_g, d_m, d_v, n, lr, beta1, beta2, eps, 0, d_step, d_scale, (hipStream_t)stream);
 }
 
 __global__ void __launch_bounds__(RX_BLOCK)

@@ -23,8 +23,8 @@ same graph has already consumed (a whole-round graph preparing slot 0 again) wai
 A segment must be replayed when its first slot is next in the cyclic order.
 
 Limits: the batch tensors are captured by address, so a graph is tied to its batch object
-(``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place);
-``dense_kind="adam"`` bakes the step count into the recording and is refused.
+(``add_batch`` records one graph per resident batch; ``copy_batch`` refreshes a batch in place).
+Dense Adam keeps its step count in device memory and advances it inside the recording.
 """
 from __future__ import annotations
 
@@ -39,8 +39,6 @@ from .autograd import backward_from_loss, clear_sort_cache
 class GraphedTrainStep:
     def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False,
                  cycle_len: int = 0):
-        if getattr(optimizer, "dense_kind", None) == "adam" and optimizer.dense:
-            raise ValueError("dense Adam keeps its step count on the host and cannot be captured")
         self.model, self.opt, self.warmup = model, optimizer, warmup
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.batches: List[Dict[str, torch.Tensor]] = []

@@ -709,6 +709,13 @@ def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, st
 
 # ------------------------------------------------------------------ dense optimizers / reductions
 def dense_adam(w, g, m, v, lr, beta1, beta2, eps, step, scale=None):
+    """``step``: the step count t >= 1 as an int, or an int32 device tensor holding it (the form a
+    recorded graph needs: the counter is advanced on the stream, the recording reads it)."""
+    if isinstance(step, Tensor):
+        _req(step, torch.int32, "step")
+        check(lib.rx_dense_adam_dstep(_p(w), _p(g), _p(m), _p(v), w.numel(), lr, beta1, beta2, eps, _p(step),
+                                      _p(scale), _dev(w), _stream(w)), "rx_dense_adam_dstep")
+        return
     check(lib.rx_dense_adam(_p(w), _p(g), _p(m), _p(v), w.numel(), lr, beta1, beta2, eps, step, _p(scale),
                             _dev(w), _stream(w)), "rx_dense_adam")
 

@@ -124,6 +124,7 @@ class FusedOptimizer:
         self._sq_used = 0
         self._dense_state = {}
         self._step = 0
+        self._step_dev = None
         self.last_total_norm: Optional[torch.Tensor] = None
 
     def detach(self):
@@ -171,7 +172,8 @@ class FusedOptimizer:
             st = self._dense_state.get(id(p))
             if st is None:
                 st = self._dense_state[id(p)] = (torch.zeros_like(w), torch.zeros_like(w))
-            ops.dense_adam(w, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.adam_eps, self._step, scale)
+            ops.dense_adam(w, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.adam_eps,
+                           self._step_dev if self._step_dev is not None else self._step, scale)
 
     def _dense_step_all(self, scale):
         """All dense parameters: SGD / Adagrad in launches of up to 24 tensors; Adam per tensor."""
@@ -198,6 +200,12 @@ class FusedOptimizer:
 
     def step(self):
         self._step += 1
+        if self.dense_kind == "adam" and self.dense:
+            # the step count also lives on the device, advanced on the stream: a recorded graph of this
+            # step then reads the count of the replay, not the one of the recording
+            if self._step_dev is None:
+                self._step_dev = torch.full((1,), self._step - 1, dtype=torch.int32, device=self.dense[0].device)
+            self._step_dev.add_(1)
         scale = None
         if self.clip_norm is not None:
             # Global norm.  Dense gradients: one launch leaves fp64 partials for up to 24 tensors;

@@ -43,10 +43,46 @@ def test_forward_loss_grads(name, kw, rtol):
     params = dict(m.named_parameters())
     for k, p in oracle.params.items():
         assert_close(params[k].grad.cpu().numpy(), p.grad.numpy(), rtol=rtol * (10 if rtol > 1e-5 else 1),
-                     what=f"grad {k}", atol=1e-7)
+                     what=f"grad {k}", atol=1e-7, elem_rtol=None if rtol <= 1e-5 else False)
     oracle.eval(); m.eval()
     with torch.no_grad():
         assert_close(m(dbatch).cpu().numpy(), oracle(batch).numpy(), rtol=rtol, what="eval logits")
+
+
+def test_dcnv2_benchmark_shape_bf16_operands():
+    """DCN-v2 at the benchmark's architecture -- 26 fields, D = 16, 13 dense features, 3 cross layers,
+    MLP 1024-512-256, bf16 GEMM operands with fp32 accumulation -- at batch 4096: logits, loss and
+    every gradient within 1e-2 of the CPU oracle.  The oracle rounds the operands of every GEMM
+    (forward and both backward products) to bfloat16 exactly as the matrix-core path does and
+    accumulates in fp32, so the comparison measures accumulation order and the occasional operand
+    that rounds the other way, not the bf16 format itself; against the fp32 oracle the same
+    logits differ by up to a few 1e-3 of their range."""
+    from oracle.fields import FieldOracle
+    from recsys_amd import synthetic
+    from recsys_amd.models import fields
+    dims = synthetic.criteo_field_dims(total_rows=2_000_000)
+    assert len(dims) == 26
+    B = 4096
+    torch.manual_seed(9)
+    m = fields.DCNv2(dims, 16, n_dense=13, n_cross=3, mlp_dims=(1024, 512, 256), bf16=True)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    oracle = FieldOracle("DCNv2", state, dims, bf16=True)
+    plain = FieldOracle("DCNv2", state, dims, bf16=False)
+    batch = synthetic.criteo_batch(dims, B, seed=4, device="cpu")
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    m = m.cuda()
+    oracle.train(); m.train()
+    lo, lm = oracle.loss(batch), m.loss(dbatch)
+    assert_close(lm.item(), lo.item(), rtol=1e-2, what="loss")
+    lo.backward(); lm.backward()
+    params = dict(m.named_parameters())
+    for k, p in oracle.params.items():
+        assert_close(params[k].grad.cpu().numpy(), p.grad.numpy(), rtol=1e-2, what=f"grad {k}", elem_rtol=0.5)
+    oracle.eval(); m.eval(); plain.eval()
+    with torch.no_grad():
+        got = m(dbatch).cpu().numpy()
+        assert_close(got, oracle(batch).numpy(), rtol=1e-2, what="eval logits")
+        assert_close(got, plain(batch).numpy(), rtol=1e-2, what="eval logits vs the fp32 oracle", elem_rtol=False)
 
 
 @pytest.mark.parametrize("name", ["FieldFM", "FieldDeepFM"])
@@ -114,8 +150,11 @@ def test_strided_sparse_matrix_is_used_in_place():
     assert torch.equal(flat, exp)
 
 
-def test_graphed_step_matches_eager_bitwise():
-    """One hipGraphLaunch per step gives the same weights, bit for bit, as launching each kernel."""
+@pytest.mark.parametrize("dense_kind", [None, "adam"])
+def test_graphed_step_matches_eager_bitwise(dense_kind):
+    """One hipGraphLaunch per step gives the same weights, bit for bit, as launching each kernel.
+    With a dense Adam tower the step count is read from device memory inside the recording, so the
+    replays take steps 3, 4, 5 and not three times the step that was recorded."""
     from recsys_amd import ops
     from recsys_amd.graph import GraphedTrainStep
     from recsys_amd.optim import FusedOptimizer
@@ -123,7 +162,7 @@ def test_graphed_step_matches_eager_bitwise():
     for graphed in (False, True):
         _, m, batch = _pair("FieldDeepFM", B=512)
         dbatch = {k: v.cuda() for k, v in batch.items()}
-        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0, dense_kind=dense_kind)
         ops.set_index_check("deferred")
         try:
             if graphed:

@@ -193,3 +193,71 @@ def test_train_step_is_bitwise_reproducible():
         outs.append([p.grad.clone() for p in m.parameters()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ dense Adam (rx_dense_adam / rx_dense_adam_dstep)
+@pytest.mark.parametrize("fixture", ["NeuMF_d16", "DeepFactorizationMachine_d16", "VanillaMF_d64"])
+def test_dense_adam_kernel_reproduces_reference_first_step(fixture):
+    """The reference's train step with torch.optim.Adam(lr=1e-3) after clip_grad_norm_(1.0)
+    (recsys/utils.py:96-103, recsys/pipelines/neuralcf/neumf.py:10): the golden capture holds every
+    parameter before the step, its gradient, the clip norm and the parameter after step 1, so the
+    kernel is fed exactly those and must land on the captured weights."""
+    from recsys_amd import ops
+    rec = load_golden(fixture)
+    state, grads, after = group(rec, "state"), group(rec, "grad"), group(rec, "adam1")
+    gmax = max(float(np.abs(g).max()) for g in grads.values())
+    scale = torch.tensor([min(1.0, 1.0 / (float(rec["clip_total_norm"]) + 1e-6))], dtype=torch.float32, device="cuda")
+    step_dev = torch.ones(1, dtype=torch.int32, device="cuda")
+    for k, g in grads.items():
+        for step in (1, step_dev):
+            w = torch.from_numpy(state[k]).cuda().contiguous()
+            m, v = torch.zeros_like(w), torch.zeros_like(w)
+            ops.dense_adam(w, torch.from_numpy(g).cuda().contiguous(), m, v, 1e-3, 0.9, 0.999, 1e-8, step, scale)
+            a, e = adagrad_well_conditioned(w.cpu().numpy(), after[k], g, gmax)
+            assert_close(a, e, rtol=1e-5, what=f"adam1 {k}")
+
+
+def test_dense_adam_steps_track_torch_and_the_device_counter_matches_the_host_one():
+    from recsys_amd import ops
+    torch.manual_seed(4)
+    w0 = torch.randn(100_003, device="cuda")
+    gs = [torch.randn_like(w0) * (0.5 + s) for s in range(4)]
+    ref = w0.clone().requires_grad_(True)
+    o = torch.optim.Adam([ref], lr=1e-2, betas=(0.8, 0.99), eps=1e-7)
+    wh, mh, vh = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
+    wd, md, vd = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.dense_adam(wd, gs[0], md, vd, 1e-2, 0.8, 0.99, 1e-7, counter)          # counter 0: no step taken
+    assert torch.equal(wd, w0) and not md.any() and not vd.any()
+    for s, g in enumerate(gs, 1):
+        ref.grad = g.clone()
+        o.step()
+        ops.dense_adam(wh, g, mh, vh, 1e-2, 0.8, 0.99, 1e-7, s)
+        counter.add_(1)
+        ops.dense_adam(wd, g, md, vd, 1e-2, 0.8, 0.99, 1e-7, counter)
+        assert torch.equal(wh, wd) and torch.equal(mh, md) and torch.equal(vh, vd)
+        assert_close(wh.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, what=f"adam step {s}")
+
+
+def test_fused_optimizer_with_dense_adam_reproduces_reference_first_step():
+    """FusedOptimizer(dense_kind="adam"): tables by fused sparse SGD, tower by rx_dense_adam with the
+    global clip factor over all gradients -- the tower weights after step 1 are the golden capture's."""
+    from recsys_amd.optim import FusedOptimizer
+    rec = load_golden("NeuMF_d16")
+    batch = to_torch(group(rec, "batch"), "cuda")
+    m = _build(rec, "NeuMF").train()
+    o = FusedOptimizer(m, kind="sgd", lr=1e-3, clip_norm=1.0, dense_kind="adam")
+    o.zero_grad(); m.loss(batch).backward(); o.step()
+    assert_close(o.last_total_norm.item(), rec["clip_total_norm"], what="clip norm")
+    grads, after = group(rec, "grad"), group(rec, "adam1")
+    gmax = max(float(np.abs(g).max()) for g in grads.values())
+    sparse = {id(p) for p in m.sparse_parameters()}
+    sd = m.state_dict()
+    checked = 0
+    for k, p in m.named_parameters():
+        if id(p) in sparse:
+            continue
+        a, e = adagrad_well_conditioned(sd[k].cpu().numpy(), after[k], grads[k], gmax)
+        assert_close(a, e, rtol=1e-5, what=f"adam1 {k}")
+        checked += 1
+    assert checked >= 6

@@ -402,12 +402,12 @@ def test_linear_bf16_within_1e2(ops, M, N, K):
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
     y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), 0, bf16=True).cpu()
     exp = torch.nn.functional.linear(x.double(), w.double(), b.double())
-    assert_close(y.numpy(), exp.numpy(), rtol=1e-2, what="bf16 linear fwd")
+    assert_close(y.numpy(), exp.numpy(), rtol=1e-2, what="bf16 linear fwd", elem_rtol=False)
     dy = torch.randn(M, N, generator=g)
     dx = ops.linear_bwd_x(dy.cuda(), w.cuda(), bf16=True).cpu()
-    assert_close(dx.numpy(), (dy.double() @ w.double()).numpy(), rtol=1e-2, what="bf16 bwd x")
+    assert_close(dx.numpy(), (dy.double() @ w.double()).numpy(), rtol=1e-2, what="bf16 bwd x", elem_rtol=False)
     dw, db = ops.linear_bwd_w(dy.cuda(), x.cuda(), bf16=True)
-    assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=1e-2, what="bf16 bwd w")
+    assert_close(dw.cpu().numpy(), (dy.double().T @ x.double()).numpy(), rtol=1e-2, what="bf16 bwd w", elem_rtol=False)
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 200, 136), (260, 132, 40), (4096, 1024, 432), (8192, 96, 72), (128, 128, 32),

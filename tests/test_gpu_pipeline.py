@@ -479,3 +479,93 @@ def test_topk_wider_than_the_kernel_limit_follows_the_reference_order():
     assert np.array_equal(topk(scores.cuda(), k=10).cpu().numpy(), order)
     distinct = torch.stack([torch.randperm(3706, generator=g) for _ in range(5)]).float()
     assert np.array_equal(topk(distinct.cuda(), k=10).cpu().numpy(), topk(distinct.numpy(), k=10))
+
+
+# ------------------------------------------------------------------ the reference's captures through the device branches
+def _golden_loader_data(rec):
+    import scipy.sparse as scs
+    shape = tuple(int(x) for x in rec["shape"])
+    r, c = rec["implicit_rows"], rec["implicit_cols"]
+    return {
+        "implicit_matrix": scs.csr_matrix((np.ones(len(r)), (r, c)), shape=shape),
+        "timestamp_matrix": scs.csr_matrix((rec["timestamp_vals"].astype(np.float64), (r, c)), shape=shape),
+        "test_codes": rec["test_codes"], "test_true": rec["test_codes"][:, :1],
+        "test_timestamp_rank": rec["test_timestamp_rank"], "negative_samples": rec["negative_samples"],
+        "user_infos": rec["user_infos"],
+    }
+
+
+def test_golden_ranking_and_metrics_through_the_device_branches():
+    """The captured scores / codes / predictions / NDCG / HR of the reference's eval path
+    (recsys/utils.py:40-75, recsys/metrics.py:4-38) fed as GPU tensors: rx_topk_codes and the
+    torch-on-device metric code must give the captured values (ranks exactly, metrics to 1e-12)."""
+    from conftest import load_golden
+    from recsys_amd.metrics import hr_score, ndcg_score
+    from recsys_amd.utils import topk
+    rec = load_golden("eval")
+    scores = torch.from_numpy(rec["scores"]).cuda()
+    codes = torch.from_numpy(rec["codes"]).cuda()
+    k = int(rec["k"])
+    pred = topk(scores, array=codes, k=k)
+    assert pred.is_cuda and np.array_equal(pred.cpu().numpy(), rec["pred"])
+    assert np.array_equal(topk(scores, array=rec["codes"], k=k).cpu().numpy(), rec["pred"])   # host codes, device scores
+    assert np.array_equal(topk(scores, subset=torch.from_numpy(rec["subset"]).cuda(), k=5).cpu().numpy(), rec["pred_subset_k5"])
+    assert np.array_equal(topk(scores, k=3).cpu().numpy(), rec["pred_plain_k3"])
+    true = torch.from_numpy(rec["true"]).cuda()
+    assert abs(ndcg_score(true, pred) - float(rec["ndcg"])) < 1e-12
+    assert abs(hr_score(true, pred) - float(rec["hr"])) < 1e-12
+    assert abs(ndcg_score(rec["true"], pred) - float(rec["ndcg"])) < 1e-12                     # host truth, device predictions
+    assert abs(hr_score(rec["true"], pred) - float(rec["hr"])) < 1e-12
+
+
+def test_golden_batches_from_the_device_resident_loader():
+    """ImplicitData on the GPU with the reference's numpy sampler under the captured seed: the one
+    train batch (as a set of rows: the epoch permutation is torch's) and the first test batch hold
+    exactly the captured tensors, dtypes included (recsys/dataset.py:165-187,228-282)."""
+    from conftest import group, load_golden
+    from recsys_amd.dataset import ImplicitData
+    rec = load_golden("loader")
+    n = len(rec["implicit_rows"])
+    idata = ImplicitData(_golden_loader_data(rec), device="cuda", train_batch_size=n, test_batch_size=4, sampler="numpy")
+    np.random.seed(int(rec["seed"]))
+    (batch,) = list(idata.create_negative_sampled_train_dataloader())
+    assert all(v.is_cuda for v in batch.values())
+    host = {k: v.cpu().numpy() for k, v in batch.items()}
+    order = np.lexsort((host["item_code"][:, 0], host["user_code"]))
+    exp = group(rec, "train_batch")
+    assert set(host) == set(exp)
+    for k, v in exp.items():
+        assert str(batch[k].dtype) == str(rec[f"train_dtype/{k}"]), k
+        assert np.array_equal(host[k][order], v), k
+    tdl = idata.create_test_dataloader()
+    assert len(tdl) == int(rec["n_test_batches"])
+    first = next(iter(tdl))
+    exp = group(rec, "test_batch0")
+    assert set(first) == set(exp) and "label" not in first
+    for k, v in exp.items():
+        assert first[k].is_cuda and str(first[k].dtype) == str(rec[f"test_dtype/{k}"]), k
+        assert np.array_equal(first[k].cpu().numpy(), v), k
+
+
+def test_golden_sampler_rows_feed_a_model_step_on_the_device():
+    """The captured output of the reference sampler (seeded numpy, recsys/dataset.py:165-187) as a
+    device batch through a drop-in model: every row is [u, positive, 4 negatives from u's pool] and
+    the loss over it equals the CPU oracle's."""
+    from conftest import load_golden
+    from oracle.models import OracleModel, init_state
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    rec = load_golden("sampler")
+    data, labels = rec["train_data"], rec["train_labels"]
+    n_users, n_items = (int(x) for x in rec["shape"])
+    pools = rec["negative_samples"]
+    for row in data:
+        assert set(row[2:].tolist()) <= set(pools[row[0]].tolist())
+    batch = {"user_code": torch.from_numpy(data[:, 0].copy()), "item_code": torch.from_numpy(data[:, 1:].copy()),
+             "label": torch.from_numpy(labels)}
+    state = init_state("VanillaMF", n_users=n_users, n_items=n_items, embedding_dim=16, seed=2)
+    oracle = OracleModel("VanillaMF", state, n_users=n_users, n_items=n_items)
+    m = VanillaMF(n_users, n_items, 16)
+    m.load_state_dict(state)
+    m = m.cuda()
+    loss = m.loss({k: v.cuda() for k, v in batch.items()})
+    assert_close(loss.item(), oracle.loss(batch).item(), rtol=1e-6, what="loss on the sampler capture")
