@@ -58,6 +58,21 @@ timed("fm2_fwd", lambda i: ops.fm2_fwd(table, bias, batches[i % 4][:, :nf - 1], 
 labels = (torch.rand(B, 1, device=dev) < 0.25).double()
 timed("fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(table, bias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
 timed("bce", lambda i: ops.bce_with_logits(T[:, :1].contiguous(), labels))
+if os.environ.get("SORTED") == "1":
+    # the same ops on occurrence lists ordered by ascending row inside every field (any order that keeps a
+    # row's occurrences together is valid input): what the bin order costs in memory locality
+    import dataclasses
+    sfgs = []
+    for sp, fg in zip(batches, fgs):
+        rows, sbs = [], []
+        for f in range(nf):
+            r, order = torch.sort(sp[:, f], stable=True)
+            rows.append(r + base[f]); sbs.append(order)
+        srow = torch.cat(rows).to(torch.int32)
+        sfgs.append(dataclasses.replace(fg, srow=srow, sb=torch.cat(sbs).to(torch.int32)))
+    timed("sorted/fg_reduce", lambda i: ops.fg_reduce(T, g, sfgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=table, target2=comp2, want_sq=True, sq_out=sq))
+    timed("sorted/fg_row_update", lambda i: ops.fg_row_update(comp, sfgs[i % 4], _lib.RX_SEG_SGD, table, lr=0.05, scale=scale, compact2=comp2, table2=bias))
+    timed("sorted/fg_row_update/nobias", lambda i: ops.fg_row_update(comp, sfgs[i % 4], _lib.RX_SEG_SGD, table, lr=0.05, scale=scale))
 if os.environ.get("OLD") == "1":
     sis = [ops.fm_sort_dedup(table, sp[:, :nf - 1], ex_base, sp[:, nf - 1:], base[nf - 1]) for sp in batches]
     timed("fm_sort_dedup", lambda i: ops.fm_sort_dedup(table, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], out=sis[i % 4]))
