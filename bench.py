@@ -48,13 +48,18 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     # times over for the D = 16 tables (64 batches name about 1 GB of distinct rows), so that the
     # step's table traffic comes from HBM; RX_BENCH_BATCHES overrides (10 = the round-1 figure)
     n_batches = int(os.environ.get("RX_BENCH_BATCHES", 64 if name in ("fm_criteo",) else 10))
-    if name == "deepfm_criteo_sharded":
+    if name in ("deepfm_criteo_sharded", "deepfm_wide_d128_sharded"):
         # the Criteo-shaped DeepFM with its tables row-sharded and its BatchNorm tower data parallel
-        # (tower gradients summed over the ranks by one all-reduce); 33 M rows x 16 per GPU
+        # (tower gradients summed over the ranks by one all-reduce); 33 M rows x 16 per GPU.
+        # deepfm_wide_d128_sharded: the 1 B-row x 128 configuration as named -- 125 M rows x 128 per
+        # GPU and the 3344-3344-1672-836-1 tower the reference's width rule gives (bf16 operands)
         from recsys_amd.sharded import ShardedFieldDeepFM
-        dims = synthetic.criteo_field_dims(total_rows=33_000_000 * world)
-        B, D, lr = 65536, 16, 0.05
-        model = ShardedFieldDeepFM(dims, D, device)
+        wide = name == "deepfm_wide_d128_sharded"
+        dims = synthetic.criteo_field_dims(total_rows=(int(os.environ.get("RX_BENCH_SHARDED_ROWS", 125_000_000)) if wide else 33_000_000) * world)
+        B, D, lr = 65536, 128 if wide else 16, 0.05
+        if wide:
+            n_batches = min(n_batches, 4)
+        model = ShardedFieldDeepFM(dims, D, device, bf16=wide)
         model.set_rule("sgd", lr, clip_norm=clip)
         model.train()
         if os.environ.get("RX_BENCH_FORCE_DIST") == "1":
@@ -306,7 +311,7 @@ def embedding_bytes_per_sample(desc, rho):
 def workload_dtype(name):
     """Arithmetic type of the path: embedding work is fp32 everywhere; the bf16 workloads round the
     tower / cross GEMM operands to bf16 (fp32 accumulation, fp32 master weights)."""
-    return "bf16" if name in ("dcnv2_criteo", "deepfm_criteo_bf16") else "f32"
+    return "bf16" if name in ("dcnv2_criteo", "deepfm_criteo_bf16", "deepfm_wide_d128_sharded") else "f32"
 
 
 def dense_flops_per_sample(name):
@@ -317,6 +322,8 @@ def dense_flops_per_sample(name):
         return 6.0 * (3 * 432 * 432 + mlp([432, 1024, 512, 256, 1]))
     if name in ("deepfm_criteo", "deepfm_criteo_bf16", "deepfm_criteo_sharded"):
         return 6.0 * mlp([432, 432, 216, 108, 1])
+    if name == "deepfm_wide_d128_sharded":
+        return 6.0 * mlp([3344, 3344, 1672, 836, 1])
     if name == "neumf_ml1m":  # per (user, item) pair: MLP 128-64-32, GMF 64-32, head 64-1; 5 pairs per sample
         return 6.0 * 5 * (mlp([128, 64, 32]) + 64 * 32 + 64)
     return None
@@ -464,7 +471,7 @@ def main():
         # the timed region starts on resident batch 0, where a whole-round graph may begin (any slot
         # can go first: all were prepared when they were registered)
         first = (-warmup) % len(w["batches"])
-        if name in ("fm_criteo_sharded", "deepfm_criteo_sharded", "fm_wide_d128") and warmup < 24:
+        if name in ("fm_criteo_sharded", "deepfm_criteo_sharded", "deepfm_wide_d128_sharded", "fm_wide_d128") and warmup < 24:
             # part of set-up, whatever --warmup says: the 64 GB tables and the exchange buffers are first
             # touched, and the allocator grows, over the first two dozen steps
             run_steps(w, 0, 24 - warmup)
@@ -521,13 +528,13 @@ def main():
     fg_on = os.environ.get("RX_NO_FIELD_GROUPS") != "1"   # the unsharded field models take the field-grouped backward
     dominant = {"fm_criteo": "fg_reduce" if fg_on else "segreduce_fm", "fm_wide_d128": "fg_reduce" if fg_on else "segreduce_fm",
                 "fm_criteo_sharded": "segreduce_fm",
-                "deepfm_criteo_sharded": "linear_bwd_w", "deepfm_criteo": "linear_bwd_w",
+                "deepfm_criteo_sharded": "linear_bwd_w", "deepfm_wide_d128_sharded": "linear_bwd_w", "deepfm_criteo": "linear_bwd_w",
                 "deepfm_criteo_bf16": "linear_bwd_w",
                 "dcnv2_criteo": "linear_bwd_w", "mf_ml1m": "mf_score_bwd", "neumf_ml1m": "linear_bwd_w"}[args.workload]
     use_graph = not args.no_graph
     if (world > 1 or force_dist) and args.workload == "fm_criteo":
         args.workload = "fm_criteo_sharded"
-    if args.workload in ("fm_criteo_sharded", "deepfm_criteo_sharded"):
+    if args.workload in ("fm_criteo_sharded", "deepfm_criteo_sharded", "deepfm_wide_d128_sharded"):
         use_graph = False
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph,
                                    repeats=args.repeats)

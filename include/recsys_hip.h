@@ -549,6 +549,21 @@ int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const i
 int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, int32_t n,
                   int32_t k, int64_t* d_out, int device, void* stream);
 
+/* ------------------------------------------------------------------ batching
+ * Negative sampling of one epoch, replacing the host numpy sequence of recsys/dataset.py:165-187
+ * (rows.repeat(n_neg); randint(0, pool); negative_samples[rows, draws]; hstack with the positives;
+ * labels [1, 0, ..., 0] in float64): for every positive p = (users[p], items[p]) the row
+ * out_items[p] = [items[p], pool[users[p], r_1], ..., pool[users[p], r_n_neg]] with r_j uniform on
+ * [0, pool_size), drawn with replacement, and out_labels[p] = [1, 0, ..., 0] (may be NULL).
+ * The draws are a pure function of (seed, p, j): r_j = (hi32(mix(seed, p * n_neg + j - 1)) *
+ * pool_size) >> 32 with mix(s, c) the splitmix64 finaliser of s + (c + 1) * 0x9E3779B97F4A7C15 --
+ * the same distribution as the reference's numpy draws, not the same stream.  pool is
+ * [n_users, pool_size] int64; a user id outside [0, n_users) sets RX_ERR_INDEX and yields code 0. */
+int rx_sample_negatives(const int64_t* d_users, const int64_t* d_items, const int64_t* d_pool,
+                        int64_t n, int64_t n_users, int32_t pool_size, int32_t n_neg, uint64_t seed,
+                        int64_t* d_out_items, double* d_out_labels, int32_t* err_flag, int device,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

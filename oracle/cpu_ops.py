@@ -256,3 +256,8 @@ def fm2_bwd(g, d_deep, feat, bias, ex_idx, ex_base, item_idx, item_base, second_
 def bce_loss(logits, labels):
     from .models import bce_with_logits
     return bce_with_logits(logits, labels)
+
+
+def run_tower(seq, x, bf16=False):
+    """The tower as plain torch modules (``bf16`` has no CPU counterpart here and is ignored)."""
+    return seq(x)

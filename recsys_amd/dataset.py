@@ -11,7 +11,9 @@ that already sit in HBM.
 
 ``sampler="numpy"`` draws the negatives with the reference's exact numpy calls
 (recsys/dataset.py:165-187), so a numpy seed reproduces its ``train_data`` bit for bit;
-``sampler="device"`` draws them with torch on the GPU (same distribution, no host work).
+``sampler="device"`` draws them on the GPU with one launch of rx_sample_negatives (same
+distribution, a counter-based stream of its own: epoch e of a loader seeded s is reproducible from
+(s, e)); on a CPU device the same rule runs in numpy.
 """
 from __future__ import annotations
 
@@ -65,7 +67,7 @@ class ImplicitData:
     test_timestamp_rank, negative_samples, user_infos)."""
 
     def __init__(self, data: dict, device="cpu", train_batch_size: int = 512, test_batch_size: int = 1024,
-                 sampler: str = "device"):
+                 sampler: str = "device", seed: int = 0):
         if sampler not in ("device", "numpy"):
             raise ValueError(sampler)
         self.implicit_matrix = data["implicit_matrix"]
@@ -91,6 +93,8 @@ class ImplicitData:
         self._ts = torch.from_numpy(ts).to(dev)
         self._pool = torch.from_numpy(np.ascontiguousarray(self.negative_samples).astype(np.int64)).to(dev)
         self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(seed)
+        self.seed, self._epoch = seed, 0
 
     def create_negative_sampled_train_dataloader(self, n_negatives: int = 4) -> EpochLoader:
         n = self._rows.shape[0]
@@ -99,11 +103,17 @@ class ImplicitData:
             items = torch.from_numpy(np.ascontiguousarray(data[:, 1:]).astype(np.int64)).to(self.device)
             label = torch.from_numpy(labels).to(self.device)
         else:
-            draws = torch.randint(0, self._pool.shape[1], (n, n_negatives), device=self.device, generator=self._gen)
-            negatives = self._pool[self._rows[:, None], draws]
-            items = torch.cat([self._cols[:, None], negatives], dim=1)
-            label = torch.zeros(n, n_negatives + 1, dtype=torch.float64, device=self.device)
-            label[:, 0] = 1
+            epoch_seed = (self.seed << 20) + self._epoch        # one stream per (loader seed, epoch)
+            self._epoch += 1
+            if self.device.type == "cuda":
+                from . import ops
+                items, label = ops.sample_negatives(self._rows, self._cols, self._pool, n_negatives, epoch_seed)
+            else:
+                from .ops import sample_negatives_host
+                items = torch.from_numpy(sample_negatives_host(self._rows.numpy(), self._cols.numpy(), self._pool.numpy(),
+                                                               n_negatives, epoch_seed))
+                label = torch.zeros(n, n_negatives + 1, dtype=torch.float64)
+                label[:, 0] = 1
         tensors = {"user_code": self._rows, "item_code": items, "user_occupation": self._occ,
                    "item_timestamp_rank": self._ts, "label": label}
         return EpochLoader(tensors, self.train_batch_size, shuffle=True, generator=self._gen)
@@ -168,6 +178,76 @@ def synthetic_ml1m_data(seed: int = 0, n_users: int = 6040, n_items: int = 3706,
             "user_infos": user_infos}
 
 
+def _read_dat(path, n_cols):
+    with open(path, encoding="ISO-8859-1") as f:
+        rows = [line.rstrip("\n").split("::") for line in f if line.strip()]
+    if any(len(r) != n_cols for r in rows):
+        raise ValueError(f"{path}: expected {n_cols} '::'-separated columns per line")
+    return [list(c) for c in zip(*rows)] if rows else [[] for _ in range(n_cols)]
+
+
+def _string_codes(values):
+    """Codes of a pandas ``category`` column read from text: the rank of each value among the
+    distinct values **as strings** ("10" sorts before "9"), in the smallest signed integer type."""
+    cats, codes = np.unique(np.asarray(values, dtype=str), return_inverse=True)
+    dtype = np.int8 if len(cats) <= 127 else np.int16 if len(cats) <= 32767 else np.int32
+    return codes.astype(dtype)
+
+
+def _rank_first_within(group, key, descending=False):
+    """pandas ``groupby(group)[key].rank(method="first") - 1``: position of every element inside its
+    group ordered by key, ties in order of appearance (for descending too)."""
+    n = len(group)
+    order = np.lexsort((np.arange(n), -key if descending else key, group))
+    g = group[order]
+    start = np.flatnonzero(np.r_[True, g[1:] != g[:-1]])
+    first = np.repeat(start, np.diff(np.r_[start, n]))
+    rank = np.empty(n, dtype=np.float64)
+    rank[order] = np.arange(n) - first
+    return rank
+
+
+def split_data_loo(ratings_path, users_path, n_test_codes: int = 100, out=None, pool: int = 500, seed: int = 47) -> dict:
+    """The reference's leave-one-out split (recsys/dataset.py:10-156) from ``ratings.dat`` /
+    ``users.dat`` ("::"-separated MovieLens files), without pandas: user code = id - 1, movie code =
+    rank of the id string among the rated ids, each user's latest rating (ties: first in the file)
+    held out, the per-user negative pool = the ``pool`` most popular (by summed rating) movies the
+    user has not rated, ``n_test_codes - 1`` pool draws per user under ``np.random.seed(seed)``.
+    Returns the ``data`` dict ``ImplicitData`` takes; ``out`` also writes it the way the reference
+    does (``np.savez(out, data=dict)``, a pickled dict: read it back with ``trust_pickle=True``)."""
+    uid, mid, rating, ts = _read_dat(ratings_path, 4)
+    user = np.asarray(uid, dtype=np.int32) - 1
+    movie = _string_codes(mid)
+    rating = np.asarray(rating, dtype=np.float32)
+    ts = np.asarray(ts, dtype=np.int64)
+    rank = _rank_first_within(user, ts)
+    reverse = _rank_first_within(user, ts, descending=True)
+    train, test = reverse > 0, reverse == 0
+
+    np.random.seed(seed)
+    user_movie = scs.csr_matrix((rating, (user, movie)))
+    score = user_movie.sum(axis=0).repeat(user_movie.shape[0], axis=0)
+    score[user_movie.nonzero()] = -1
+    negative_samples = np.asarray(np.argsort(score, axis=1)[:, ::-1])[:, :pool]
+    draws = np.random.randint(0, negative_samples.shape[1], (negative_samples.shape[0], n_test_codes - 1))
+    negative_codes = np.take_along_axis(negative_samples, draws, 1)
+
+    test_true = movie[test][:, None]
+    rating_matrix = scs.csr_matrix((rating[train], (user[train], movie[train])))
+    implicit_matrix = rating_matrix.copy()
+    implicit_matrix[implicit_matrix.nonzero()] = 1
+    timestamp_matrix = scs.csr_matrix((rank[train], (user[train], movie[train])))
+    u_id, gender, age, occupation, _ = _read_dat(users_path, 5)
+    user_infos = np.stack([np.asarray(u_id, dtype=np.int32) - 1, _string_codes(gender).astype(np.int32),
+                           _string_codes(age).astype(np.int32), np.asarray(occupation, dtype=np.int32)], 1)
+    data = {"rating_matrix": rating_matrix, "implicit_matrix": implicit_matrix, "timestamp_matrix": timestamp_matrix,
+            "test_codes": np.hstack([test_true, negative_codes]), "test_true": test_true,
+            "test_timestamp_rank": rank[test].astype(int), "negative_samples": negative_samples, "user_infos": user_infos}
+    if out is not None:
+        np.savez(out, data=data)
+    return data
+
+
 def load_ml1m_data(path, trust_pickle: bool = False):
     """Read the ``ml1m.npz`` written by the reference's own split (recsys/dataset.py:143-156).  That
     file stores a pickled dict, and unpickling runs code from the file: it is only read when the
@@ -180,7 +260,8 @@ def load_ml1m_data(path, trust_pickle: bool = False):
 
 def load_implicit_data(device="cpu", train_batch_size: int = 512, test_batch_size: int = 1024, path=None,
                        sampler: str = "device", trust_pickle: bool = False) -> ImplicitData:
-    """``path`` to a user-built ml1m.npz, or ML-1M-shaped synthetic data when None."""
+    """``path`` to a user-built ml1m.npz (``split_data_loo(..., out=path)``), or ML-1M-shaped
+    synthetic data when None."""
     data = load_ml1m_data(path, trust_pickle) if path is not None else synthetic_ml1m_data()
     return ImplicitData(data, device=device, train_batch_size=train_batch_size, test_batch_size=test_batch_size,
                         sampler=sampler)

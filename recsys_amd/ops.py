@@ -1033,3 +1033,60 @@ def topk_codes(scores: Tensor, codes: Optional[Tensor], k: int) -> Tensor:
     check(lib.rx_topk_codes(_p(scores), _p(codes), rows, n, k, _p(out), _dev(scores), _stream(scores)),
           "rx_topk_codes")
     return out
+
+
+# ------------------------------------------------------------------ batching
+def sample_negatives(users: Tensor, items: Tensor, pool: Tensor, n_neg: int, seed: int,
+                     want_labels: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """rx_sample_negatives: ``[n, 1 + n_neg]`` item codes (the positive first, then ``n_neg`` uniform
+    draws with replacement from ``pool[user]``) and the float64 ``[1, 0, ..., 0]`` label rows.
+    The draws depend on (seed, position, draw number) only; ``sample_negatives_host`` is the same
+    function in numpy."""
+    _idx(users, "users"); _idx(items, "items")
+    _req(pool, torch.int64, "pool", 2)
+    n = users.numel()
+    if users.dim() != 1 or items.shape != users.shape:
+        raise ValueError("users and items: expected two [n] vectors")
+    _same_device(users, items); _same_device(users, pool)
+    dev = users.device
+    out = torch.empty(n, 1 + n_neg, dtype=torch.int64, device=dev)
+    labels = torch.empty(n, 1 + n_neg, dtype=torch.float64, device=dev) if want_labels else None
+    check(lib.rx_sample_negatives(_p(users), _p(items), _p(pool), n, pool.shape[0], pool.shape[1], n_neg,
+                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _p(out), _p(labels), _p(_err_flag(dev)), _dev(users),
+                                  _stream(users)), "rx_sample_negatives")
+    _after_index_op(dev)
+    return out, labels
+
+
+def sample_negatives_host(users, items, pool, n_neg: int, seed: int):
+    """The draw rule of rx_sample_negatives in numpy (uint64 arithmetic wraps like the device's)."""
+    import numpy as np
+    users, items, pool = (np.asarray(x) for x in (users, items, pool))
+    n, P = len(users), pool.shape[1]
+    out = np.empty((n, 1 + n_neg), dtype=np.int64)
+    out[:, 0] = items
+    if n_neg:
+        with np.errstate(over="ignore"):
+            c = (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(n_neg) + np.arange(n_neg, dtype=np.uint64)[None, :])
+            z = np.uint64(int(seed) & 0xFFFFFFFFFFFFFFFF) + (c + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            r = ((z >> np.uint64(32)) * np.uint64(P)) >> np.uint64(32)
+        out[:, 1:] = pool[users[:, None], r.astype(np.int64)]
+    return out
+
+
+# ------------------------------------------------------------------ model-level pieces of the backend surface
+# (the sharded models take their kernels from a backend module; these two complete that surface so
+# that a model never asks which backend it runs on)
+def bce_loss(logits: Tensor, labels: Tensor) -> Tensor:
+    """Mean BCE-with-logits with the reference's fp64 promotion, as an autograd node (rx_bce_fwd)."""
+    from .autograd import bce_with_logits
+    return bce_with_logits(logits, labels)
+
+
+def run_tower(seq, x: Tensor, bf16: bool = False) -> Tensor:
+    """An nn.Sequential tower (Linear / BatchNorm1d / ReLU / Dropout) through the dense-layer kernels."""
+    from .models.base import run_tower as _run
+    return _run(seq, x, bf16=bf16)

@@ -416,10 +416,7 @@ class ShardedFieldFM(torch.nn.Module):
         return _ShardedFM.apply(self._anchor, self, flat, sparse.shape[0], self.n_fields - 1, None, None, prep)[0]
 
     def loss(self, inputs):
-        if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend used by the gloo tests
-            return self.ops.bce_loss(self(inputs), inputs["label"])
-        from .autograd import bce_with_logits
-        return bce_with_logits(self(inputs), inputs["label"])
+        return self.ops.bce_loss(self(inputs), inputs["label"])
 
 
 class ShardedFieldDeepFM(ShardedFieldFM):
@@ -459,10 +456,7 @@ class ShardedFieldDeepFM(ShardedFieldFM):
         flat = prep[3] if prep is not None else self._flat(sparse)
         logits, x = _ShardedFM.apply(self._anchor, self, flat, B, self.n_fields - 1, self.deep_cols,
                                      _dense_input(inputs, self.n_dense, B, self.pad), prep)
-        if hasattr(self.ops, "bce_loss"):      # CPU stand-in backend: the tower as plain torch modules
-            return logits + self.deep_mlp(x)
-        from .models.base import run_tower
-        return logits + run_tower(self.deep_mlp, x, bf16=self.bf16)
+        return logits + self.ops.run_tower(self.deep_mlp, x, bf16=self.bf16)
 
     def allreduce_dense_grads(self):
         """Sum of the tower gradients over the ranks, one collective on a flat buffer (73 MB at the

@@ -104,3 +104,31 @@ def test_synthetic_ml1m_shape():
         assert not seen[u, d["negative_samples"][u]].any()      # pool = unseen items
         assert not seen[u, d["test_true"][u, 0]]                 # held-out positive is not in train
     assert (np.asarray(d["implicit_matrix"].sum(1)).reshape(-1) >= 19).all()
+
+
+def test_leave_one_out_split_matches_reference_on_toy_files(tmp_path):
+    """recsys/dataset.py:10-156 on a toy ratings.dat / users.dat pair (users shuffled in the file, tied
+    timestamps, movie ids whose string order differs from the numeric one, fewer movies than the
+    500-item pool): every array of the captured split, values and dtypes."""
+    from recsys_amd.dataset import ImplicitData, load_ml1m_data, split_data_loo
+    rec = load_golden("split")
+    rp, up, out = tmp_path / "ratings.dat", tmp_path / "users.dat", tmp_path / "ml1m.npz"
+    rp.write_text("\n".join(rec["ratings_lines"].tolist()) + "\n")
+    up.write_text("\n".join(rec["users_lines"].tolist()) + "\n")
+    data = split_data_loo(rp, up, n_test_codes=int(rec["n_test_codes"]), out=out)
+    for k in ("rating_matrix", "implicit_matrix", "timestamp_matrix"):
+        m = data[k].tocoo()
+        order = np.lexsort((m.col, m.row))
+        exp = group(rec, k)
+        assert tuple(m.shape) == tuple(exp["shape"]) and str(data[k].dtype) == str(exp["dtype"]), k
+        assert np.array_equal(m.row[order], exp["rows"]) and np.array_equal(m.col[order], exp["cols"]), k
+        assert np.array_equal(m.data[order], exp["vals"]), k
+    for k in ("test_codes", "test_true", "test_timestamp_rank", "negative_samples", "user_infos"):
+        assert np.array_equal(np.asarray(data[k]), rec[k]), k
+        assert str(np.asarray(data[k]).dtype) == str(rec[f"{k}_dtype"]), k
+    with np.testing.assert_raises(ValueError):
+        load_ml1m_data(out)                                   # a pickled dict: only on request
+    again = load_ml1m_data(out, trust_pickle=True)
+    assert np.array_equal(again["test_codes"], data["test_codes"])
+    idata = ImplicitData(data, device="cpu", train_batch_size=16, sampler="numpy")
+    assert idata.n_users == 14 and len(idata.create_negative_sampled_train_dataloader()) == -(-data["implicit_matrix"].nnz // 16)
