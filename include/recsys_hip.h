@@ -58,6 +58,12 @@ int rx_wall_clock(int64_t* d_slot, int device, void* stream);
  *   out[i, s.col : s.col + s.dim] = s.table[row, :]
  * div = N broadcasts one gathered row over N consecutive output rows (user rows over the
  * N items of a sample); stride/k pick field k out of a [B, stride] index matrix.
+ * bag > 1 sum-pools: the block receives the sum, in bag order, of the rows named by index
+ * elements j .. j + bag - 1 (k + bag <= stride) -- the .sum(1) over a field block that follows a
+ * multi-field lookup (recsys/models/matrix_factorization/factorization_machine.py:40-46).
+ * All segments of a call are served by ONE launch when every dim and col is a multiple of 4,
+ * out_ld too, pointers 16-byte aligned and the bags of a row total at most 32 index entries;
+ * other shapes take one launch per segment.
  */
 typedef struct {
   const float* table;   /* [rows, dim] */
@@ -69,7 +75,7 @@ typedef struct {
   int32_t div;          /* >= 1 */
   int32_t stride;       /* >= 1 */
   int32_t k;            /* 0 <= k < stride */
-  int32_t pad_;
+  int32_t bag;          /* 0 or 1: one row; > 1: sum of `bag` consecutive index elements' rows */
 } rx_gather_seg;
 
 int rx_gather_concat(const rx_gather_seg* segs, int n_segs, float* d_out, int64_t out_rows,

@@ -19,7 +19,7 @@ vp, sz = C.c_void_p, C.c_size_t
 
 class GatherSeg(C.Structure):
     _fields_ = [("table", vp), ("idx", vp), ("rows", i64), ("base", i64), ("dim", i32),
-                ("col", i32), ("div", i32), ("stride", i32), ("k", i32), ("pad_", i32)]
+                ("col", i32), ("div", i32), ("stride", i32), ("k", i32), ("bag", i32)]
 
 
 class MFArgs(C.Structure):

@@ -317,11 +317,13 @@ class FMLoss(Function):
 # ------------------------------------------------------------------ tower-input assembly
 class GatherConcat(Function):
     """out[M, W] assembled from gathered rows (rx_gather_concat).  ``spec`` is a list of
-    ``(param_slot, idx, col, div, stride, k, base)``; ``tables`` the distinct table parameters."""
+    ``(param_slot, idx, col, div, stride, k, base[, bag])``; ``tables`` the distinct table parameters.
+    A block with ``bag`` > 1 is the sum of the rows of ``bag`` consecutive index elements."""
 
     @staticmethod
     def forward(ctx, spec, out_rows, out_cols, *tables):
-        segs = [Segment(tables[slot], idx, col, div, stride, k, base) for (slot, idx, col, div, stride, k, base) in spec]
+        spec = [tuple(s) + (1,) if len(s) == 7 else tuple(s) for s in spec]
+        segs = [Segment(tables[slot], idx, col, div, stride, k, base, bag) for (slot, idx, col, div, stride, k, base, bag) in spec]
         ctx.spec, ctx.tables, ctx.out_rows = spec, tables, out_rows
         return ops.gather_concat(segs, out_rows, out_cols)
 
@@ -333,16 +335,24 @@ class GatherConcat(Function):
             mine = [s for s in ctx.spec if s[0] == slot]
             dim = table.shape[1]
             n_each = [ctx.out_rows // s[3] for s in mine]
+            pooled = any(s[7] > 1 for s in mine)
             occ = torch.empty(sum(n_each), dim, dtype=torch.float32, device=dout.device)
-            idx_parts = []
+            idx_parts, occ_parts = [], []
             o = 0
             for s, n in zip(mine, n_each):
-                _, idx, col, div, stride, k, base = s
+                _, idx, col, div, stride, k, base, bag = s
                 ops.gather_concat_bwd(dout, col, dim, div, out=occ[o:o + n])
+                if bag > 1:      # every member of a bag receives the bag's gradient
+                    used = idx.reshape(-1, stride)[:n, k:k + bag].reshape(-1)
+                    occ_parts.append(occ[o:o + n].repeat_interleave(bag, 0))
+                else:
+                    used = idx.reshape(-1, stride)[:n, k] if stride > 1 else idx.reshape(-1)[:n]
+                    occ_parts.append(occ[o:o + n])
                 o += n
-                used = idx.reshape(-1, stride)[:n, k] if stride > 1 else idx.reshape(-1)[:n]
                 idx_parts.append(used + base if base else used)
             flat = idx_parts[0] if len(idx_parts) == 1 else torch.cat(idx_parts)
+            if pooled:
+                occ = occ_parts[0] if len(occ_parts) == 1 else torch.cat(occ_parts)
             si = sorted_index(flat, table.shape[0])
             grads.append(table_backward(table, si, occ))
         return (None, None, None, *grads)

@@ -22,12 +22,82 @@ extern "C" int rx_wall_clock(int64_t* d_slot, int device, void* stream) {
   return 0;
 }
 
-struct GatherSegs {
+// ---------------------------------------------------------------- tower-input assembly
+// One launch for all segments.  A block owns GATHER_TILE consecutive output rows: it first resolves
+// every index those rows need (field pick, broadcast divisor, base offset, bounds check) into an LDS
+// tile with one sweep of coalesced-as-possible loads, then its threads walk the tile's 16-byte pieces
+// in output order, so that consecutive lanes write consecutive pieces of one output row and read
+// consecutive pieces of one table row.  A pooled segment (bag > 1) sums its bag of rows in bag order.
+#define GATHER_TILE 64
+#define GATHER_MAX_ENTRIES 32  // LDS index entries per output row (sum of the segments' bags)
+
+struct GatherPlan {
   rx_gather_seg s[RX_MAX_SEGS];
   int n;
+  int piece_start[RX_MAX_SEGS + 1];  // first 16-byte piece of each segment inside an output row
+  int ent_start[RX_MAX_SEGS + 1];    // first index entry of each segment inside an output row
 };
 
-// One launch per segment keeps the lane->row mapping exact for each width.
+__global__ void __launch_bounds__(RX_BLOCK)
+gather_multi_kernel(GatherPlan P, float* __restrict__ out, int64_t out_rows, int64_t out_ld, int32_t* err_flag) {
+  __shared__ int64_t rows_lds[GATHER_TILE * GATHER_MAX_ENTRIES];
+  __shared__ const float* tab_lds[RX_MAX_SEGS];
+  __shared__ int meta_lds[RX_MAX_SEGS][4];  // dim, col, bag, first entry
+  __shared__ int piece_lds[RX_MAX_SEGS + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * GATHER_TILE;
+  const int tile = (int)(out_rows - i0 < GATHER_TILE ? out_rows - i0 : GATHER_TILE);
+  const int ents = P.ent_start[P.n];
+  if (threadIdx.x <= P.n) piece_lds[threadIdx.x] = P.piece_start[threadIdx.x];
+  if (threadIdx.x < P.n) {
+    const rx_gather_seg& sg = P.s[threadIdx.x];
+    tab_lds[threadIdx.x] = sg.table;
+    meta_lds[threadIdx.x][0] = sg.dim; meta_lds[threadIdx.x][1] = sg.col;
+    meta_lds[threadIdx.x][2] = sg.bag > 1 ? sg.bag : 1; meta_lds[threadIdx.x][3] = P.ent_start[threadIdx.x];
+  }
+  // index tile: entry e of row r (r fastest, so that a wavefront reads neighbouring samples)
+  for (int q = 0; q < P.n; ++q) {
+    const rx_gather_seg& sg = P.s[q];
+    const int bag = sg.bag > 1 ? sg.bag : 1;
+    const int e0 = P.ent_start[q];
+    for (int t = threadIdx.x; t < tile * bag; t += RX_BLOCK) {
+      const int m = t / tile, r = t - m * tile;
+      const int64_t j = ((i0 + r) / sg.div) * sg.stride + sg.k + m;
+      const int64_t row = sg.idx[j] + sg.base;
+      rows_lds[r * ents + e0 + m] = rx_row_ok(row, sg.rows, err_flag) ? row : -1;
+    }
+  }
+  __syncthreads();
+  const int ppr = piece_lds[P.n];
+  const int total = tile * ppr;
+#pragma unroll 4
+  for (int p = threadIdx.x; p < total; p += RX_BLOCK) {
+    const int r = p / ppr, c = p - r * ppr;
+    int q = 0;
+#pragma unroll
+    for (int u = 1; u < RX_MAX_SEGS; ++u) q += (u < P.n && c >= piece_lds[u]) ? 1 : 0;
+    const int cc = (c - piece_lds[q]) * 4;
+    const int dim = meta_lds[q][0], bag = meta_lds[q][2];
+    const float* tab = tab_lds[q];
+    const int64_t* ent = rows_lds + r * ents + meta_lds[q][3];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bag == 1) {  // a copy, bit for bit
+      const int64_t row = ent[0];
+      if (row >= 0) v = *reinterpret_cast<const float4*>(tab + row * dim + cc);
+    } else {
+      for (int m = 0; m < bag; ++m) {
+        const int64_t row = ent[m];
+        if (row >= 0) {
+          const float4 w = *reinterpret_cast<const float4*>(tab + row * dim + cc);
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + (i0 + r) * out_ld + meta_lds[q][1] + cc) = v;
+  }
+}
+
+// Fallback for widths, columns or pointers that rule out 16-byte pieces: one launch per segment,
+// a lane group per output row.
 template <int VEC>
 __global__ void __launch_bounds__(RX_BLOCK)
 gather_seg_kernel(rx_gather_seg s, float* __restrict__ out, int64_t out_rows, int64_t out_ld,
@@ -36,18 +106,23 @@ gather_seg_kernel(rx_gather_seg s, float* __restrict__ out, int64_t out_rows, in
   const int64_t i = gid / group;  // output row
   const int lg = (int)(gid % group);
   if (i >= out_rows) return;
+  const int bag = s.bag > 1 ? s.bag : 1;
   const int64_t j = (i / s.div) * s.stride + s.k;
-  // every lane of the group reads the same 8 bytes: one broadcast load from L1
-  const int64_t row = s.idx[j] + s.base;
-  const bool ok = rx_row_ok(row, s.rows, lg == 0 ? err_flag : nullptr);
-  const float* src = s.table + row * (int64_t)s.dim;
   float* dst = out + i * out_ld + s.col;
   for (int k = 0; k < chunks; ++k) {
     const int c = (lg + k * group) * VEC;
-    if (c < s.dim) {
-      RxPack<VEC> v = ok ? rx_load<VEC>(src + c) : rx_zero<VEC>();
-      rx_store<VEC>(dst + c, v);
+    if (c >= s.dim) continue;
+    RxPack<VEC> acc = rx_zero<VEC>();
+    for (int m = 0; m < bag; ++m) {
+      // every lane of the group reads the same 8 bytes: one broadcast load from L1
+      const int64_t row = s.idx[j + m] + s.base;
+      if (!rx_row_ok(row, s.rows, (lg == 0 && k == 0) ? err_flag : nullptr)) continue;
+      const RxPack<VEC> v = rx_load<VEC>(s.table + row * (int64_t)s.dim + c);
+      if (bag == 1) { acc = v; break; }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc.v[e] += v.v[e];
     }
+    rx_store<VEC>(dst + c, acc);
   }
 }
 
@@ -59,12 +134,30 @@ extern "C" int rx_gather_concat(const rx_gather_seg* segs, int n_segs, float* d_
   RX_REQUIRE(out_rows >= 0 && out_ld >= 1, "rx_gather_concat: bad output shape");
   if (out_rows == 0) return 0;
   RX_REQUIRE(segs && d_out, "rx_gather_concat: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  bool pieces = (out_ld % 4 == 0) && rx_aligned16(d_out);
+  GatherPlan P{};
+  P.n = n_segs;
   for (int q = 0; q < n_segs; ++q) {
     const rx_gather_seg& s = segs[q];
     RX_REQUIRE(s.table && s.idx, "rx_gather_concat: segment %d has a null pointer", q);
     RX_REQUIRE(s.dim >= 1 && s.dim <= RX_MAX_DIM, "rx_gather_concat: segment %d dim %d unsupported", q, s.dim);
     RX_REQUIRE(s.div >= 1 && s.stride >= 1 && s.k >= 0 && s.k < s.stride, "rx_gather_concat: segment %d bad div/stride/k", q);
+    RX_REQUIRE(s.bag >= 0 && s.k + (s.bag > 1 ? s.bag : 1) <= s.stride, "rx_gather_concat: segment %d: bag %d leaves its index row (k %d, stride %d)", q, s.bag, s.k, s.stride);
     RX_REQUIRE(s.col >= 0 && (int64_t)s.col + s.dim <= out_ld, "rx_gather_concat: segment %d exceeds out_ld", q);
+    P.s[q] = s;
+    P.piece_start[q + 1] = P.piece_start[q] + s.dim / 4;
+    P.ent_start[q + 1] = P.ent_start[q] + (s.bag > 1 ? s.bag : 1);
+    pieces = pieces && s.dim % 4 == 0 && s.col % 4 == 0 && rx_aligned16(s.table);
+  }
+  if (pieces && P.ent_start[n_segs] <= GATHER_MAX_ENTRIES) {
+    const unsigned grid = (unsigned)rx_cdiv(out_rows, GATHER_TILE);
+    hipLaunchKernelGGL(gather_multi_kernel, dim3(grid), dim3(RX_BLOCK), 0, st, P, d_out, out_rows, out_ld, err_flag);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  for (int q = 0; q < n_segs; ++q) {
+    const rx_gather_seg& s = segs[q];
     RxRowShape sh = rx_row_shape(s.dim);
     const bool vec4 = sh.vec == 4 && (s.col % 4 == 0) && (out_ld % 4 == 0) && rx_aligned16(s.table) && rx_aligned16(d_out);
     if (!vec4) {
@@ -76,7 +169,6 @@ extern "C" int rx_gather_concat(const rx_gather_seg* segs, int n_segs, float* d_
     }
     const int64_t threads = out_rows * sh.group;
     const unsigned grid = (unsigned)rx_cdiv(threads, RX_BLOCK);
-    hipStream_t st = (hipStream_t)stream;
     if (vec4)
       hipLaunchKernelGGL(gather_seg_kernel<4>, dim3(grid), dim3(RX_BLOCK), 0, st, s, d_out, out_rows, out_ld, sh.group, sh.chunks, err_flag);
     else

@@ -115,6 +115,7 @@ class Segment:
     stride: int = 1
     k: int = 0
     base: int = 0
+    bag: int = 1        # > 1: the block is the sum of the rows of `bag` consecutive index elements
 
 
 def _segs_array(segs: Sequence[Segment]):
@@ -123,7 +124,7 @@ def _segs_array(segs: Sequence[Segment]):
         _table(s.table, f"segment {i} table")
         _idx(s.idx, f"segment {i} idx")
         arr[i] = GatherSeg(s.table.data_ptr(), s.idx.data_ptr(), s.table.shape[0], s.base,
-                           s.table.shape[1], s.col, s.div, s.stride, s.k, 0)
+                           s.table.shape[1], s.col, s.div, s.stride, s.k, s.bag)
     return arr
 
 
@@ -132,7 +133,7 @@ def gather_concat(segs: Sequence[Segment], out_rows: int, out_cols: int,
     ref = segs[0].table
     for s in segs:
         _same_device(ref, s.table, s.idx)
-        need = ((out_rows - 1) // s.div) * s.stride + s.k + 1 if out_rows else 0
+        need = ((out_rows - 1) // s.div) * s.stride + s.k + max(s.bag, 1) if out_rows else 0
         if s.idx.numel() < need:
             raise ValueError("gather_concat: index tensor shorter than the rows it must serve")
     if out is None:

@@ -75,21 +75,59 @@ def train_step(model, optimizer, inputs, clip_norm):
     return loss.detach()
 
 
-def train_loop(model, data, optimizer, num_epochs, clip_norm, k=10):
+class LoopGraph:
+    """Replays the train step as one HIP graph inside ``train_epoch``: the first ``eager_steps``
+    batches of the first epoch run eagerly (they are ordinary train steps and leave every lazily
+    sized buffer at its final size), the step is then recorded once on a static copy of a batch, and
+    every later full-size batch is copied into that copy (``GraphedTrainStep.copy_batch``) and
+    replayed.  A short last batch runs eagerly."""
+
+    def __init__(self, model, optimizer, eager_steps: int = 2):
+        from .graph import GraphedTrainStep
+        if not isinstance(optimizer, FusedOptimizer):
+            raise TypeError("graph replay of the train step needs a FusedOptimizer")
+        self.step = GraphedTrainStep(model, optimizer, warmup=0)
+        self.eager_left, self.slot, self.rows = eager_steps, None, None
+
+    def __call__(self, model, optimizer, inputs, clip_norm):
+        rows = next(iter(inputs.values())).shape[0]
+        if self.eager_left > 0 or (self.rows is not None and rows != self.rows):
+            self.eager_left -= 1
+            return train_step(model, optimizer, inputs, clip_norm)
+        if self.slot is None:
+            optimizer.clip_norm = clip_norm
+            self.rows = rows
+            self.slot = self.step.add_batch({k: v.clone() for k, v in inputs.items()})   # records, executes nothing
+        self.step.copy_batch(self.slot, inputs)
+        return self.step(self.slot).detach()
+
+
+def train_epoch(model, optimizer, train_dl, clip_norm, step_fn=None):
+    """One pass over ``train_dl`` (recsys/utils.py:93-106 without its two host reads per step);
+    returns the sum of the batch losses as a device tensor."""
+    step_fn = step_fn or train_step
+    running = None
+    for inputs in train_dl:
+        loss = step_fn(model, optimizer, inputs, clip_norm)
+        running = loss.clone() if running is None else running.add_(loss)
+    return running
+
+
+def train_loop(model, data, optimizer, num_epochs, clip_norm, k=10, graph=False):
+    """recsys/utils.py:84-117.  ``graph=True`` (GPU, FusedOptimizer): the step is replayed as a HIP
+    graph from the third batch on (``LoopGraph``)."""
     history = []
     data.create_test_dataloader()
     eval_loop(model, data, k, epoch=None, num_epochs=None, epoch_loss=None)
     on_gpu = next(model.parameters()).is_cuda
     if on_gpu:
         ops.set_index_check("deferred")
+    step_fn = LoopGraph(model, optimizer) if graph else None
     try:
         for epoch in range(num_epochs):
             model.train()
             train_dl = data.create_negative_sampled_train_dataloader()
-            running = None
-            for inputs in train_dl:
-                loss = train_step(model, optimizer, inputs, clip_norm)
-                running = loss if running is None else running + loss
+            running = train_epoch(model, optimizer, train_dl, clip_norm, step_fn)
             if on_gpu:
                 ops.raise_if_index_error()
             epoch_loss = float(running.item()) / len(train_dl)

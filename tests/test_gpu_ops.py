@@ -39,6 +39,60 @@ def test_gather_rows_bit_exact(ops, dim):
     assert torch.equal(out, exp.reshape(33 * 5, 3 * dim))
 
 
+@pytest.mark.parametrize("dims,rows,N", [((64, 64), 40960, 5), ((16, 32, 8, 128), 1000, 3), ((16, 7), 300, 2), ((64,) * 8, 129, 1)])
+def test_gather_many_segments_in_one_launch(ops, dims, rows, N):
+    """Segments of different widths, tables and index layouts (broadcast, field pick) at sizes that
+    span many 64-row tiles with a ragged last one; (16, 7) forces the per-segment fallback."""
+    g = _gen(rows)
+    B = rows // N if rows % N == 0 else rows
+    N = rows // B
+    fields = torch.randint(0, 50, (B, len(dims)), generator=g)
+    items = torch.randint(0, 80, (B, N), generator=g)
+    tables = [torch.randn(90, d, generator=g) for d in dims]
+    segs, exp, col = [], [], 0
+    for q, (t, d) in enumerate(zip(tables, dims)):
+        if q % 2 == 0:
+            segs.append(ops.Segment(t.cuda(), items.cuda(), col))
+            exp.append(t[items].reshape(B * N, d))
+        else:
+            segs.append(ops.Segment(t.cuda(), fields.cuda(), col, div=N, stride=len(dims), k=q, base=3))
+            exp.append(t[fields[:, q] + 3][:, None, :].expand(B, N, d).reshape(B * N, d))
+        col += d
+    pad = (-col) % 4 if all(d % 4 == 0 for d in dims) else 0
+    out = ops.gather_concat(segs, B * N, col + pad)
+    assert torch.equal(out[:, :col].cpu(), torch.cat(exp, 1))
+
+
+@pytest.mark.parametrize("dim,bag", [(16, 3), (64, 8), (5, 4), (128, 26)])
+def test_gather_sum_pool(ops, dim, bag):
+    """bag > 1: a block is the sum, in bag order, of a bag of rows -- against an fp32 loop in the same
+    order (bit for bit), forward; backward through autograd against torch's index + sum."""
+    from recsys_amd import autograd as rxa
+    g = _gen(dim * bag)
+    B = 257
+    table = torch.randn(400, dim, generator=g)
+    other = torch.randn(50, dim, generator=g)
+    idx = torch.randint(0, 300, (B, bag + 2), generator=g)
+    idx[:, 0] %= 50
+    segs = [ops.Segment(table.cuda(), idx.cuda(), 0, stride=bag + 2, k=1, base=7, bag=bag),
+            ops.Segment(other.cuda(), idx.cuda(), dim, stride=bag + 2, k=0, base=0)]
+    out = ops.gather_concat(segs, B, 2 * dim).cpu()
+    acc = torch.zeros(B, dim)
+    for m in range(bag):
+        acc = acc + table[idx[:, 1 + m] + 7]
+    assert torch.equal(out[:, :dim], acc)
+    assert torch.equal(out[:, dim:], other[idx[:, 0]])
+    # autograd: pooled block + plain block
+    wt = table.cuda().requires_grad_(True)
+    spec = [(0, idx.cuda(), 0, 1, bag + 2, 1, 7, bag)]
+    y = rxa.GatherConcat.apply(spec, B, dim, wt)
+    w = torch.randn(B, dim, generator=g)
+    (y * w.cuda()).sum().backward()
+    ref = table.clone().requires_grad_(True)
+    (ref[idx[:, 1:1 + bag] + 7].sum(1) * w).sum().backward()
+    assert_close(wt.grad.cpu().numpy(), ref.grad.numpy(), rtol=1e-5, what="pooled gather grad")
+
+
 def test_gather_out_of_range_raises(ops):
     table = torch.randn(10, 8).cuda()
     bad = torch.tensor([0, 10, 3]).cuda()

@@ -15,7 +15,7 @@ def _small_data():
     return ImplicitData(d, device="cuda", train_batch_size=256, test_batch_size=128)
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "graph"])
 def test_train_loop_learns(fused, capsys):
     """recsys/utils.py:84-117 call pattern: eval before training, then epochs of train + eval."""
     from recsys_amd.models.neuralcf import NeuMF
@@ -28,7 +28,7 @@ def test_train_loop_learns(fused, capsys):
         opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=5e-3)
-    hist = train_loop(model, data, opt, num_epochs=4, clip_norm=1.0, k=10)
+    hist = train_loop(model, data, opt, num_epochs=4, clip_norm=1.0, k=10, graph=fused == "graph")
     out = capsys.readouterr().out
     assert out.count("metrics - ndcg@10") == 5 and "epoch [2/4], loss:" in out
     losses = [h[0] for h in hist]
@@ -634,3 +634,38 @@ def test_device_loader_epochs_are_reproducible_from_the_seed():
         assert torch.equal(ea["item_code"].cpu(), ec["item_code"])          # the numpy mirror on a CPU device
     e2 = a.create_negative_sampled_train_dataloader().tensors
     assert not torch.equal(e2["item_code"], ea["item_code"])               # next epoch, next stream
+
+
+@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF"])
+def test_train_epoch_graph_replay_matches_eager_bitwise(name):
+    """utils.LoopGraph: two epochs with the step replayed as a graph on copied-in batches give the
+    same weights and epoch losses, bit for bit, as the eager loop on the same seeded loader."""
+    from recsys_amd import ops
+    from recsys_amd.dataset import ImplicitData, synthetic_ml1m_data
+    from recsys_amd.models import matrix_factorization as mf
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.utils import LoopGraph, train_epoch
+    d = synthetic_ml1m_data(seed=3, n_users=400, n_items=300, n_occupations=7, n_train=12000, pool=60, n_test_codes=50)
+    results = []
+    for graphed in (False, True):
+        data = ImplicitData(d, device="cuda", train_batch_size=500, seed=9)
+        torch.manual_seed(0)
+        kw = dict(n_users=data.n_users, n_items=data.n_items, embedding_dim=16)
+        if name == "TemporalMF":
+            kw.update(n_occupations=data.n_occupations, max_timestamp_rank=data.max_timestamp_rank)
+        model = getattr(mf, name)(**kw).cuda().train()
+        opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
+        step = LoopGraph(model, opt) if graphed else None
+        ops.set_index_check("deferred")
+        try:
+            sums = [float(train_epoch(model, opt, data.create_negative_sampled_train_dataloader(), 1.0, step).item())
+                    for _ in range(2)]
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        if graphed:
+            assert step.slot is not None and len(step.step.graphs) == 1
+        results.append((sums, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    for k, v in results[0][1].items():
+        assert torch.equal(v, results[1][1][k]), k
