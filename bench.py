@@ -78,7 +78,8 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
                 model.allreduce_dense_grads()
                 model.dense_sgd_step(lr, model.finish_step(model.dense_grads()))
 
-        return dict(model=model, opt=_DeepOpt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
+        w = dict(model=model, opt=_DeepOpt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
+        return graph_sharded(w, device, world) if use_graph else w
     if name == "fm_criteo_sharded":
         # tables row-sharded over the ranks (row r on rank r % G), batch data parallel, index / row /
         # gradient exchange by all-to-all; per-GPU batch fixed (weak scaling)
@@ -106,7 +107,8 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
                 model.finish_step()     # global-norm clip over all ranks, then the pending row updates
 
         # the global loss is the mean over all ranks' rows: each rank back-propagates loss / G
-        return dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
+        w = dict(model=model, opt=_Opt(), batches=batches, B=B, desc=desc, graphed=None, loss_scale=1.0 / world, dims=dims)
+        return graph_sharded(w, device, world) if use_graph else w
     if name in ("fm_criteo", "fm_wide_d128", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
         B, D = 65536, 16
@@ -149,6 +151,29 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
                           "side stream while batch i trains (one index preparation per step, off the critical path)")
     else:
         desc["launch"] = "eager"
+    return w
+
+
+def graph_sharded(w, device, world):
+    """Sharded workloads: one HIP graph per resident batch (index work, exchanges, backward, clip and
+    update in one launch).  On by default at one rank, where it is tested against eager steps bit for
+    bit with the RCCL calls inside the recording; at more ranks eager launch unless
+    RX_BENCH_SHARDED_GRAPH=1 (recorded collectives could not be rehearsed on several GPUs here)."""
+    want = os.environ.get("RX_BENCH_SHARDED_GRAPH")
+    if want == "0" or (world > 1 and want != "1"):
+        return w
+    from recsys_amd.graph import ShardedGraphStep
+    model, opt, scale = w["model"], w["opt"], w["loss_scale"]
+
+    def step(batch):
+        opt.zero_grad()
+        loss = model.loss(batch)
+        (loss * scale).backward()
+        opt.step()
+        return loss.detach()
+
+    w["graphed"] = ShardedGraphStep(step, w["batches"], device, warmup=3)
+    w["desc"]["launch"] = w["desc"]["launch"].replace("eager, asynchronous", "one HIP graph per step (exchanges recorded inside)")
     return w
 
 
@@ -572,7 +597,9 @@ def main():
     if (world > 1 or force_dist) and args.workload == "fm_criteo":
         args.workload = "fm_criteo_sharded"
     if args.workload in ("fm_criteo_sharded", "deepfm_criteo_sharded", "deepfm_wide_d128_sharded"):
-        use_graph = False
+        # graphs with the exchanges inside: at one rank by default, at more ranks on request (graph_sharded)
+        want = os.environ.get("RX_BENCH_SHARDED_GRAPH")
+        use_graph = use_graph and want != "0" and (world == 1 or want == "1")
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph,
                                    repeats=args.repeats)
     if use_graph:
@@ -686,6 +713,10 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        # recorded collectives must be gone before the group is torn down (the teardown blocks otherwise)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize(device)
         dist.destroy_process_group()
 
 

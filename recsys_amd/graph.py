@@ -181,3 +181,53 @@ class GraphedTrainStep:
     def __call__(self, slot: int) -> torch.Tensor:
         self.graphs[slot].replay()
         return self.losses[slot]
+
+
+class ShardedGraphStep:
+    """One HIP graph per resident batch for a row-sharded model (``sharded.ShardedFieldFM`` and its
+    DeepFM variant) running its fixed-capacity exchange, where no size crosses to the host: the
+    whole step -- index work, all-to-all exchanges (RCCL calls are recorded like kernels), forward,
+    backward, owner-side reduce, clip, update -- replays as one launch.
+
+    ``step_fn(batch) -> loss`` runs one complete train step eagerly; it is called ``warmup`` times on
+    the first batch before recording (real steps).  Every rank must construct, replay and release
+    these graphs in the same order.  Call ``release()`` before ``destroy_process_group()``: tearing
+    the group down while recorded collectives are alive blocks."""
+
+    def __init__(self, step_fn, batches, device, warmup: int = 3):
+        if ops._INDEX_CHECK != "deferred":
+            raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
+        self.batches = list(batches)
+        self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.losses: List[torch.Tensor] = []
+        self.segments: Dict[int, tuple] = {}      # no multi-step graphs (same driver interface as GraphedTrainStep)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn(self.batches[0])
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        pool = None
+        for b in self.batches:
+            g = torch.cuda.CUDAGraph()
+            clear_sort_cache()
+            # thread-local error mode: the process group's watchdog thread polls the events of earlier
+            # collectives while this thread records, which the global mode turns into a capture error
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                loss = step_fn(b)
+            clear_sort_cache()
+            pool = pool or g.pool()
+            self.graphs.append(g)
+            self.losses.append(loss.detach())
+
+    def __call__(self, slot: int) -> torch.Tensor:
+        self.graphs[slot].replay()
+        return self.losses[slot]
+
+    def segment_at(self, slot: int) -> int:
+        return 0          # one graph per step (same driver interface as GraphedTrainStep)
+
+    def release(self) -> None:
+        self.graphs.clear()
+        self.losses.clear()

@@ -669,3 +669,20 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name):
     assert results[0][0] == results[1][0]
     for k, v in results[0][1].items():
         assert torch.equal(v, results[1][1][k]), k
+
+
+@pytest.mark.parametrize("model", ["fm", "deepfm"])
+def test_sharded_step_replayed_as_a_graph_through_rccl_matches_eager_bitwise(model):
+    """graph.ShardedGraphStep at one rank on the nccl (RCCL) backend with the exchanges forced on:
+    index work, the all-to-alls, backward, clip and update replay as one HIP graph per batch and
+    leave the same weights, bit for bit, as eager steps.  Runs in a process of its own (it owns a
+    process group and must tear it down after releasing the graphs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ROWS="300000", DIM="16", B="4096", MODEL=model, MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "-u", os.path.join(root, "profiles", "sharded_graph_probe.py")], env=env,
+                         capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "bitwise equal True" in out.stdout and "group destroyed" in out.stdout, out.stdout[-2000:]
