@@ -555,6 +555,45 @@ int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const i
 int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, int32_t n,
                   int32_t k, int64_t* d_out, int device, void* stream);
 
+/* ------------------------------------------------------------------ dense layers, bf16 activations in HBM
+ * The Linear(+ReLU) stacks and DCN-v2 cross layers of recsys_amd.models.fields (a14; the towers of
+ * recsys/models/neuralcf/deep_factorization_machine.py:6-24 in their bf16 option) with every
+ * activation that only feeds matrix products stored as bfloat16 (uint16_t bit patterns, round to
+ * nearest even): the products round their operands to bf16 anyway, so the values are those of
+ * rx_linear_*(bf16 = 1) on fp32 storage while each operand moves half the bytes.  fp32
+ * accumulation, fp32 master weights; W16 / W16T are per-use bf16 copies of a weight [N, K] made
+ * by rx_to_bf16 ([N, K], and transposed [K, N] for the input gradient).  Rows must be 16-byte
+ * addressable (leading dimensions multiples of 8 elements), K and N multiples of 8; N == 1 (the
+ * tower's last layer, K <= 512) takes matrix-vector kernels that read the fp32 weights `W`.
+ *   rx_to_bf16         dst = bf16(src) for an fp32 [rows, cols] matrix; transpose != 0 writes
+ *                      dst[c, r] (weight matrices)
+ *   rx_linear16_fwd    Y = act(X16 W16^T + b), Y fp32 or bf16 (out_bf16)
+ *   rx_linear16_bwd_x  dX = dY16 W (through W16T); fp32 output (accumulate: dX += ...), or bf16
+ *                      output with an optional gate16 [M, K] (the bf16 output of the ReLU layer
+ *                      in front: entries with gate <= 0 become 0, i.e. that layer's ReLU backward
+ *                      fused into this epilogue)
+ *   rx_linear16_bwd_w  dW = dY16^T X16 (slabs over the batch, summed in slab order), db = column
+ *                      sums of dY16 (may be NULL)
+ *   rx_cross16_fwd     x_next = x0 * u + x_l in fp32 plus its bf16 copy (operand of the next products)
+ *   rx_cross16_bwd     rx_cross_combine_bwd_stack with du = d * x0 written as bf16 only */
+int rx_to_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+               int transpose, int device, void* stream);
+int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* W, const float* b,
+                    void* Y, int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int out_bf16, int device,
+                    void* stream);
+int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16_t* W16T, const float* W, void* dX, int64_t ldx,
+                      const uint16_t* gate16, int64_t ldg, int64_t M, int32_t N, int32_t K, int accumulate,
+                      int out_bf16, int device, void* stream);
+size_t rx_linear16_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16_t* X16, int64_t ldx, float* dW, float* db,
+                      int64_t M, int32_t N, int32_t K, void* ws, size_t ws_bytes, int device, void* stream);
+int rx_cross16_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* xl, int64_t ldl,
+                   float* xn, int64_t ldn, uint16_t* xn16, int64_t ldn16, int64_t rows, int32_t cols, int device,
+                   void* stream);
+int rx_cross16_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u, int64_t ldu,
+                   uint16_t* du16, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl, int64_t ldxl,
+                   int64_t rows, int32_t cols, int accumulate, int identity, int device, void* stream);
+
 /* ------------------------------------------------------------------ batching
  * Negative sampling of one epoch, replacing the host numpy sequence of recsys/dataset.py:165-187
  * (rows.repeat(n_neg); randint(0, pool); negative_samples[rows, draws]; hstack with the positives;

@@ -99,6 +99,13 @@ PROTOTYPES = {
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
+    "rx_to_bf16": (C.c_int, [vp, i64, vp, i64, i64, i32, C.c_int, C.c_int, vp]),
+    "rx_linear16_fwd": (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
+    "rx_linear16_bwd_x": (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
+    "rx_linear16_bwd_w_workspace_bytes": (sz, [i64, i32, i32]),
+    "rx_linear16_bwd_w": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, sz, C.c_int, vp]),
+    "rx_cross16_fwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
+    "rx_cross16_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_sample_negatives": (C.c_int, [vp, vp, vp, i64, i64, i32, i32, C.c_uint64, vp, vp, vp, C.c_int, vp]),
     "rx_dense_adam_dstep": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp, C.c_int, vp]),
     "rx_dense_sgd": (C.c_int, [vp, vp, i64, f32, vp, C.c_int, vp]),

@@ -475,6 +475,98 @@ def cross_stack(x0: Tensor, layers, bf16: bool = False) -> Tensor:
     return CrossStack.apply(x0, bf16, *wb)
 
 
+def h16_shapes_ok(x: Tensor, weights) -> bool:
+    """Shapes the bf16-activation kernels take: fp32 GPU input with 16-byte addressable rows, every
+    layer width a multiple of 8 (the last layer may have one output column, up to 512 inputs)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1 and x.shape[1] % 8 == 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0):
+        return False
+    ws = list(weights)
+    for i, w in enumerate(ws):
+        n, k = w.shape
+        if k % 8 != 0:
+            return False
+        if n % 8 != 0 and not (i == len(ws) - 1 and n == 1 and k <= 512):
+            return False
+    return True
+
+
+class CrossStack16(Function):
+    """CrossStack with bf16 operand copies in HBM: every x_l is kept in fp32 for the residual chain
+    and as the bf16 copy the matrix products read (written by the same combine kernel); du exists in
+    bf16 only.  Same arithmetic as CrossStack(bf16=True) -- the products round these operands to
+    bf16 there too -- except that the bias gradient sums the rounded du.  Returns (x_L, bf16 copy)."""
+
+    @staticmethod
+    def forward(ctx, x0, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        x16 = ops.to_bf16(x0)
+        xs16, us, x = [x16], [], x0
+        for w, b in zip(ws, bs):
+            u = ops.linear16_fwd(xs16[-1], w, b, relu=False, out_bf16=False)
+            us.append(u)
+            x, xn16 = ops.cross16_fwd(x0, u, x)
+            xs16.append(xn16)
+        ctx.save_for_backward(x0, *xs16[:-1], *us, *ws)
+        ctx.L = len(ws)
+        ctx.mark_non_differentiable(xs16[-1])
+        return x, xs16[-1]
+
+    @staticmethod
+    def backward(ctx, dxn, _d16):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x0 = saved[0]
+        xs16, us, ws = saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:1 + 3 * L]
+        d = dxn if (dxn.stride(-1) == 1 and dxn.stride(0) % 4 == 0) else ops._padded(*dxn.shape, dxn.device).copy_(dxn)
+        dx0 = ops._padded(x0.shape[0], x0.shape[1], x0.device)
+        grads = [None] * (2 * L)
+        for l in range(L - 1, -1, -1):
+            last, first = l == L - 1, l == 0
+            du16, dxl = ops.cross16_bwd(d, x0, us[l], dx0, accumulate=not last, identity=first, want_dxl=last and not first)
+            target = dx0 if first else (dxl if last else d)
+            ops.linear16_bwd_x(du16, ws[l], out=target, accumulate=True)
+            grads[2 * l], grads[2 * l + 1] = ops.linear16_bwd_w(du16, xs16[l], True)
+            d = target
+        return (dx0,) + tuple(grads)
+
+
+class MLPStack16(Function):
+    """Linear + ReLU layers (the last one without ReLU) as one autograd node with bf16 activations in
+    HBM: hidden outputs are stored in bf16 only, the backward walk keeps the pre-activation
+    gradients in bf16 and applies each ReLU gate inside the epilogue of the product behind it.
+    ``x16``: the input's bf16 copy when the producer already made one (else None)."""
+
+    @staticmethod
+    def forward(ctx, x, x16, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        acts = [x16 if x16 is not None else ops.to_bf16(x)]
+        L = len(ws)
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            last = i == L - 1
+            acts.append(ops.linear16_fwd(acts[-1], w, b, relu=not last, out_bf16=not last))
+        ctx.save_for_backward(*acts[:-1], *ws)
+        ctx.L, ctx.has_b = L, [b is not None for b in bs]
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        acts, ws = saved[:L], saved[L:2 * L]
+        d16 = ops.to_bf16(dy.contiguous())
+        grads = [None] * (2 * L)
+        dx = None
+        for l in range(L - 1, -1, -1):
+            dw, db = ops.linear16_bwd_w(d16, acts[l], ctx.has_b[l])
+            grads[2 * l], grads[2 * l + 1] = dw, db
+            if l > 0:
+                d16 = ops.linear16_bwd_x(d16, ws[l], gate16=acts[l], out_bf16=True)
+            elif ctx.needs_input_grad[0]:
+                dx = ops.linear16_bwd_x(d16, ws[l], out_bf16=False)
+        return (dx, None) + tuple(grads)
+
+
 # ------------------------------------------------------------------ loss
 class BatchNormAct(Function):
     """BatchNorm1d (+ ReLU) (+ Dropout) of the reference's BN towers in three launches forward

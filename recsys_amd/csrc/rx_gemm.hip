@@ -1162,3 +1162,610 @@ extern "C" int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const f
   return cross_combine_bwd_run(dxn, ldd, x0, ld0, u, ldu, du, lddu, dx0_acc, ldx0, dxl, ldxl, rows, cols, accumulate, identity,
                                device, stream, "rx_cross_combine_bwd_stack");
 }
+
+// ================================================================ bf16 activations in HBM
+// The tower kept in bf16 between its layers: an activation (or a pre-activation gradient) that only
+// ever feeds matrix products is stored as the bf16 value those products would round it to anyway,
+// so the results are the ones of the fp32-storage path above while every operand moves half the
+// bytes and no conversion sits between the global load and LDS.  Weights stay fp32 masters; a
+// layer's bf16 copy ([N, K], and [K, N] for the input gradient, which makes that product
+// K-contiguous on both sides like the forward) is made per use by rx_to_bf16.
+//   * 128 x 128 tile, 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16, 64 k per step: 16 MFMAs per
+//     wave between barriers; next step's 16-byte loads in flight behind them (register staging,
+//     two LDS buffers, one barrier per step)
+//   * K-contiguous operands [row][64 + 8] read 16 bytes per lane; the weight gradient's operands
+//     (contiguous along the output dimensions) kept as loaded [k][128 + 32] and read through the
+//     transposing LDS read
+//   * epilogue variants as separate instantiations: fp32 or bf16 output, bias + ReLU, accumulate
+//     into fp32, and the ReLU gate of the layer in front applied from its stored bf16 output
+#define H_BK 64
+#define H_LDK (H_BK + 8)
+#define H_T 128
+#define H_LDR (H_T + 32)
+
+struct Gemm16Args {
+  const uint16_t* A; int64_t lda;   // K-contiguous: A(i,k) = A[i*lda + k]; else A(i,k) = A[k*lda + i]
+  const uint16_t* B; int64_t ldb;   // K-contiguous: B(k,j) = B[j*ldb + k]; else B(k,j) = B[k*ldb + j]
+  void* C; int64_t ldc;             // [M, N] fp32 or bf16
+  const float* bias;                // [N] or null
+  const uint16_t* gate; int64_t ldg;  // [M, N] bf16: output forced to 0 where gate <= 0
+  int64_t M, N, K;
+  int act;
+  int64_t k_per_slab, c_slab_stride;
+  int tiles_n;
+};
+
+struct HRegs { uint4 v[4]; };
+
+// K-contiguous: thread = (row tid/8 [+32p], 8 k at (tid%8)*8); K % 8 == 0, so a 16-byte piece is whole or absent
+__device__ __forceinline__ void h_load_kc(const uint16_t* __restrict__ P, int64_t ld, int64_t r0, int64_t r_lim,
+                                          int64_t k0, int64_t k_end, int tid, HRegs& t) {
+  const int64_t k = k0 + (tid & 7) * 8;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t row = r0 + (tid >> 3) + 32 * p;
+    const bool ok = row < r_lim && k < k_end;
+    uint4 a = *reinterpret_cast<const uint4*>(P + (ok ? row : 0) * ld + (ok ? k : 0));
+    if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
+    t.v[p] = a;
+  }
+}
+
+__device__ __forceinline__ void h_store_kc(uint16_t* lds, int tid, const HRegs& t) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&lds[((tid >> 3) + 32 * p) * H_LDK + (tid & 7) * 8]) = t.v[p];
+}
+
+// contiguous along the output dimension: 64 k-rows of 128 elements; thread = (k-row tid/16 [+16p], 8 at (tid%16)*8)
+__device__ __forceinline__ void h_load_mc(const uint16_t* __restrict__ P, int64_t ld, int64_t c0, int64_t c_lim,
+                                          int64_t k0, int64_t k_end, int tid, HRegs& t) {
+  const int64_t c = c0 + (tid & 15) * 8;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t k = k0 + (tid >> 4) + 16 * p;
+    const bool ok = k < k_end && c < c_lim;
+    uint4 a = *reinterpret_cast<const uint4*>(P + (ok ? k : 0) * ld + (ok ? c : 0));
+    if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
+    t.v[p] = a;
+  }
+}
+
+__device__ __forceinline__ void h_store_mc(uint16_t* lds, int tid, const HRegs& t) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&lds[((tid >> 4) + 16 * p) * H_LDR + (tid & 15) * 8]) = t.v[p];
+}
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 h_frag(const uint16_t* lds, int base, int ks, int lane) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const bf16x8*>(&lds[(base + (lane & 31)) * H_LDK + ks + 8 * (lane >> 5)]);
+  } else {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const uint16_t* a0 = &lds[(ks + 8 * (lane >> 5) + q) * H_LDR + base + 16 * ((lane >> 4) & 1) + 4 * pp];
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a0 + 4 * H_LDR));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+// KC: both operands K-contiguous (forward, input gradient); !KC: both contiguous along the output
+// dimensions (weight gradient, K = batch, slabs over blockIdx.z, fp32 output only)
+template <bool KC, bool OUT16, bool GATE, bool ACCUM>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemm_h16_kernel(Gemm16Args g, int swizzle) {
+  constexpr int OP_SZ = KC ? H_T * H_LDK : H_BK * H_LDR;
+  extern __shared__ __attribute__((aligned(16))) uint16_t h_lds[];   // [2][2 * OP_SZ]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  int64_t bid = blockIdx.x;
+  if (swizzle) bid = (bid % 8) * (gridDim.x / 8) + bid / 8;
+  const int64_t tile_m = bid / g.tiles_n;
+  const int tile_n = (int)(bid % g.tiles_n);
+  const int64_t m0 = tile_m * H_T;
+  const int64_t n0 = (int64_t)tile_n * H_T;
+  const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
+  const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  HRegs ra, rb;
+  auto fetch = [&](int64_t k0) {
+    if constexpr (KC) {
+      h_load_kc(g.A, g.lda, m0, g.M, k0, k_end, tid, ra);
+      h_load_kc(g.B, g.ldb, n0, g.N, k0, k_end, tid, rb);
+    } else {
+      h_load_mc(g.A, g.lda, m0, g.M, k0, k_end, tid, ra);
+      h_load_mc(g.B, g.ldb, n0, g.N, k0, k_end, tid, rb);
+    }
+  };
+  auto stash = [&](int buf) {
+    uint16_t* base = h_lds + buf * 2 * OP_SZ;
+    if constexpr (KC) { h_store_kc(base, tid, ra); h_store_kc(base + OP_SZ, tid, rb); }
+    else { h_store_mc(base, tid, ra); h_store_mc(base + OP_SZ, tid, rb); }
+  };
+
+  fetch(k_begin);
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += H_BK) {
+    const bool more = k0 + H_BK < k_end;
+    if (more) fetch(k0 + H_BK);
+    const uint16_t* As = h_lds + cur * 2 * OP_SZ;
+    const uint16_t* Bs = As + OP_SZ;
+#pragma unroll
+    for (int ks = 0; ks < H_BK; ks += 16) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = h_frag<KC>(As, (wave_m * 2 + i) * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = h_frag<KC>(Bs, (wave_n * 2 + j) * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + (wave_n * 2 + j) * 32 + l31;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        if constexpr (GATE) {
+          const uint16_t gt = g.gate[row * g.ldg + col];
+          if (gt == 0 || (gt & 0x8000u)) v = 0.f;
+        }
+        if constexpr (OUT16) {
+          reinterpret_cast<uint16_t*>(g.C)[row * g.ldc + col] = f32_to_bf16_rne(v);
+        } else {
+          float* dst = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride + row * g.ldc + col;
+          *dst = ACCUM ? (*dst + v) : v;
+        }
+      }
+    }
+  }
+}
+
+#define H_LDS_BYTES(KC_) ((size_t)2 * 2 * ((KC_) ? H_T * H_LDK : H_BK * H_LDR) * sizeof(uint16_t))
+
+template <bool KC, bool OUT16, bool GATE, bool ACCUM>
+static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
+  g.tiles_n = (int)rx_cdiv(g.N, H_T);
+  const int64_t blocks = rx_cdiv(g.M, H_T) * g.tiles_n;
+  RX_REQUIRE(blocks < (1ll << 31), "gemm16: grid too large");
+  const size_t lds = H_LDS_BYTES(KC);
+  static bool raised = false;   // per instantiation: 72 KB / 80 KB of dynamic LDS need the attribute once
+  if (!raised) {
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = true;
+  }
+  const int swz = (blocks % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline bool h16_ok(const void* p, int64_t ld) { return ld % 8 == 0 && rx_aligned16(p); }
+
+// ---- fp32 -> bf16 copies (activations entering the tower, per-use weight copies, optionally transposed)
+__global__ void __launch_bounds__(RX_BLOCK)
+to_bf16_kernel(const float* __restrict__ src, int64_t lds_, uint16_t* __restrict__ dst, int64_t ldd, int64_t rows, int cols) {
+  const int cq = (cols + 3) / 4;
+  const int64_t total = rows * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cq;
+    const int c = (int)(i - r * cq) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < cols) dst[r * ldd + c + e] = f32_to_bf16_rne(src[r * lds_ + c + e]);
+  }
+}
+
+// dst[c, r] = bf16(src[r, c]) through a 32 x 32 LDS tile (weights only: small)
+__global__ void __launch_bounds__(RX_BLOCK)
+to_bf16_t_kernel(const float* __restrict__ src, int64_t lds_, uint16_t* __restrict__ dst, int64_t ldd, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + ty + 8 * q, c = c0 + tx;
+    tile[ty + 8 * q][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + ty + 8 * q, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = f32_to_bf16_rne(tile[tx][ty + 8 * q]);
+  }
+}
+
+extern "C" int rx_to_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols,
+                          int transpose, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(rows >= 0 && cols >= 1 && ld_src >= cols && ld_dst >= (transpose ? rows : cols), "rx_to_bf16: bad shape");
+  if (rows == 0) return 0;
+  RX_REQUIRE(src && dst, "rx_to_bf16: null argument");
+  if (transpose) {
+    RX_REQUIRE(rows < (1 << 20), "rx_to_bf16: the transposing copy is for weight matrices (rows < 2^20)");
+    hipLaunchKernelGGL(to_bf16_t_kernel, dim3((unsigned)rx_cdiv(cols, 32), (unsigned)rx_cdiv(rows, 32)), dim3(RX_BLOCK), 0, (hipStream_t)stream,
+                       src, ld_src, dst, ld_dst, (int)rows, (int)cols);
+  } else {
+    int64_t grid = rx_cdiv(rows * ((cols + 3) / 4), RX_BLOCK);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows, (int)cols);
+  }
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- one output column (the tower's last layer) with bf16 activations: K / 8 lanes of 16 bytes per row
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ float round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_rne(v)); }
+
+template <int LPR>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv16_fwd_kernel(const uint16_t* __restrict__ X, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                  float* __restrict__ Y, int64_t ldy, int64_t M, int K, int act) {
+  constexpr int RL = RX_BLOCK / LPR;
+  const int cq = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int k0 = cq * 8;
+  const bool ok = k0 < K;
+  float wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wv[e] = ok ? round_bf16(w[k0 + e]) : 0.f;
+  const float bv = b ? b[0] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < M; r += (int64_t)gridDim.x * RL) {
+    const uint4 x = ok ? *reinterpret_cast<const uint4*>(X + r * ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += bf16_bits_to_f32(xs[e] & 0xffffu) * wv[2 * e] + bf16_bits_to_f32(xs[e] >> 16) * wv[2 * e + 1];
+#pragma unroll
+    for (int d = LPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (cq == 0) {
+      float v = s + bv;
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      Y[r * ldy] = v;
+    }
+  }
+}
+
+// dZ16[m, k] = gate(h16[m, k]) * bf16(dy16[m] * bf16(w[k]))  (gate may be null)
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv16_bwd_x_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const float* __restrict__ w, const uint16_t* __restrict__ gate,
+                    int64_t ldg, uint16_t* __restrict__ dZ, int64_t ldz, int64_t M, int K) {
+  const int kq = K / 8;
+  const int64_t total = M * kq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / kq;
+    const int k0 = (int)(i - m * kq) * 8;
+    const float gy = bf16_bits_to_f32(dY[m * ldd]);
+    uint4 gt = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    if (gate) gt = *reinterpret_cast<const uint4*>(gate + m * ldg + k0);
+    const uint32_t gs[4] = {gt.x, gt.y, gt.z, gt.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = gs[e] & 0xffffu, hi = gs[e] >> 16;
+      const float a = (lo != 0 && !(lo & 0x8000u)) ? gy * round_bf16(w[k0 + 2 * e]) : 0.f;
+      const float c = (hi != 0 && !(hi & 0x8000u)) ? gy * round_bf16(w[k0 + 2 * e + 1]) : 0.f;
+      o[e] = (uint32_t)f32_to_bf16_rne(a) | ((uint32_t)f32_to_bf16_rne(c) << 16);
+    }
+    *reinterpret_cast<uint4*>(dZ + m * ldz + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// slab z: part_w[z][k] = sum_m dy16[m] * X16[m, k], part_b[z] = sum_m dy16[m]
+template <int LPR>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv16_bwd_w_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const uint16_t* __restrict__ X, int64_t ldx, int64_t M, int K,
+                    int64_t rows_per_slab, float* __restrict__ part_w, float* __restrict__ part_b) {
+  constexpr int RL = RX_BLOCK / LPR;
+  __shared__ float red[RL][LPR * 8 + 1];
+  __shared__ float redb[RL];
+  const int cq = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int k0 = cq * 8;
+  const bool ok = k0 < K;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float sb = 0.f;
+  for (int64_t r = lo + rl; r < hi; r += RL) {
+    const uint4 x = ok ? *reinterpret_cast<const uint4*>(X + r * ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
+    const float gy = bf16_bits_to_f32(dY[r * ldd]);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s[2 * e] += gy * bf16_bits_to_f32(xs[e] & 0xffffu);
+      s[2 * e + 1] += gy * bf16_bits_to_f32(xs[e] >> 16);
+    }
+    sb += gy;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][k0 + e] = s[e];
+  if (cq == 0) redb[rl] = sb;
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += RX_BLOCK) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) t += red[q][k];
+    part_w[(int64_t)blockIdx.x * K + k] = t;
+  }
+  if (threadIdx.x == 0 && part_b) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) t += redb[q];
+    part_b[blockIdx.x] = t;
+  }
+}
+
+static inline int gemv16_lpr(int K) {
+  int l = 1;
+  while (l * 8 < K) l <<= 1;
+  return l;
+}
+static inline bool gemv16_ok(int32_t N, int32_t K) { return N == 1 && K % 8 == 0 && K >= 8 && K <= 512; }
+
+// ---- column sums of a bf16 matrix: partial[z][j]; a block covers 128 columns with 16 row lanes of 16-byte loads
+template <int DUMMY>
+__global__ void __launch_bounds__(RX_BLOCK)
+colsum16_slab_kernel(const uint16_t* __restrict__ dY, int64_t ldd, int64_t M, int N, int64_t rows_per_slab, float* __restrict__ partial) {
+  __shared__ float red[16][128 + 1];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int j0 = blockIdx.x * 128 + cq * 8;
+  const int64_t lo = (int64_t)blockIdx.z * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (j0 < N) {   // N % 8 == 0
+    int64_t r = lo + rl;
+    for (; r + 48 < hi; r += 64) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(dY + (r + 16 * u) * ldd + j0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t xs[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[2 * e] += bf16_bits_to_f32(xs[e] & 0xffffu); s[2 * e + 1] += bf16_bits_to_f32(xs[e] >> 16); }
+      }
+    }
+    for (; r < hi; r += 16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(dY + r * ldd + j0);
+      const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[2 * e] += bf16_bits_to_f32(xs[e] & 0xffffu); s[2 * e + 1] += bf16_bits_to_f32(xs[e] >> 16); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cq * 8 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    if (j < N) partial[(int64_t)blockIdx.z * N + j] = t;
+  }
+}
+
+extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* W, const float* b,
+                               void* Y, int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int out_bf16, int device,
+                               void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0 && ldx >= K && ldy >= N, "rx_linear16_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  RX_REQUIRE(act == 0 || act == 1, "rx_linear16_fwd: unknown activation %d", act);
+  if (M == 0) return 0;
+  RX_REQUIRE(X16 && Y && h16_ok(X16, ldx), "rx_linear16_fwd: null or unaligned activations");
+  hipStream_t st = (hipStream_t)stream;
+  if (gemv16_ok(N, K) && !out_bf16) {
+    RX_REQUIRE(W, "rx_linear16_fwd: the one-column layer reads the fp32 weights");
+    const int lpr = gemv16_lpr(K);
+    int64_t grid = rx_cdiv(M, RX_BLOCK / lpr);
+    if (grid > 4096) grid = 4096;
+    RX_GEMV_DISPATCH(gemv16_fwd_kernel, lpr, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, X16, ldx, W, b, (float*)Y, ldy, M, (int)K, act);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  RX_REQUIRE(W16 && rx_aligned16(W16), "rx_linear16_fwd: null or unaligned bf16 weights");
+  Gemm16Args g{};
+  g.A = X16; g.lda = ldx; g.B = W16; g.ldb = K; g.C = Y; g.ldc = ldy; g.bias = b;
+  g.M = M; g.N = N; g.K = K; g.act = act; g.k_per_slab = K;
+  return out_bf16 ? gemm_h16_launch<true, true, false, false>(g, 1, st) : gemm_h16_launch<true, false, false, false>(g, 1, st);
+}
+
+extern "C" int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16_t* W16T, const float* W, void* dX, int64_t ldx,
+                                 const uint16_t* gate16, int64_t ldg, int64_t M, int32_t N, int32_t K, int accumulate,
+                                 int out_bf16, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && N >= 1 && K >= 1 && ldd >= N && ldx >= K, "rx_linear16_bwd_x: bad shape");
+  RX_REQUIRE(!(accumulate && (out_bf16 || gate16)), "rx_linear16_bwd_x: accumulation is for ungated fp32 outputs");
+  RX_REQUIRE(!gate16 || out_bf16, "rx_linear16_bwd_x: the gated form writes bf16");
+  if (M == 0) return 0;
+  RX_REQUIRE(dY16 && dX, "rx_linear16_bwd_x: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (gemv16_ok(N, K) && out_bf16) {
+    RX_REQUIRE(W && h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg)), "rx_linear16_bwd_x: one-column layer: fp32 weights and aligned rows");
+    int64_t grid = rx_cdiv(M * (K / 8), RX_BLOCK);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gemv16_bwd_x_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, dY16, ldd, W, gate16, ldg, (uint16_t*)dX, ldx, M, (int)K);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  RX_REQUIRE(N % 8 == 0 && h16_ok(dY16, ldd) && W16T && rx_aligned16(W16T), "rx_linear16_bwd_x: N must be a multiple of 8, operands 16-byte aligned");
+  Gemm16Args g{};
+  g.A = dY16; g.lda = ldd; g.B = W16T; g.ldb = N; g.C = dX; g.ldc = ldx; g.bias = nullptr; g.gate = gate16; g.ldg = ldg;
+  g.M = M; g.N = K; g.K = N; g.act = 0; g.k_per_slab = N;
+  if (gate16) return gemm_h16_launch<true, true, true, false>(g, 1, st);
+  if (out_bf16) return gemm_h16_launch<true, true, false, false>(g, 1, st);
+  return accumulate ? gemm_h16_launch<true, false, false, true>(g, 1, st) : gemm_h16_launch<true, false, false, false>(g, 1, st);
+}
+
+static int bwd_w16_slabs(int64_t M, int32_t N, int32_t K) {
+  const int64_t tiles = rx_cdiv(N, 128) * rx_cdiv(K, 128);
+  int64_t want = rx_cdiv(768, tiles);
+  const int64_t max_by_rows = rx_cdiv(M, 2 * H_BK);
+  if (want > max_by_rows) want = max_by_rows;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+#define COLSUM16_SLABS 64
+extern "C" size_t rx_linear16_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N < 1 || K < 1) return 256;
+  const int s = bwd_w16_slabs(M, N, K);
+  const size_t bslabs = (size_t)(s > COLSUM16_SLABS ? s : COLSUM16_SLABS);
+  return rx_align_up((size_t)s * N * K * sizeof(float), 256) + rx_align_up(bslabs * N * sizeof(float), 256);
+}
+
+extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16_t* X16, int64_t ldx, float* dW, float* db,
+                                 int64_t M, int32_t N, int32_t K, void* ws, size_t ws_bytes, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 1 && N >= 1 && K >= 8 && K % 8 == 0 && ldd >= N && ldx >= K, "rx_linear16_bwd_w: bad shape");
+  RX_REQUIRE(dY16 && X16 && dW && ws && h16_ok(X16, ldx), "rx_linear16_bwd_w: null or unaligned argument");
+  RX_REQUIRE(ws_bytes >= rx_linear16_bwd_w_workspace_bytes(M, N, K), "rx_linear16_bwd_w: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int s = bwd_w16_slabs(M, N, K);
+  int64_t rows_per_slab = rx_cdiv(M, s);
+  rows_per_slab = rx_cdiv(rows_per_slab, H_BK) * H_BK;
+  const int n_slabs = (int)rx_cdiv(M, rows_per_slab);
+  float* slabs = (float*)ws;
+  float* bpart = (float*)((char*)ws + rx_align_up((size_t)s * N * K * sizeof(float), 256));
+  const int64_t nk = (int64_t)N * K;
+  if (gemv16_ok(N, K)) {
+    const int lpr = gemv16_lpr(K);
+    RX_GEMV_DISPATCH(gemv16_bwd_w_kernel, lpr, dim3((unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY16, ldd, X16, ldx, M, (int)K, rows_per_slab,
+                     slabs, db ? bpart : (float*)nullptr);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv((int64_t)K, 64) + (db ? 1 : 0))), dim3(RX_BLOCK), 0, st, slabs,
+                       (int64_t)K, n_slabs, dW, (const float*)bpart, (int64_t)(db ? 1 : 0), n_slabs, db);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
+  RX_REQUIRE(N % 8 == 0 && h16_ok(dY16, ldd), "rx_linear16_bwd_w: N must be a multiple of 8 and dY 16-byte aligned");
+  Gemm16Args g{};
+  g.A = dY16; g.lda = ldd; g.B = X16; g.ldb = ldx; g.C = slabs; g.ldc = K; g.bias = nullptr;
+  g.M = N; g.N = K; g.K = M; g.act = 0; g.k_per_slab = rows_per_slab; g.c_slab_stride = nk;
+  if (gemm_h16_launch<false, false, false, false>(g, n_slabs, st)) return 1;
+  int cs = 0;
+  if (db) {
+    int64_t cs_rows = rx_cdiv(M, COLSUM16_SLABS);
+    cs_rows = rx_cdiv(cs_rows, 16) * 16;
+    cs = (int)rx_cdiv(M, cs_rows);
+    hipLaunchKernelGGL(colsum16_slab_kernel<0>, dim3((unsigned)rx_cdiv(N, 128), 1, (unsigned)cs), dim3(RX_BLOCK), 0, st, dY16, ldd, M, (int)N, cs_rows, bpart);
+    RX_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv(nk, 64) + (db ? rx_cdiv(N, 64) : 0))), dim3(RX_BLOCK), 0, st, slabs, nk,
+                     n_slabs, dW, (const float*)bpart, (int64_t)(db ? N : 0), cs, db);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- DCN-v2 cross combine with the bf16 copies the matrix products read
+__global__ void __launch_bounds__(RX_BLOCK)
+cross16_fwd_kernel(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ u, int64_t ldu,
+                   const float* __restrict__ xl, int64_t ldl, float* __restrict__ xn, int64_t ldn,
+                   uint16_t* __restrict__ xn16, int64_t ldn16, int64_t rows, int cq) {
+  const int64_t n = rows * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cq;
+    const int c = (int)(i - r * cq) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(x0 + r * ld0 + c);
+    const float4 b = *reinterpret_cast<const float4*>(u + r * ldu + c);
+    const float4 d = *reinterpret_cast<const float4*>(xl + r * ldl + c);
+    const float4 o = make_float4(a.x * b.x + d.x, a.y * b.y + d.y, a.z * b.z + d.z, a.w * b.w + d.w);
+    *reinterpret_cast<float4*>(xn + r * ldn + c) = o;
+    *reinterpret_cast<uint2*>(xn16 + r * ldn16 + c) = make_uint2((uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16),
+                                                                 (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16));
+  }
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+cross16_bwd_kernel(const float* __restrict__ dxn, int64_t ldd, const float* __restrict__ x0, int64_t ld0,
+                   const float* __restrict__ u, int64_t ldu, uint16_t* __restrict__ du16, int64_t lddu,
+                   float* __restrict__ dx0_acc, int64_t ldx0, float* __restrict__ dxl, int64_t ldxl,
+                   int64_t rows, int cq, int accumulate, int identity) {
+  const int64_t n = rows * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cq;
+    const int c = (int)(i - r * cq) * 4;
+    const float4 d = *reinterpret_cast<const float4*>(dxn + r * ldd + c);
+    const float4 a = *reinterpret_cast<const float4*>(x0 + r * ld0 + c);
+    const float4 b = *reinterpret_cast<const float4*>(u + r * ldu + c);
+    *reinterpret_cast<uint2*>(du16 + r * lddu + c) = make_uint2((uint32_t)f32_to_bf16_rne(d.x * a.x) | ((uint32_t)f32_to_bf16_rne(d.y * a.y) << 16),
+                                                                (uint32_t)f32_to_bf16_rne(d.z * a.z) | ((uint32_t)f32_to_bf16_rne(d.w * a.w) << 16));
+    float4 g0 = make_float4(d.x * b.x, d.y * b.y, d.z * b.z, d.w * b.w);
+    if (identity) { g0.x += d.x; g0.y += d.y; g0.z += d.z; g0.w += d.w; }
+    float4* acc = reinterpret_cast<float4*>(dx0_acc + r * ldx0 + c);
+    if (accumulate) { const float4 o = *acc; g0.x += o.x; g0.y += o.y; g0.z += o.z; g0.w += o.w; }
+    *acc = g0;
+    if (dxl) *reinterpret_cast<float4*>(dxl + r * ldxl + c) = d;
+  }
+}
+
+static inline bool f4_ok(const void* p, int64_t ld) { return ld % 4 == 0 && rx_aligned16(p); }
+
+extern "C" int rx_cross16_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* xl, int64_t ldl,
+                              float* xn, int64_t ldn, uint16_t* xn16, int64_t ldn16, int64_t rows, int32_t cols, int device,
+                              void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(rows >= 0 && cols >= 4 && cols % 4 == 0 && ld0 >= cols && ldu >= cols && ldl >= cols && ldn >= cols && ldn16 >= cols,
+             "rx_cross16_fwd: bad shape (cols a multiple of 4)");
+  if (rows == 0) return 0;
+  RX_REQUIRE(x0 && u && xl && xn && xn16, "rx_cross16_fwd: null argument");
+  RX_REQUIRE(f4_ok(x0, ld0) && f4_ok(u, ldu) && f4_ok(xl, ldl) && f4_ok(xn, ldn) && ldn16 % 4 == 0 && ((uintptr_t)xn16 % 8 == 0),
+             "rx_cross16_fwd: rows must be 16-byte addressable");
+  int64_t grid = rx_cdiv(rows * (cols / 4), RX_BLOCK);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cross16_fwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, x0, ld0, u, ldu, xl, ldl, xn, ldn,
+                     xn16, ldn16, rows, (int)(cols / 4));
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_cross16_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u, int64_t ldu,
+                              uint16_t* du16, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl, int64_t ldxl,
+                              int64_t rows, int32_t cols, int accumulate, int identity, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(rows >= 0 && cols >= 4 && cols % 4 == 0 && ldd >= cols && ld0 >= cols && ldu >= cols && lddu >= cols && ldx0 >= cols &&
+                 (!dxl || ldxl >= cols), "rx_cross16_bwd: bad shape (cols a multiple of 4)");
+  if (rows == 0) return 0;
+  RX_REQUIRE(dxn && x0 && u && du16 && dx0_acc, "rx_cross16_bwd: null argument");
+  RX_REQUIRE(f4_ok(dxn, ldd) && f4_ok(x0, ld0) && f4_ok(u, ldu) && f4_ok(dx0_acc, ldx0) && (!dxl || f4_ok(dxl, ldxl)) && lddu % 4 == 0 &&
+                 ((uintptr_t)du16 % 8 == 0), "rx_cross16_bwd: rows must be 16-byte addressable");
+  int64_t grid = rx_cdiv(rows * (cols / 4), RX_BLOCK);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(cross16_bwd_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dxn, ldd, x0, ld0, u, ldu, du16, lddu,
+                     dx0_acc, ldx0, dxl, ldxl, rows, (int)(cols / 4), accumulate, identity);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,6 +1,8 @@
 """Shared pieces of the drop-in modules."""
 from __future__ import annotations
 
+import os
+
 from typing import Iterator, List
 
 import torch
@@ -56,11 +58,30 @@ def as_index(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
-def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False) -> Tensor:
+def _relu_chain(mods):
+    """The Linear layers of a [Linear, ReLU] * n + [Linear] stack, or None for any other stack."""
+    if len(mods) % 2 == 0:
+        return None
+    for i, m in enumerate(mods):
+        if not isinstance(m, nn.Linear if i % 2 == 0 else nn.ReLU):
+            return None
+    return mods[0::2]
+
+
+def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = None) -> Tensor:
     """Evaluate a Linear/(BatchNorm1d)/ReLU/Dropout stack.  Linear (+ a directly following ReLU)
     goes through the MFMA GEMM with the ReLU fused into its epilogue; BatchNorm1d with the ReLU and
-    Dropout behind it is one fused normalisation (rx_bn_*); anything else runs as the torch module."""
+    Dropout behind it is one fused normalisation (rx_bn_*); anything else runs as the torch module.
+    With ``bf16`` a pure Linear/ReLU stack of suitable widths runs as one node that keeps its
+    activations in bf16 in HBM (autograd.MLPStack16; ``x16``: a bf16 copy of ``x`` if the producer
+    made one); RX_NO_BF16_STORAGE=1 keeps fp32 storage."""
     mods = list(seq)
+    chain = _relu_chain(mods) if bf16 and os.environ.get("RX_NO_BF16_STORAGE") != "1" else None
+    if chain is not None and rxa.h16_shapes_ok(x, [m.weight for m in chain]):
+        wb = []
+        for m in chain:
+            wb += [m.weight, m.bias]
+        return rxa.MLPStack16.apply(x, x16, *wb)
     i = 0
     while i < len(mods):
         m = mods[i]

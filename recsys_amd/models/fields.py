@@ -11,6 +11,8 @@ N = 1, so the same rx_fm2 kernels serve both shapes.  Tower input column order:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Sequence
 
 import torch
@@ -170,5 +172,13 @@ class DCNv2(_FieldTable):
                               d_emb + self.n_dense + self.pad, False,
                               _dense_input(inputs, self.n_dense, ex.shape[0], self.pad), inputs.get("_rx_presort"),
                               self._field_base)
+        if (self.bf16 and len(self.cross) and os.environ.get("RX_NO_BF16_STORAGE") != "1"
+                and rxa.h16_shapes_ok(x0, [m.weight for m in self.cross])):
+            # operands of every product kept as bf16 copies in HBM (same rounding, half the bytes)
+            wb = []
+            for m in self.cross:
+                wb += [m.weight, m.bias]
+            x, x16 = rxa.CrossStack16.apply(x0, *wb)
+            return run_tower(self.mlp, x, bf16=True, x16=x16)
         x = rxa.cross_stack(x0, self.cross, self.bf16) if len(self.cross) else x0
         return run_tower(self.mlp, x, bf16=self.bf16)

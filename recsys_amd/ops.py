@@ -1091,3 +1091,110 @@ def run_tower(seq, x: Tensor, bf16: bool = False) -> Tensor:
     """An nn.Sequential tower (Linear / BatchNorm1d / ReLU / Dropout) through the dense-layer kernels."""
     from .models.base import run_tower as _run
     return _run(seq, x, bf16=bf16)
+
+
+# ------------------------------------------------------------------ dense layers with bf16 activations in HBM
+def _mat16(t: Tensor, name: str) -> Tuple[Tensor, int]:
+    """2-D bfloat16 with unit inner stride and 16-byte addressable rows."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2):
+        raise TypeError(f"{name}: expected a 2-D bfloat16 GPU tensor")
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        raise ValueError(f"{name}: inner stride must be 1")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t, ld
+
+
+def _padded16(rows: int, cols: int, device) -> Tensor:
+    """bf16 [rows, cols] whose row stride is a multiple of 8 elements (16 bytes)."""
+    cp = (cols + 7) // 8 * 8
+    buf = torch.empty(rows, cp, dtype=torch.bfloat16, device=device)
+    return buf if cp == cols else buf[:, :cols]
+
+
+def to_bf16(x: Tensor, transpose: bool = False) -> Tensor:
+    """rx_to_bf16: round an fp32 matrix to bf16 (nearest even); ``transpose`` for weight matrices."""
+    x, ldx = _mat(x, "x")
+    rows, cols = x.shape
+    out = _padded16(cols, rows, x.device) if transpose else _padded16(rows, cols, x.device)
+    _, ldo = _mat16(out, "out")
+    check(lib.rx_to_bf16(_p(x), ldx, _p(out), ldo, rows, cols, int(transpose), _dev(x), _stream(x)), "rx_to_bf16")
+    return out
+
+
+def linear16_fwd(x16: Tensor, w: Tensor, b: Optional[Tensor], relu: bool, out_bf16: bool, w16: Optional[Tensor] = None) -> Tensor:
+    """act(x16 w^T + b) from bf16 activations; ``w`` the fp32 weight [N, K] (its bf16 copy is made
+    here unless ``w16`` is passed).  Output bf16 (feeds the next layer) or fp32."""
+    x16, ldx = _mat16(x16, "x16")
+    _req(w, torch.float32, "weight", 2)
+    M, K = x16.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear16: x is [{M},{K}] but weight is {tuple(w.shape)}")
+    if b is not None:
+        _req(b, torch.float32, "bias", 1)
+    if N > 1 or out_bf16:
+        w16 = w16 if w16 is not None else to_bf16(w)
+    out = _padded16(M, N, x16.device) if out_bf16 else _padded(M, N, x16.device)
+    ldy = out.stride(0) if M > 1 else max(N, out.stride(0))
+    check(lib.rx_linear16_fwd(_p(x16), ldx, _p(w16), _p(w), _p(b), _p(out), ldy, M, N, K, int(relu), int(out_bf16),
+                              _dev(x16), _stream(x16)), "rx_linear16_fwd")
+    return out
+
+
+def linear16_bwd_x(dy16: Tensor, w: Tensor, gate16: Optional[Tensor] = None, out_bf16: bool = False,
+                   out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """dX = dY16 W; bf16 output with the ReLU gate of the layer in front (``gate16`` = its bf16
+    output) or fp32 output, optionally accumulated into ``out``."""
+    dy16, ldd = _mat16(dy16, "dy16")
+    _req(w, torch.float32, "weight", 2)
+    M, N = dy16.shape
+    K = w.shape[1]
+    w16t = to_bf16(w, transpose=True) if N > 1 else None
+    ldg = 0
+    if gate16 is not None:
+        gate16, ldg = _mat16(gate16, "gate16")
+    if out is None:
+        out = _padded16(M, K, dy16.device) if out_bf16 else _padded(M, K, dy16.device)
+    ldx = out.stride(0) if M > 1 else max(K, out.stride(0))
+    check(lib.rx_linear16_bwd_x(_p(dy16), ldd, _p(w16t), _p(w), _p(out), ldx, _p(gate16), ldg, M, N, K, int(accumulate),
+                                int(out_bf16), _dev(dy16), _stream(dy16)), "rx_linear16_bwd_x")
+    return out
+
+
+def linear16_bwd_w(dy16: Tensor, x16: Tensor, want_bias: bool = True):
+    dy16, ldd = _mat16(dy16, "dy16")
+    x16, ldx = _mat16(x16, "x16")
+    M, N = dy16.shape
+    K = x16.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy16.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy16.device) if want_bias else None
+    ws = _ws(int(lib.rx_linear16_bwd_w_workspace_bytes(M, N, K)), dy16.device)
+    check(lib.rx_linear16_bwd_w(_p(dy16), ldd, _p(x16), ldx, _p(dw), _p(db), M, N, K, _p(ws), ws.numel(), _dev(dy16),
+                                _stream(dy16)), "rx_linear16_bwd_w")
+    return dw, db
+
+
+def cross16_fwd(x0, u, xl):
+    """x_next = x0 * u + x_l: (fp32, its bf16 copy)."""
+    x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u"); xl, ldl = _mat(xl, "xl")
+    rows, cols = x0.shape
+    xn = _padded(rows, cols, x0.device)
+    xn16 = _padded16(rows, cols, x0.device)
+    check(lib.rx_cross16_fwd(_p(x0), ld0, _p(u), ldu, _p(xl), ldl, _p(xn), xn.stride(0), _p(xn16), xn16.stride(0), rows, cols,
+                             _dev(x0), _stream(x0)), "rx_cross16_fwd")
+    return xn, xn16
+
+
+def cross16_bwd(dxn, x0, u, dx0_acc, accumulate: bool, identity: bool, want_dxl: bool):
+    """cross_combine_bwd_stack with du written as bf16 only.  Returns (du16, dxl or None)."""
+    dxn, ldd = _mat(dxn, "dxn"); x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u")
+    dx0_acc, ldx0 = _mat(dx0_acc, "dx0")
+    rows, cols = dxn.shape
+    du16 = _padded16(rows, cols, dxn.device)
+    dxl, ldxl = None, 0
+    if want_dxl:
+        dxl = _padded(rows, cols, dxn.device)
+        ldxl = dxl.stride(0)
+    check(lib.rx_cross16_bwd(_p(dxn), ldd, _p(x0), ld0, _p(u), ldu, _p(du16), du16.stride(0), _p(dx0_acc), ldx0, _p(dxl), ldxl,
+                             rows, cols, int(accumulate), int(identity), _dev(dxn), _stream(dxn)), "rx_cross16_bwd")
+    return du16, dxl

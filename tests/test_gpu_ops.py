@@ -635,3 +635,81 @@ def test_bce_gradient_at_exactly_zero_logits(ops):
     ref.backward()
     assert abs(loss.item() - ref.item()) <= 1e-7 * abs(ref.item())
     assert torch.allclose(dl.cpu(), xr.grad, rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------ dense layers with bf16 activations in HBM
+def _r16(t):
+    return t.bfloat16().float()
+
+
+def test_to_bf16_and_transposed_copy(ops):
+    g = _gen(3)
+    x = torch.randn(301, 432, generator=g).cuda()
+    assert torch.equal(ops.to_bf16(x), x.bfloat16())
+    w = torch.randn(107, 216, generator=g).cuda()
+    assert torch.equal(ops.to_bf16(w, transpose=True), w.t().contiguous().bfloat16())
+    view = torch.randn(64, 440, generator=g).cuda()[:, :432]          # a column block of a wider matrix
+    assert torch.equal(ops.to_bf16(view), view.bfloat16())
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 432, 432), (513, 104, 216), (4096, 1024, 432), (130, 256, 512), (129, 8, 8),
+                                   (300, 1, 256), (4097, 1, 64)])
+def test_linear16_matches_products_of_the_rounded_operands(ops, M, N, K):
+    """Forward (bf16 and fp32 output, bias, ReLU), input gradient (fp32, accumulated, and bf16 with the
+    ReLU gate) and weight gradient + column sums against fp64 products of the bf16-rounded operands."""
+    g = _gen(M + N + K)
+    x16 = torch.randn(M, K, generator=g).bfloat16()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = x16.double() @ _r16(w).double().t() + b.double()
+    y32 = ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=False, out_bf16=False)
+    assert y32.dtype == torch.float32
+    assert_close(y32.cpu().numpy(), ref.numpy(), rtol=1e-5, what="linear16 fwd fp32")
+    if N > 1:
+        y16 = ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=True, out_bf16=True)
+        assert y16.dtype == torch.bfloat16
+        # one bf16 rounding of the fp32 result: within half a bf16 ulp (2^-9) of the exact value
+        assert_close(y16.float().cpu().numpy(), ref.relu().numpy(), rtol=2.0 ** -8, what="linear16 fwd bf16", elem_rtol=False)
+        assert torch.equal(y16.cpu(), ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=True, out_bf16=False).bfloat16().cpu())
+    dy16 = torch.randn(M, N, generator=g).bfloat16()
+    refx = dy16.double() @ _r16(w).double()
+    if N > 1:
+        dx = ops.linear16_bwd_x(dy16.cuda(), w.cuda(), out_bf16=False)
+        assert_close(dx.cpu().numpy(), refx.numpy(), rtol=1e-5, what="linear16 bwd x")
+        base = torch.randn(M, K, generator=g)
+        acc = base.clone().cuda()
+        ops.linear16_bwd_x(dy16.cuda(), w.cuda(), out=acc, accumulate=True)
+        assert_close(acc.cpu().numpy(), (base.double() + refx).numpy(), rtol=1e-5, what="linear16 bwd x accumulated")
+    gate = torch.randn(M, K, generator=g).relu().bfloat16()
+    gate[0, 0] = -0.0
+    dz = ops.linear16_bwd_x(dy16.cuda(), w.cuda(), gate16=gate.cuda(), out_bf16=True)
+    expz = torch.where(gate.float() > 0, refx, torch.zeros_like(refx))
+    assert dz.dtype == torch.bfloat16
+    assert_close(dz.float().cpu().numpy(), expz.numpy(), rtol=2.0 ** -8, what="linear16 bwd x gated", elem_rtol=False)
+    assert not dz.float().cpu()[gate.float() <= 0].any()
+    dw, db = ops.linear16_bwd_w(dy16.cuda(), x16.cuda(), True)
+    assert_close(dw.cpu().numpy(), (dy16.double().t() @ x16.double()).numpy(), rtol=1e-5, what="linear16 bwd w")
+    assert_close(db.cpu().numpy(), dy16.double().sum(0).numpy(), rtol=1e-5, what="linear16 bias grad")
+    dw2, _ = ops.linear16_bwd_w(dy16.cuda(), x16.cuda(), True)
+    assert torch.equal(dw, dw2)
+
+
+def test_cross16_combine_matches_torch(ops):
+    g = _gen(11)
+    rows, cols = 777, 432
+    x0, u, xl, d = (torch.randn(rows, cols, generator=g).cuda() for _ in range(4))
+    xn, xn16 = ops.cross16_fwd(x0, u, xl)
+    exp = x0 * u + xl
+    assert torch.equal(xn, exp) and torch.equal(xn16, exp.bfloat16())
+    for accumulate, identity, want in ((False, False, True), (True, False, False), (True, True, False)):
+        acc0 = torch.randn(rows, cols, generator=g).cuda()
+        acc = acc0.clone()
+        du16, dxl = ops.cross16_bwd(d, x0, u, acc, accumulate=accumulate, identity=identity, want_dxl=want)
+        assert torch.equal(du16, (d * x0).bfloat16())
+        g0 = d * u
+        if identity:
+            g0 = g0 + d
+        if accumulate:
+            g0 = g0 + acc0
+        assert torch.equal(acc, g0)
+        assert (dxl is None) == (not want) and (dxl is None or torch.equal(dxl, d))
