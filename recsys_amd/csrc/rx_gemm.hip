@@ -1182,6 +1182,7 @@ extern "C" int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const f
 #define H_LDK (H_BK + 8)
 #define H_T 128
 #define H_LDR (H_T + 32)
+#define H_LDC (H_T + 8)   // fp32 image of the output tile: rows 4 apart land 32 banks apart
 
 struct Gemm16Args {
   const uint16_t* A; int64_t lda;   // K-contiguous: A(i,k) = A[i*lda + k]; else A(i,k) = A[k*lda + i]
@@ -1323,31 +1324,76 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
     cur ^= 1;
   }
 
-  // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: the accumulators (C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) go
+  // through an fp32 LDS image of the tile, so that the output, the gate and the accumulate operand
+  // are all touched as whole 16-byte pieces of contiguous rows
+  float* ct = reinterpret_cast<float*>(h_lds);
   const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t col = n0 + (wave_n * 2 + j) * 32 + l31;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + (wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      for (int r = 0; r < 16; ++r)
+        ct[((wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * H_LDC + (wave_n * 2 + j) * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  if constexpr (OUT16) {
+    // 8 columns per thread: 16 threads per row, 16 rows per pass
+    const int c8 = (tid & 15) * 8;
+    const int64_t col = n0 + c8;
+    if (col < g.N) {   // N % 8 == 0: a piece is whole or absent
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = g.bias ? g.bias[col + e] : 0.f;
+      uint16_t* C16 = reinterpret_cast<uint16_t*>(g.C);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int rr = (tid >> 4) + 16 * p;
+        const int64_t row = m0 + rr;
         if (row >= g.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        const float4 lo = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8]);
+        const float4 hi = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8 + 4]);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t gs[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
         if constexpr (GATE) {
-          const uint16_t gt = g.gate[row * g.ldg + col];
-          if (gt == 0 || (gt & 0x8000u)) v = 0.f;
+          const uint4 gt = *reinterpret_cast<const uint4*>(g.gate + row * g.ldg + col);
+          gs[0] = gt.x; gs[1] = gt.y; gs[2] = gt.z; gs[3] = gt.w;
         }
-        if constexpr (OUT16) {
-          reinterpret_cast<uint16_t*>(g.C)[row * g.ldc + col] = f32_to_bf16_rne(v);
-        } else {
-          float* dst = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride + row * g.ldc + col;
-          *dst = ACCUM ? (*dst + v) : v;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = v[2 * e] + bv[2 * e], c = v[2 * e + 1] + bv[2 * e + 1];
+          if (g.act == 1) { a = a > 0.f ? a : 0.f; c = c > 0.f ? c : 0.f; }
+          if constexpr (GATE) {
+            const uint32_t glo = gs[e] & 0xffffu, ghi = gs[e] >> 16;
+            if (glo == 0 || (glo & 0x8000u)) a = 0.f;
+            if (ghi == 0 || (ghi & 0x8000u)) c = 0.f;
+          }
+          o[e] = (uint32_t)f32_to_bf16_rne(a) | ((uint32_t)f32_to_bf16_rne(c) << 16);
         }
+        *reinterpret_cast<uint4*>(C16 + row * g.ldc + col) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  } else {
+    // 4 columns per thread: 32 threads per row, 8 rows per pass.  ldc % 4 == 0 here; a weight-gradient
+    // slab has N % 8 == 0, the other fp32 outputs N % 4 == 0 (checked by the callers)
+    const int c4 = (tid & 31) * 4;
+    const int64_t col = n0 + c4;
+    if (col < g.N) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+      float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int rr = (tid >> 5) + 8 * p;
+        const int64_t row = m0 + rr;
+        if (row >= g.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c4]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (g.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        float4* dst = reinterpret_cast<float4*>(Cf + row * g.ldc + col);
+        if constexpr (ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
       }
     }
   }
@@ -1374,6 +1420,7 @@ static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
 }
 
 static inline bool h16_ok(const void* p, int64_t ld) { return ld % 8 == 0 && rx_aligned16(p); }
+static inline bool f4_ok(const void* p, int64_t ld) { return ld % 4 == 0 && rx_aligned16(p); }
 
 // ---- fp32 -> bf16 copies (activations entering the tower, per-use weight copies, optionally transposed)
 __global__ void __launch_bounds__(RX_BLOCK)
@@ -1596,6 +1643,8 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
     return 0;
   }
   RX_REQUIRE(W16 && rx_aligned16(W16), "rx_linear16_fwd: null or unaligned bf16 weights");
+  RX_REQUIRE(out_bf16 ? (N % 8 == 0 && h16_ok(Y, ldy)) : (N % 4 == 0 && f4_ok(Y, ldy)),
+             "rx_linear16_fwd: output rows must be whole 16-byte pieces (N a multiple of 8 for bf16, 4 for fp32)");
   Gemm16Args g{};
   g.A = X16; g.lda = ldx; g.B = W16; g.ldb = K; g.C = Y; g.ldc = ldy; g.bias = b;
   g.M = M; g.N = N; g.K = K; g.act = act; g.k_per_slab = K;
@@ -1621,6 +1670,8 @@ extern "C" int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16
     return 0;
   }
   RX_REQUIRE(N % 8 == 0 && h16_ok(dY16, ldd) && W16T && rx_aligned16(W16T), "rx_linear16_bwd_x: N must be a multiple of 8, operands 16-byte aligned");
+  RX_REQUIRE(out_bf16 ? (K % 8 == 0 && h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg))) : (K % 4 == 0 && f4_ok(dX, ldx)),
+             "rx_linear16_bwd_x: output (and gate) rows must be whole 16-byte pieces");
   Gemm16Args g{};
   g.A = dY16; g.lda = ldd; g.B = W16T; g.ldb = N; g.C = dX; g.ldc = ldx; g.bias = nullptr; g.gate = gate16; g.ldg = ldg;
   g.M = M; g.N = K; g.K = N; g.act = 0; g.k_per_slab = N;
@@ -1731,8 +1782,6 @@ cross16_bwd_kernel(const float* __restrict__ dxn, int64_t ldd, const float* __re
     if (dxl) *reinterpret_cast<float4*>(dxl + r * ldxl + c) = d;
   }
 }
-
-static inline bool f4_ok(const void* p, int64_t ld) { return ld % 4 == 0 && rx_aligned16(p); }
 
 extern "C" int rx_cross16_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* xl, int64_t ldl,
                               float* xn, int64_t ldn, uint16_t* xn16, int64_t ldn16, int64_t rows, int32_t cols, int device,
