@@ -575,7 +575,10 @@ int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, i
  *   rx_linear16_bwd_w  dW = dY16^T X16 (slabs over the batch, summed in slab order), db = column
  *                      sums of dY16 (may be NULL)
  *   rx_cross16_fwd     x_next = x0 * u + x_l in fp32 plus its bf16 copy (operand of the next products)
- *   rx_cross16_bwd     rx_cross_combine_bwd_stack with du = d * x0 written as bf16 only */
+ *   rx_cross16_bwd     rx_cross_combine_bwd_stack with du = d * x0 written as bf16 only
+ *   rx_cross16_layer_fwd  one whole cross layer in one launch: u = X16 W16^T + b (kept, the backward
+ *                      needs it) and, in the same epilogue, x_next = x0 * u + x_l with its bf16 copy;
+ *                      bit for bit rx_linear16_fwd followed by rx_cross16_fwd */
 int rx_to_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols,
                int transpose, int device, void* stream);
 int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* W, const float* b,
@@ -590,6 +593,9 @@ int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16_t* X16, in
 int rx_cross16_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* xl, int64_t ldl,
                    float* xn, int64_t ldn, uint16_t* xn16, int64_t ldn16, int64_t rows, int32_t cols, int device,
                    void* stream);
+int rx_cross16_layer_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* b, const float* x0,
+                         int64_t ld0, const float* xl, int64_t ldl, float* u, int64_t ldu, float* xn, int64_t ldn,
+                         uint16_t* xn16, int64_t ldn16, int64_t M, int32_t d, int device, void* stream);
 int rx_cross16_bwd(const float* dxn, int64_t ldd, const float* x0, int64_t ld0, const float* u, int64_t ldu,
                    uint16_t* du16, int64_t lddu, float* dx0_acc, int64_t ldx0, float* dxl, int64_t ldxl,
                    int64_t rows, int32_t cols, int accumulate, int identity, int device, void* stream);

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "rx_linear16_bwd_w_workspace_bytes": (sz, [i64, i32, i32]),
     "rx_linear16_bwd_w": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, vp, sz, C.c_int, vp]),
     "rx_cross16_fwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
+    "rx_cross16_layer_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_cross16_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_sample_negatives": (C.c_int, [vp, vp, vp, i64, i64, i32, i32, C.c_uint64, vp, vp, vp, C.c_int, vp]),
     "rx_dense_adam_dstep": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, vp, C.c_int, vp]),

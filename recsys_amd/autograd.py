@@ -503,9 +503,12 @@ class CrossStack16(Function):
         x16 = ops.to_bf16(x0)
         xs16, us, x = [x16], [], x0
         for w, b in zip(ws, bs):
-            u = ops.linear16_fwd(xs16[-1], w, b, relu=False, out_bf16=False)
+            if b is not None and x.shape[0] > 1:
+                u, x, xn16 = ops.cross16_layer_fwd(xs16[-1], w, b, x0, x)     # product + combine in one launch
+            else:
+                u = ops.linear16_fwd(xs16[-1], w, b, relu=False, out_bf16=False)
+                x, xn16 = ops.cross16_fwd(x0, u, x)
             us.append(u)
-            x, xn16 = ops.cross16_fwd(x0, u, x)
             xs16.append(xn16)
         ctx.save_for_backward(x0, *xs16[:-1], *us, *ws)
         ctx.L = len(ws)

@@ -1194,6 +1194,11 @@ struct Gemm16Args {
   int act;
   int64_t k_per_slab, c_slab_stride;
   int tiles_n;
+  // cross-layer epilogue: with u = A B + bias written to C, also x_next = x0 * u + xl (fp32 and bf16)
+  const float* x0; int64_t ld0;
+  const float* xl; int64_t ldl;
+  float* xn; int64_t ldn;
+  uint16_t* xn16; int64_t ldn16;
 };
 
 struct HRegs { uint4 v[4]; };
@@ -1255,7 +1260,7 @@ __device__ __forceinline__ bf16x8 h_frag(const uint16_t* lds, int base, int ks, 
 
 // KC: both operands K-contiguous (forward, input gradient); !KC: both contiguous along the output
 // dimensions (weight gradient, K = batch, slabs over blockIdx.z, fp32 output only)
-template <bool KC, bool OUT16, bool GATE, bool ACCUM>
+template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false>
 __global__ void __launch_bounds__(RX_BLOCK)
 gemm_h16_kernel(Gemm16Args g, int swizzle) {
   constexpr int OP_SZ = KC ? H_T * H_LDK : H_BK * H_LDR;
@@ -1394,6 +1399,15 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
         float4* dst = reinterpret_cast<float4*>(Cf + row * g.ldc + col);
         if constexpr (ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
+        if constexpr (CROSS) {   // the DCN-v2 combine on the tile just produced: x_next = x0 * u + x_l
+          const float4 a = *reinterpret_cast<const float4*>(g.x0 + row * g.ld0 + col);
+          const float4 d = *reinterpret_cast<const float4*>(g.xl + row * g.ldl + col);
+          const float4 o = make_float4(a.x * v.x + d.x, a.y * v.y + d.y, a.z * v.z + d.z, a.w * v.w + d.w);
+          *reinterpret_cast<float4*>(g.xn + row * g.ldn + col) = o;
+          *reinterpret_cast<uint2*>(g.xn16 + row * g.ldn16 + col) =
+              make_uint2((uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16),
+                         (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16));
+        }
       }
     }
   }
@@ -1401,7 +1415,7 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
 
 #define H_LDS_BYTES(KC_) ((size_t)2 * 2 * ((KC_) ? H_T * H_LDK : H_BK * H_LDR) * sizeof(uint16_t))
 
-template <bool KC, bool OUT16, bool GATE, bool ACCUM>
+template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false>
 static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
   g.tiles_n = (int)rx_cdiv(g.N, H_T);
   const int64_t blocks = rx_cdiv(g.M, H_T) * g.tiles_n;
@@ -1409,12 +1423,12 @@ static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
   const size_t lds = H_LDS_BYTES(KC);
   static bool raised = false;   // per instantiation: 72 KB / 80 KB of dynamic LDS need the attribute once
   if (!raised) {
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM>),
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = true;
   }
   const int swz = (blocks % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);
+  hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -1649,6 +1663,23 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
   g.A = X16; g.lda = ldx; g.B = W16; g.ldb = K; g.C = Y; g.ldc = ldy; g.bias = b;
   g.M = M; g.N = N; g.K = K; g.act = act; g.k_per_slab = K;
   return out_bf16 ? gemm_h16_launch<true, true, false, false>(g, 1, st) : gemm_h16_launch<true, false, false, false>(g, 1, st);
+}
+
+extern "C" int rx_cross16_layer_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* b, const float* x0,
+                                    int64_t ld0, const float* xl, int64_t ldl, float* u, int64_t ldu, float* xn, int64_t ldn,
+                                    uint16_t* xn16, int64_t ldn16, int64_t M, int32_t d, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && d >= 8 && d % 8 == 0 && ldx >= d && ld0 >= d && ldl >= d && ldu >= d && ldn >= d && ldn16 >= d,
+             "rx_cross16_layer_fwd: bad shape (width a multiple of 8)");
+  if (M == 0) return 0;
+  RX_REQUIRE(X16 && W16 && x0 && xl && u && xn && xn16, "rx_cross16_layer_fwd: null argument");
+  RX_REQUIRE(h16_ok(X16, ldx) && rx_aligned16(W16) && f4_ok(x0, ld0) && f4_ok(xl, ldl) && f4_ok(u, ldu) && f4_ok(xn, ldn) &&
+                 ldn16 % 4 == 0 && ((uintptr_t)xn16 % 8 == 0), "rx_cross16_layer_fwd: rows must be 16-byte addressable");
+  Gemm16Args g{};
+  g.A = X16; g.lda = ldx; g.B = W16; g.ldb = d; g.C = u; g.ldc = ldu; g.bias = b;
+  g.M = M; g.N = d; g.K = d; g.act = 0; g.k_per_slab = d;
+  g.x0 = x0; g.ld0 = ld0; g.xl = xl; g.ldl = ldl; g.xn = xn; g.ldn = ldn; g.xn16 = xn16; g.ldn16 = ldn16;
+  return gemm_h16_launch<true, false, false, false, true>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16_t* W16T, const float* W, void* dX, int64_t ldx,

@@ -1185,6 +1185,22 @@ def cross16_fwd(x0, u, xl):
     return xn, xn16
 
 
+def cross16_layer_fwd(x16: Tensor, w: Tensor, b: Tensor, x0: Tensor, xl: Tensor):
+    """One cross layer in one launch: returns (u, x_next, x_next16) with u = x16 w^T + b and
+    x_next = x0 * u + x_l (rx_cross16_layer_fwd)."""
+    x16, ldx = _mat16(x16, "x16")
+    x0, ld0 = _mat(x0, "x0"); xl, ldl = _mat(xl, "xl")
+    _req(w, torch.float32, "weight", 2); _req(b, torch.float32, "bias", 1)
+    M, d = x16.shape
+    if tuple(w.shape) != (d, d) or tuple(x0.shape) != (M, d) or tuple(xl.shape) != (M, d):
+        raise ValueError("cross16_layer_fwd: a cross layer is square and x0 / x_l have the input's shape")
+    w16 = to_bf16(w)
+    u, xn, xn16 = _padded(M, d, x16.device), _padded(M, d, x16.device), _padded16(M, d, x16.device)
+    check(lib.rx_cross16_layer_fwd(_p(x16), ldx, _p(w16), _p(b), _p(x0), ld0, _p(xl), ldl, _p(u), u.stride(0), _p(xn), xn.stride(0),
+                                   _p(xn16), xn16.stride(0), M, d, _dev(x16), _stream(x16)), "rx_cross16_layer_fwd")
+    return u, xn, xn16
+
+
 def cross16_bwd(dxn, x0, u, dx0_acc, accumulate: bool, identity: bool, want_dxl: bool):
     """cross_combine_bwd_stack with du written as bf16 only.  Returns (du16, dxl or None)."""
     dxn, ldd = _mat(dxn, "dxn"); x0, ld0 = _mat(x0, "x0"); u, ldu = _mat(u, "u")

@@ -191,6 +191,45 @@ def test_reduce_modes_match_an_fp64_scatter_add(dim, with_deep):
             assert_close(wa, (table.double() - lr * 0.37 * Gref).float(), rtol=1e-5, what="scaled sgd")
 
 
+def test_two_backward_passes_before_one_clipped_step():
+    """Gradient accumulation over two batches with a clip: both pending row updates reach the table
+    one after the other, equal to two sequential dense updates with the common clip factor."""
+    from recsys_amd import synthetic
+    from recsys_amd.models import fields
+    from recsys_amd.optim import FusedOptimizer
+    dims = [7, 1000, 13, 5000, 3, 211]
+    torch.manual_seed(0)
+    m = fields.FieldFM(dims, 16).cuda()
+    w0, b0 = m.feature_embedding.weight.detach().clone(), m.bias_embedding.weight.detach().clone()
+    batches = [synthetic.criteo_batch(dims, 700, seed=s, device="cuda") for s in (1, 2)]
+    opt = FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=0.05)
+    opt.zero_grad()
+    for b in batches:
+        m.loss(b).backward()
+    opt.step()
+    # restatement: dense gradients of both batches, the optimizer's norm (the two gradients counted
+    # separately, as its partial sums do), both updates applied with that factor
+    offs = torch.tensor([0] + dims[:-1], device="cuda").cumsum(0)
+    grads = []
+    for b in batches:
+        wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        idx = b["sparse"] + offs[None, :]
+        e = wr[idx]
+        s = e.sum(1)
+        logits = br[idx].sum(1) + 0.5 * (s * s - (e * e).sum(1)).sum(-1, keepdim=True)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits, b["label"]).backward()
+        grads.append((wr.grad, br.grad))
+    total = sum(float((gw.double() ** 2).sum() + (gb.double() ** 2).sum()) for gw, gb in grads) ** 0.5
+    assert_close(torch.tensor(opt.last_total_norm.item()), torch.tensor(total), rtol=1e-5, what="norm over both passes")
+    scale = min(1.0, 0.05 / (total + 1e-6))
+    w_exp, b_exp = w0.double(), b0.double()
+    for gw, gb in grads:
+        w_exp = w_exp - 0.1 * scale * gw.double()
+        b_exp = b_exp - 0.1 * scale * gb.double()
+    assert_close(m.feature_embedding.weight.detach(), w_exp.float(), rtol=1e-5, what="rows after two pending updates")
+    assert_close(m.bias_embedding.weight.detach(), b_exp.float(), rtol=1e-5, what="bias after two pending updates")
+
+
 def test_reduce_agrees_with_the_sorted_path_on_hot_rows():
     """Runs of thousands of positions (tiny fields) cross many wavefront windows: compare with the
     position-ordered reduce over the fully sorted list (rx_segreduce_fm)."""

@@ -713,3 +713,15 @@ def test_cross16_combine_matches_torch(ops):
             g0 = g0 + acc0
         assert torch.equal(acc, g0)
         assert (dxl is None) == (not want) and (dxl is None or torch.equal(dxl, d))
+
+
+@pytest.mark.parametrize("M,d", [(1000, 432), (129, 176), (4096, 64)])
+def test_cross16_layer_in_one_launch_equals_product_then_combine(ops, M, d):
+    g = _gen(M + d)
+    x0, xl = torch.randn(M, d, generator=g).cuda(), torch.randn(M, d, generator=g).cuda()
+    w, b = (torch.randn(d, d, generator=g) / d ** 0.5).cuda(), torch.randn(d, generator=g).cuda()
+    x16 = ops.to_bf16(xl)
+    u, xn, xn16 = ops.cross16_layer_fwd(x16, w, b, x0, xl)
+    u2 = ops.linear16_fwd(x16, w, b, relu=False, out_bf16=False)
+    xn2, xn216 = ops.cross16_fwd(x0, u2, xl)
+    assert torch.equal(u, u2) and torch.equal(xn, xn2) and torch.equal(xn16, xn216)
