@@ -333,7 +333,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
 }
 
 // One operand tile in flight: 16 floats per thread.
-struct G2Regs { float4 v[4]; };
+struct G2Regs { float4 v[4]; unsigned ok; };   // ok: one bit per 16-byte piece inside the matrix (zeroed at the LDS store)
 
 // K-contiguous operand: tile rows r0.., 32 k from k0; thread = (row tid/4 [+64], 8 k at (tid%4)*8)
 __device__ __forceinline__ void g2_load_kc(const float* __restrict__ P, int64_t rs, int64_t r0, int64_t r_lim,
@@ -345,23 +345,23 @@ __device__ __forceinline__ void g2_load_kc(const float* __restrict__ P, int64_t 
     // k_end is a multiple of 4 on this path: each 16-byte half is either whole or absent
     const bool ok = row < r_lim && k < k_end, ok2 = row < r_lim && k + 4 < k_end;
     const float* src = P + (ok ? row : 0) * rs + (ok ? k : 0);
-    float4 a = *reinterpret_cast<const float4*>(src);
-    float4 b = *reinterpret_cast<const float4*>(src + (ok2 ? 4 : 0));
-    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ok2) b = make_float4(0.f, 0.f, 0.f, 0.f);
-    t.v[2 * p] = a;
-    t.v[2 * p + 1] = b;
+    t.v[2 * p] = *reinterpret_cast<const float4*>(src);
+    t.v[2 * p + 1] = *reinterpret_cast<const float4*>(src + (ok2 ? 4 : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= ((ok ? 1u : 0u) | (ok2 ? 2u : 0u)) << (2 * p);
   }
 }
 
 __device__ __forceinline__ void g2_store_kc(uint16_t* lds, int tid, const G2Regs& t) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 va = ((t.ok >> (2 * p)) & 1u) ? t.v[2 * p] : z, vb = ((t.ok >> (2 * p + 1)) & 1u) ? t.v[2 * p + 1] : z;
     uint4 o;
-    o.x = pack_bf16(t.v[2 * p].x, t.v[2 * p].y);
-    o.y = pack_bf16(t.v[2 * p].z, t.v[2 * p].w);
-    o.z = pack_bf16(t.v[2 * p + 1].x, t.v[2 * p + 1].y);
-    o.w = pack_bf16(t.v[2 * p + 1].z, t.v[2 * p + 1].w);
+    o.x = pack_bf16(va.x, va.y);
+    o.y = pack_bf16(va.z, va.w);
+    o.z = pack_bf16(vb.x, vb.y);
+    o.w = pack_bf16(vb.z, vb.w);
     *reinterpret_cast<uint4*>(&lds[((tid >> 2) + 64 * p) * G2_LDK + (tid & 3) * 8]) = o;
   }
 }
@@ -375,18 +375,19 @@ __device__ __forceinline__ void g2_load_mc(const float* __restrict__ P, int64_t 
   for (int p = 0; p < 4; ++p) {
     const int64_t k = k0 + (tid >> 5) + 8 * p;
     const bool ok = k < k_end && c < c_lim;
-    float4 a = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
-    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    t.v[p] = a;
+    t.v[p] = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= (ok ? 1u : 0u) << p;
   }
 }
 
 __device__ __forceinline__ void g2_store_mc(uint16_t* lds, int tid, const G2Regs& t) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
+    const float4 v = ((t.ok >> p) & 1u) ? t.v[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 o;
-    o.x = pack_bf16(t.v[p].x, t.v[p].y);
-    o.y = pack_bf16(t.v[p].z, t.v[p].w);
+    o.x = pack_bf16(v.x, v.y);
+    o.y = pack_bf16(v.z, v.w);
     *reinterpret_cast<uint2*>(&lds[((tid >> 5) + 8 * p) * G2_LDR + (tid & 31) * 4]) = o;
   }
 }
@@ -544,7 +545,7 @@ slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, floa
 #define G3_BK 16
 #define G3_LD (G2_T + 4)
 
-struct G3Regs { float4 v[2]; };
+struct G3Regs { float4 v[2]; unsigned ok; };   // ok: pieces inside the matrix (the rest is zeroed at the LDS store, not behind the load)
 
 // K-contiguous: thread = (row tid/4 [+64], 4 k at (tid%4)*4); M/N-contiguous: (k-row tid/32 [+8], 4 at (tid%32)*4)
 __device__ __forceinline__ void g3_load_kc(const float* __restrict__ P, int64_t rs, int64_t r0, int64_t r_lim,
@@ -554,17 +555,18 @@ __device__ __forceinline__ void g3_load_kc(const float* __restrict__ P, int64_t 
   for (int p = 0; p < 2; ++p) {
     const int64_t row = r0 + (tid >> 2) + 64 * p;
     const bool ok = row < r_lim && k < k_end;
-    float4 a = *reinterpret_cast<const float4*>(P + (ok ? row : 0) * rs + (ok ? k : 0));
-    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    t.v[p] = a;
+    t.v[p] = *reinterpret_cast<const float4*>(P + (ok ? row : 0) * rs + (ok ? k : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= (ok ? 1u : 0u) << p;
   }
 }
 
 __device__ __forceinline__ void g3_store_kc(float* lds, int tid, const G3Regs& t) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
+    const float4 v = ((t.ok >> p) & 1u) ? t.v[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     float* dst = lds + ((tid & 3) * 4) * G3_LD + (tid >> 2) + 64 * p;
-    dst[0] = t.v[p].x; dst[G3_LD] = t.v[p].y; dst[2 * G3_LD] = t.v[p].z; dst[3 * G3_LD] = t.v[p].w;
+    dst[0] = v.x; dst[G3_LD] = v.y; dst[2 * G3_LD] = v.z; dst[3 * G3_LD] = v.w;
   }
 }
 
@@ -575,16 +577,16 @@ __device__ __forceinline__ void g3_load_mc(const float* __restrict__ P, int64_t 
   for (int p = 0; p < 2; ++p) {
     const int64_t k = k0 + (tid >> 5) + 8 * p;
     const bool ok = k < k_end && c < c_lim;
-    float4 a = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
-    if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-    t.v[p] = a;
+    t.v[p] = *reinterpret_cast<const float4*>(P + (ok ? k : 0) * ks + (ok ? c : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= (ok ? 1u : 0u) << p;
   }
 }
 
 __device__ __forceinline__ void g3_store_mc(float* lds, int tid, const G3Regs& t) {
 #pragma unroll
   for (int p = 0; p < 2; ++p)
-    *reinterpret_cast<float4*>(lds + ((tid >> 5) + 8 * p) * G3_LD + (tid & 31) * 4) = t.v[p];
+    *reinterpret_cast<float4*>(lds + ((tid >> 5) + 8 * p) * G3_LD + (tid & 31) * 4) = ((t.ok >> p) & 1u) ? t.v[p] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <bool A_KC, bool B_KC, bool ACCUM>
@@ -1170,16 +1172,19 @@ extern "C" int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const f
 // bytes and no conversion sits between the global load and LDS.  Weights stay fp32 masters; a
 // layer's bf16 copy ([N, K], and [K, N] for the input gradient, which makes that product
 // K-contiguous on both sides like the forward) is made per use by rx_to_bf16.
-//   * 128 x 128 tile, 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16, 64 k per step: 16 MFMAs per
-//     wave between barriers; next step's 16-byte loads in flight behind them (register staging,
-//     two LDS buffers, one barrier per step)
-//   * K-contiguous operands [row][64 + 8] read 16 bytes per lane; the weight gradient's operands
+//   * 128 x 128 tile, 2 x 2 waves of 2 x 2 v_mfma_f32_32x32x16_bf16, H_BK k per step; next step's
+//     16-byte loads in flight behind the MFMAs (register staging, two LDS buffers, one barrier per step)
+//   * K-contiguous operands [row][H_BK + 8] read 16 bytes per lane; the weight gradient's operands
 //     (contiguous along the output dimensions) kept as loaded [k][128 + 32] and read through the
 //     transposing LDS read
 //   * epilogue variants as separate instantiations: fp32 or bf16 output, bias + ReLU, accumulate
 //     into fp32, and the ReLU gate of the layer in front applied from its stored bf16 output
-#define H_BK 64
+#ifndef H_BK
+#define H_BK 32   // 64 was measured too: 72 KB of operand buffers leave 2 workgroups per CU; 40 KB leave 3, which pays (DCN-v2 step 3.02 -> 2.89 ms)
+#endif
 #define H_LDK (H_BK + 8)
+#define H_CPR (H_BK / 8)        // 16-byte pieces per K-contiguous tile row
+#define H_NP (H_BK / 16)        // pieces per thread and operand
 #define H_T 128
 #define H_LDR (H_T + 32)
 #define H_LDC (H_T + 8)   // fp32 image of the output tile: rows 4 apart land 32 banks apart
@@ -1201,25 +1206,29 @@ struct Gemm16Args {
   uint16_t* xn16; int64_t ldn16;
 };
 
-struct HRegs { uint4 v[4]; };
+// Pieces in flight between a K-step's global loads and its LDS stores.  Out-of-range pieces are
+// loaded from a clamped (valid) address and zeroed only when they are written to LDS: a select
+// right behind the load would make the wave wait for the load before the MFMAs it is meant to hide behind.
+struct HRegs { uint4 v[H_NP]; unsigned ok; };
 
 // K-contiguous: thread = (row tid/8 [+32p], 8 k at (tid%8)*8); K % 8 == 0, so a 16-byte piece is whole or absent
 __device__ __forceinline__ void h_load_kc(const uint16_t* __restrict__ P, int64_t ld, int64_t r0, int64_t r_lim,
                                           int64_t k0, int64_t k_end, int tid, HRegs& t) {
-  const int64_t k = k0 + (tid & 7) * 8;
+  const int64_t k = k0 + (tid % H_CPR) * 8;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int64_t row = r0 + (tid >> 3) + 32 * p;
+  for (int p = 0; p < H_NP; ++p) {
+    const int64_t row = r0 + (tid / H_CPR) + (RX_BLOCK / H_CPR) * p;
     const bool ok = row < r_lim && k < k_end;
-    uint4 a = *reinterpret_cast<const uint4*>(P + (ok ? row : 0) * ld + (ok ? k : 0));
-    if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
-    t.v[p] = a;
+    t.v[p] = *reinterpret_cast<const uint4*>(P + (ok ? row : 0) * ld + (ok ? k : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= (ok ? 1u : 0u) << p;
   }
 }
 
 __device__ __forceinline__ void h_store_kc(uint16_t* lds, int tid, const HRegs& t) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&lds[((tid >> 3) + 32 * p) * H_LDK + (tid & 7) * 8]) = t.v[p];
+  for (int p = 0; p < H_NP; ++p)
+    *reinterpret_cast<uint4*>(&lds[((tid / H_CPR) + (RX_BLOCK / H_CPR) * p) * H_LDK + (tid % H_CPR) * 8]) = ((t.ok >> p) & 1u) ? t.v[p] : make_uint4(0u, 0u, 0u, 0u);
 }
 
 // contiguous along the output dimension: 64 k-rows of 128 elements; thread = (k-row tid/16 [+16p], 8 at (tid%16)*8)
@@ -1227,18 +1236,19 @@ __device__ __forceinline__ void h_load_mc(const uint16_t* __restrict__ P, int64_
                                           int64_t k0, int64_t k_end, int tid, HRegs& t) {
   const int64_t c = c0 + (tid & 15) * 8;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < H_NP; ++p) {
     const int64_t k = k0 + (tid >> 4) + 16 * p;
     const bool ok = k < k_end && c < c_lim;
-    uint4 a = *reinterpret_cast<const uint4*>(P + (ok ? k : 0) * ld + (ok ? c : 0));
-    if (!ok) a = make_uint4(0u, 0u, 0u, 0u);
-    t.v[p] = a;
+    t.v[p] = *reinterpret_cast<const uint4*>(P + (ok ? k : 0) * ld + (ok ? c : 0));
+    if (p == 0) t.ok = 0u;
+    t.ok |= (ok ? 1u : 0u) << p;
   }
 }
 
 __device__ __forceinline__ void h_store_mc(uint16_t* lds, int tid, const HRegs& t) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(&lds[((tid >> 4) + 16 * p) * H_LDR + (tid & 15) * 8]) = t.v[p];
+  for (int p = 0; p < H_NP; ++p)
+    *reinterpret_cast<uint4*>(&lds[((tid >> 4) + 16 * p) * H_LDR + (tid & 15) * 8]) = ((t.ok >> p) & 1u) ? t.v[p] : make_uint4(0u, 0u, 0u, 0u);
 }
 
 template <bool KC>
@@ -1334,86 +1344,95 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
   // are all touched as whole 16-byte pieces of contiguous rows
   float* ct = reinterpret_cast<float*>(h_lds);
   const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {      // 64 rows at a time: the image then fits beside nothing bigger than the operand buffers
+    if (half) __syncthreads();
+    if (wave_m == half) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ct[((wave_m * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * H_LDC + (wave_n * 2 + j) * 32 + l31] = acc[i][j][r];
-  __syncthreads();
-  if constexpr (OUT16) {
-    // 8 columns per thread: 16 threads per row, 16 rows per pass
-    const int c8 = (tid & 15) * 8;
-    const int64_t col = n0 + c8;
-    if (col < g.N) {   // N % 8 == 0: a piece is whole or absent
-      float bv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = g.bias ? g.bias[col + e] : 0.f;
-      uint16_t* C16 = reinterpret_cast<uint16_t*>(g.C);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int rr = (tid >> 4) + 16 * p;
-        const int64_t row = m0 + rr;
-        if (row >= g.M) continue;
-        const float4 lo = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8]);
-        const float4 hi = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8 + 4]);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint32_t gs[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        if constexpr (GATE) {
-          const uint4 gt = *reinterpret_cast<const uint4*>(g.gate + row * g.ldg + col);
-          gs[0] = gt.x; gs[1] = gt.y; gs[2] = gt.z; gs[3] = gt.w;
-        }
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = v[2 * e] + bv[2 * e], c = v[2 * e + 1] + bv[2 * e + 1];
-          if (g.act == 1) { a = a > 0.f ? a : 0.f; c = c > 0.f ? c : 0.f; }
-          if constexpr (GATE) {
-            const uint32_t glo = gs[e] & 0xffffu, ghi = gs[e] >> 16;
-            if (glo == 0 || (glo & 0x8000u)) a = 0.f;
-            if (ghi == 0 || (ghi & 0x8000u)) c = 0.f;
-          }
-          o[e] = (uint32_t)f32_to_bf16_rne(a) | ((uint32_t)f32_to_bf16_rne(c) << 16);
-        }
-        *reinterpret_cast<uint4*>(C16 + row * g.ldc + col) = make_uint4(o[0], o[1], o[2], o[3]);
-      }
+          for (int r = 0; r < 16; ++r)
+            ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * H_LDC + (wave_n * 2 + j) * 32 + l31] = acc[i][j][r];
     }
-  } else {
-    // 4 columns per thread: 32 threads per row, 8 rows per pass.  ldc % 4 == 0 here; a weight-gradient
-    // slab has N % 8 == 0, the other fp32 outputs N % 4 == 0 (checked by the callers)
-    const int c4 = (tid & 31) * 4;
-    const int64_t col = n0 + c4;
-    if (col < g.N) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
-      float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride;
+    __syncthreads();
+    const int64_t mh = m0 + 64 * half;
+    if constexpr (OUT16) {
+      // 8 columns per thread: 16 threads per row, 16 rows per pass
+      const int c8 = (tid & 15) * 8;
+      const int64_t col = n0 + c8;
+      if (col < g.N) {   // N % 8 == 0: a piece is whole or absent
+        float bv[8];
 #pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int rr = (tid >> 5) + 8 * p;
-        const int64_t row = m0 + rr;
-        if (row >= g.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c4]);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (g.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-        float4* dst = reinterpret_cast<float4*>(Cf + row * g.ldc + col);
-        if constexpr (ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *dst = v;
-        if constexpr (CROSS) {   // the DCN-v2 combine on the tile just produced: x_next = x0 * u + x_l
-          const float4 a = *reinterpret_cast<const float4*>(g.x0 + row * g.ld0 + col);
-          const float4 d = *reinterpret_cast<const float4*>(g.xl + row * g.ldl + col);
-          const float4 o = make_float4(a.x * v.x + d.x, a.y * v.y + d.y, a.z * v.z + d.z, a.w * v.w + d.w);
-          *reinterpret_cast<float4*>(g.xn + row * g.ldn + col) = o;
-          *reinterpret_cast<uint2*>(g.xn16 + row * g.ldn16 + col) =
-              make_uint2((uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16),
-                         (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16));
+        for (int e = 0; e < 8; ++e) bv[e] = g.bias ? g.bias[col + e] : 0.f;
+        uint16_t* C16 = reinterpret_cast<uint16_t*>(g.C);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = (tid >> 4) + 16 * p;
+          const int64_t row = mh + rr;
+          if (row >= g.M) continue;
+          const float4 lo = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8]);
+          const float4 hi = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c8 + 4]);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          uint32_t gs[4] = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          if constexpr (GATE) {
+            const uint4 gt = *reinterpret_cast<const uint4*>(g.gate + row * g.ldg + col);
+            gs[0] = gt.x; gs[1] = gt.y; gs[2] = gt.z; gs[3] = gt.w;
+          }
+          uint32_t o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = v[2 * e] + bv[2 * e], c = v[2 * e + 1] + bv[2 * e + 1];
+            if (g.act == 1) { a = a > 0.f ? a : 0.f; c = c > 0.f ? c : 0.f; }
+            if constexpr (GATE) {
+              const uint32_t glo = gs[e] & 0xffffu, ghi = gs[e] >> 16;
+              if (glo == 0 || (glo & 0x8000u)) a = 0.f;
+              if (ghi == 0 || (ghi & 0x8000u)) c = 0.f;
+            }
+            o[e] = (uint32_t)f32_to_bf16_rne(a) | ((uint32_t)f32_to_bf16_rne(c) << 16);
+          }
+          *reinterpret_cast<uint4*>(C16 + row * g.ldc + col) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else {
+      // 4 columns per thread: 32 threads per row, 8 rows per pass.  ldc % 4 == 0 here; a weight-gradient
+      // slab has N % 8 == 0, the other fp32 outputs N % 4 == 0 (checked by the callers)
+      const int c4 = (tid & 31) * 4;
+      const int64_t col = n0 + c4;
+      if (col < g.N) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+        float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int rr = (tid >> 5) + 8 * p;
+          const int64_t row = mh + rr;
+          if (row >= g.M) continue;
+          float4 v = *reinterpret_cast<const float4*>(&ct[rr * H_LDC + c4]);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          if (g.act == 1) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+          float4* dst = reinterpret_cast<float4*>(Cf + row * g.ldc + col);
+          if constexpr (ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *dst = v;
+          if constexpr (CROSS) {   // the DCN-v2 combine on the tile just produced: x_next = x0 * u + x_l
+            const float4 a = *reinterpret_cast<const float4*>(g.x0 + row * g.ld0 + col);
+            const float4 d = *reinterpret_cast<const float4*>(g.xl + row * g.ldl + col);
+            const float4 o = make_float4(a.x * v.x + d.x, a.y * v.y + d.y, a.z * v.z + d.z, a.w * v.w + d.w);
+            *reinterpret_cast<float4*>(g.xn + row * g.ldn + col) = o;
+            *reinterpret_cast<uint2*>(g.xn16 + row * g.ldn16 + col) =
+                make_uint2((uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16),
+                           (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16));
+          }
         }
       }
     }
   }
 }
 
-#define H_LDS_BYTES(KC_) ((size_t)2 * 2 * ((KC_) ? H_T * H_LDK : H_BK * H_LDR) * sizeof(uint16_t))
+#define H_LDS_OPERANDS(KC_) ((size_t)2 * 2 * ((KC_) ? H_T * H_LDK : H_BK * H_LDR) * sizeof(uint16_t))
+#define H_LDS_IMAGE ((size_t)64 * H_LDC * sizeof(float))
+#define H_LDS_BYTES(KC_) (H_LDS_OPERANDS(KC_) > H_LDS_IMAGE ? H_LDS_OPERANDS(KC_) : H_LDS_IMAGE)
 
 template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false>
 static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
