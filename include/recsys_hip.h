@@ -562,16 +562,19 @@ int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, i
  * nearest even): the products round their operands to bf16 anyway, so the values are those of
  * rx_linear_*(bf16 = 1) on fp32 storage while each operand moves half the bytes.  fp32
  * accumulation, fp32 master weights; W16 / W16T are per-use bf16 copies of a weight [N, K] made
- * by rx_to_bf16 ([N, K], and transposed [K, N] for the input gradient).  Rows must be 16-byte
- * addressable (leading dimensions multiples of 8 elements), K and N multiples of 8; N == 1 (the
- * tower's last layer, K <= 512) takes matrix-vector kernels that read the fp32 weights `W`.
+ * by rx_to_bf16 ([N, K], and transposed [K, N] for the input gradient), rows padded to a multiple
+ * of 8 elements.  Every bf16 matrix has 16-byte addressable rows (leading dimension a multiple of
+ * 8 elements) whose padding columns hold ZEROS: K and N need only be multiples of 4, a 16-byte
+ * piece that straddles the end of a row reads zeros and writes zeros there.  N == 1 (the tower's
+ * last layer, K <= 512) takes matrix-vector kernels that read the fp32 weights `W`.
  *   rx_to_bf16         dst = bf16(src) for an fp32 [rows, cols] matrix; transpose != 0 writes
  *                      dst[c, r] (weight matrices)
  *   rx_linear16_fwd    Y = act(X16 W16^T + b), Y fp32 or bf16 (out_bf16)
  *   rx_linear16_bwd_x  dX = dY16 W (through W16T); fp32 output (accumulate: dX += ...), or bf16
  *                      output with an optional gate16 [M, K] (the bf16 output of the ReLU layer
  *                      in front: entries with gate <= 0 become 0, i.e. that layer's ReLU backward
- *                      fused into this epilogue)
+ *                      fused into this epilogue); gate16 with an fp32 output is taken by the
+ *                      one-column layer only
  *   rx_linear16_bwd_w  dW = dY16^T X16 (slabs over the batch, summed in slab order), db = column
  *                      sums of dY16 (may be NULL)
  *   rx_cross16_fwd     x_next = x0 * u + x_l in fp32 plus its bf16 copy (operand of the next products)
@@ -579,6 +582,17 @@ int rx_topk_codes(const float* d_scores, const int64_t* d_codes, int64_t rows, i
  *   rx_cross16_layer_fwd  one whole cross layer in one launch: u = X16 W16^T + b (kept, the backward
  *                      needs it) and, in the same epilogue, x_next = x0 * u + x_l with its bf16 copy;
  *                      bit for bit rx_linear16_fwd followed by rx_cross16_fwd */
+/* BatchNorm passes of a tower that keeps its activations in bf16: rx_bn_apply writing bf16 only, and
+ * rx_bn_bwd reading that bf16 output as its ReLU / dropout gate and writing its gradient as bf16. */
+int rx_bn_apply16(const float* d_x, int64_t ldx, int64_t M, int32_t C, const float* d_mean,
+                  const float* d_rstd, const float* d_gamma, const float* d_beta, int relu,
+                  const uint8_t* d_keep, float keep_scale, uint16_t* d_out16, int64_t ldo, int device,
+                  void* stream);
+int rx_bn_bwd16(const float* d_dout, int64_t ldd, const float* d_x, int64_t ldx, const uint16_t* d_out16,
+                int64_t ldo, int64_t M, int32_t C, const float* d_mean, const float* d_rstd,
+                const float* d_gamma, int gate, float keep_scale, int batch_stats, uint16_t* d_dx16,
+                int64_t lddx, float* d_dgamma, float* d_dbeta, void* ws, size_t ws_bytes, int device,
+                void* stream);
 int rx_to_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols,
                int transpose, int device, void* stream);
 int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* W, const float* b,

@@ -43,13 +43,14 @@ def _tower_input(e, dense, width=None):
     return x
 
 
-def field_deepfm_logits(P, inputs, field_dims, train=False, dropout=0.0, buffers_out=None, **_):
+def field_deepfm_logits(P, inputs, field_dims, train=False, dropout=0.0, buffers_out=None, bf16=False, **_):
     from .models import _bn_tower
     e, idx = _rows(P, "feature_embedding.weight", inputs["sparse"], field_dims)
     bias = P["bias_embedding.weight"][:, 0][idx].sum(1, keepdim=True)
     fm = fm_second_order(e[:, :-1], e[:, -1:])
     x = _tower_input(e, inputs.get("dense"), P["deep_mlp.0.weight"].shape[1])
-    return bias + fm + _bn_tower(P, "deep_mlp", x, train, buffers_out, dropout)
+    linear = (lambda a, w, b: _linear(a, w, b, True)) if bf16 else F.linear
+    return bias + fm + _bn_tower(P, "deep_mlp", x, train, buffers_out, dropout, linear=linear)
 
 
 def _r16(t):
@@ -103,7 +104,7 @@ class FieldOracle:
 
     def __init__(self, name, state, field_dims, dropout=0.0, bf16=False):
         self.fn, self.field_dims, self.dropout, self.training = self.FN[name], list(field_dims), dropout, True
-        self.bf16 = bf16          # DCNv2 only: GEMM operands rounded to bfloat16
+        self.bf16 = bf16          # DCNv2 / FieldDeepFM towers: GEMM operands rounded to bfloat16
         self.params, self.buffers = {}, {}
         for k, v in state.items():
             t = torch.as_tensor(v).detach().clone()

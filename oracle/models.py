@@ -58,11 +58,12 @@ def fm_second_order(ex: Tensor, item: Tensor) -> Tensor:
     return 0.5 * (s * s - q).sum(-1)
 
 
-def _bn_tower(P, prefix: str, x: Tensor, train: bool, buffers_out: dict | None, dropout: float):
+def _bn_tower(P, prefix: str, x: Tensor, train: bool, buffers_out: dict | None, dropout: float, linear=F.linear):
     """Linear -> BatchNorm1d -> ReLU -> Dropout, three times, then Linear(.,1)
-    (recsys/models/neuralcf/widendeep.py:6-24; indices 0,1,4,5,8,9,12 in the Sequential)."""
+    (recsys/models/neuralcf/widendeep.py:6-24; indices 0,1,4,5,8,9,12 in the Sequential).
+    ``linear``: the Linear op (the bf16-operand towers of oracle.fields pass their own)."""
     for lin, bn in ((0, 1), (4, 5), (8, 9)):
-        x = F.linear(x, P[f"{prefix}.{lin}.weight"], P[f"{prefix}.{lin}.bias"])
+        x = linear(x, P[f"{prefix}.{lin}.weight"], P[f"{prefix}.{lin}.bias"])
         rm, rv = P[f"{prefix}.{bn}.running_mean"], P[f"{prefix}.{bn}.running_var"]
         if train:
             rm, rv = rm.clone(), rv.clone()
@@ -78,7 +79,7 @@ def _bn_tower(P, prefix: str, x: Tensor, train: bool, buffers_out: dict | None, 
             )
         x = F.relu(x)
         x = F.dropout(x, dropout, training=train)
-    return F.linear(x, P[f"{prefix}.12.weight"], P[f"{prefix}.12.bias"])
+    return linear(x, P[f"{prefix}.12.weight"], P[f"{prefix}.12.bias"])
 
 
 def _relu_tower(P, prefix: str, x: Tensor, n_linear: int, train: bool, dropout: float):

@@ -99,6 +99,9 @@ PROTOTYPES = {
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
+    "rx_bn_apply16": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, f32, vp, i64, C.c_int, vp]),
+    "rx_bn_bwd16": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, C.c_int, f32, C.c_int, vp, i64, vp, vp, vp, sz,
+                              C.c_int, vp]),
     "rx_to_bf16": (C.c_int, [vp, i64, vp, i64, i64, i32, C.c_int, C.c_int, vp]),
     "rx_linear16_fwd": (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_linear16_bwd_x": (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

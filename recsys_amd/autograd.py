@@ -477,16 +477,16 @@ def cross_stack(x0: Tensor, layers, bf16: bool = False) -> Tensor:
 
 def h16_shapes_ok(x: Tensor, weights) -> bool:
     """Shapes the bf16-activation kernels take: fp32 GPU input with 16-byte addressable rows, every
-    layer width a multiple of 8 (the last layer may have one output column, up to 512 inputs)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1 and x.shape[1] % 8 == 0
-            and x.stride(1) == 1 and x.stride(0) % 4 == 0):
+    layer width a multiple of 4 (the last layer may have one output column, up to 512 inputs)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1 and x.shape[1] % 4 == 0
+            and x.shape[1] >= 8 and x.stride(1) == 1 and x.stride(0) % 4 == 0):
         return False
     ws = list(weights)
     for i, w in enumerate(ws):
         n, k = w.shape
-        if k % 8 != 0:
+        if k % 4 != 0 or k < 8:
             return False
-        if n % 8 != 0 and not (i == len(ws) - 1 and n == 1 and k <= 512):
+        if n % 4 != 0 and not (i == len(ws) - 1 and n == 1 and k <= 512):
             return False
     return True
 
@@ -568,6 +568,104 @@ class MLPStack16(Function):
             elif ctx.needs_input_grad[0]:
                 dx = ops.linear16_bwd_x(d16, ws[l], out_bf16=False)
         return (dx, None) + tuple(grads)
+
+
+class BNTower16(Function):
+    """The reference's BatchNorm tower -- [Linear, BatchNorm1d, ReLU, Dropout] * n + Linear(., 1)
+    (recsys/models/neuralcf/deep_factorization_machine.py:6-24) -- as one autograd node with bf16
+    operand storage: every Linear reads a bf16 activation (the input's copy, then the bf16 output of
+    the normalisation in front of it) and writes fp32 for the statistics pass; the backward walk
+    keeps the gradient that enters a normalisation in fp32 and the one that leaves it -- an operand
+    of two matrix products -- in bf16.  Same arithmetic as the per-layer nodes with ``bf16=True``.
+    ``cfg``: per hidden block (momentum, eps, p, batch statistics?, update running buffers?);
+    tensors per block: w, b, gamma, beta, running_mean, running_var; then the last layer's w, b."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *t):
+        nb = len(cfg)
+        a16 = [ops.to_bf16(x)]
+        zs, stats, keeps = [], [], []
+        for i, (momentum, eps, p, batch_stats, update) in enumerate(cfg):
+            w, b, gamma, beta, rm, rv = t[6 * i:6 * i + 6]
+            z = ops.linear16_fwd(a16[-1], w, b, relu=False, out_bf16=False)
+            if batch_stats:
+                if z.shape[0] < 2 and update:
+                    raise ValueError("Expected more than 1 value per channel when training")
+                mean, rstd = ops.bn_stats(z, eps, momentum if update else 0.0, rm if update else None, rv if update else None)
+            else:
+                mean, rstd = rm, torch.rsqrt(rv + eps)
+            keep, keep_scale = None, 1.0
+            if p > 0.0:
+                keep = torch.empty(z.shape, dtype=torch.uint8, device=z.device).bernoulli_(1.0 - p)
+                keep_scale = 1.0 / (1.0 - p)
+            a16.append(ops.bn_apply16(z, mean, rstd, gamma, beta, True, keep, keep_scale))
+            zs.append(z); stats += [mean, rstd]; keeps.append(keep_scale)
+        w_last, b_last = t[6 * nb], t[6 * nb + 1]
+        y = ops.linear16_fwd(a16[-1], w_last, b_last, relu=False, out_bf16=False)
+        ctx.save_for_backward(*a16, *zs, *stats, *[t[6 * i + 2] for i in range(nb)], *[t[6 * i] for i in range(nb)], w_last)
+        ctx.nb, ctx.keeps, ctx.cfg, ctx.has_b_last = nb, keeps, cfg, b_last is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        nb = ctx.nb
+        s = ctx.saved_tensors
+        a16, zs = s[:nb + 1], s[nb + 1:2 * nb + 1]
+        stats = s[2 * nb + 1:4 * nb + 1]
+        gammas, ws, w_last = s[4 * nb + 1:5 * nb + 1], s[5 * nb + 1:6 * nb + 1], s[6 * nb + 1]
+        grads = [None] * (6 * nb + 2)
+        d16 = ops.to_bf16(dy.contiguous())
+        grads[6 * nb], db = ops.linear16_bwd_w(d16, a16[nb], ctx.has_b_last)
+        grads[6 * nb + 1] = db
+        dout = ops.linear16_bwd_x(d16, w_last, out_bf16=False)               # fp32: it enters a normalisation
+        dx = None
+        for i in range(nb - 1, -1, -1):
+            batch_stats = ctx.cfg[i][3]
+            dz16, dgamma, dbeta = ops.bn_bwd16(dout, zs[i], a16[i + 1], stats[2 * i], stats[2 * i + 1], gammas[i], True,
+                                               ctx.keeps[i], batch_stats)
+            grads[6 * i + 2], grads[6 * i + 3] = dgamma, dbeta
+            grads[6 * i], grads[6 * i + 1] = ops.linear16_bwd_w(dz16, a16[i], True)
+            if i > 0:
+                dout = ops.linear16_bwd_x(dz16, ws[i], out_bf16=False)
+            elif ctx.needs_input_grad[0]:
+                dx = ops.linear16_bwd_x(dz16, ws[i], out_bf16=False)
+        return (dx, None) + tuple(grads)
+
+
+def bn_tower16(seq, x: Tensor):
+    """Run ``seq`` through BNTower16 if it is [Linear, BatchNorm1d(affine), ReLU, Dropout] * n +
+    [Linear(., 1)] with widths the bf16-activation kernels take; returns None otherwise."""
+    import torch.nn as nn
+    mods = list(seq)
+    if len(mods) < 5 or (len(mods) - 1) % 4 != 0:
+        return None
+    blocks = [mods[i:i + 4] for i in range(0, len(mods) - 1, 4)]
+    last = mods[-1]
+    kinds = (nn.Linear, nn.BatchNorm1d, nn.ReLU, nn.Dropout)
+    if not isinstance(last, nn.Linear) or last.out_features != 1 or last.bias is None:
+        return None
+    for blk in blocks:
+        if not all(isinstance(m, k) for m, k in zip(blk, kinds)):
+            return None
+        if not blk[1].affine or blk[0].bias is None or blk[0].out_features % 4 != 0:
+            return None
+    if not h16_shapes_ok(x, [b[0].weight for b in blocks] + [last.weight]):
+        return None
+    cfg, tensors = [], []
+    for lin, bn, _, drop in blocks:
+        training = bn.training
+        momentum = 0.0
+        update = training and bn.track_running_stats
+        if update:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        batch_stats = training or not bn.track_running_stats
+        cfg.append((momentum, bn.eps, float(drop.p) if drop.training else 0.0, batch_stats, update))
+        tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                    bn.running_var if bn.track_running_stats else None]
+    tensors += [last.weight, last.bias]
+    return BNTower16.apply(x, tuple(cfg), *tensors)
 
 
 # ------------------------------------------------------------------ loss

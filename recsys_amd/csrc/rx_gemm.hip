@@ -1362,10 +1362,10 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
       // 8 columns per thread: 16 threads per row, 16 rows per pass
       const int c8 = (tid & 15) * 8;
       const int64_t col = n0 + c8;
-      if (col < g.N) {   // N % 8 == 0: a piece is whole or absent
+      if (col < g.N) {   // a piece that straddles N ends in the row's zero padding (leading dimensions are multiples of 8)
         float bv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = g.bias ? g.bias[col + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
         uint16_t* C16 = reinterpret_cast<uint16_t*>(g.C);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1521,7 +1521,7 @@ gemv16_fwd_kernel(const uint16_t* __restrict__ X, int64_t ldx, const float* __re
   const bool ok = k0 < K;
   float wv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) wv[e] = ok ? round_bf16(w[k0 + e]) : 0.f;
+  for (int e = 0; e < 8; ++e) wv[e] = (ok && k0 + e < K) ? round_bf16(w[k0 + e]) : 0.f;   // rows are zero padded to 8
   const float bv = b ? b[0] : 0.f;
   for (int64_t r = (int64_t)blockIdx.x * RL + rl; r < M; r += (int64_t)gridDim.x * RL) {
     const uint4 x = ok ? *reinterpret_cast<const uint4*>(X + r * ldx + k0) : make_uint4(0u, 0u, 0u, 0u);
@@ -1539,28 +1539,42 @@ gemv16_fwd_kernel(const uint16_t* __restrict__ X, int64_t ldx, const float* __re
   }
 }
 
-// dZ16[m, k] = gate(h16[m, k]) * bf16(dy16[m] * bf16(w[k]))  (gate may be null)
+// dZ16[m, k] = gate(h16[m, k]) * bf16(dy16[m] * bf16(w[k]))  (gate may be null); OUT32: the products
+// themselves in fp32 (exact: two bf16 factors), for a consumer that is not a matrix product
+template <bool OUT32>
 __global__ void __launch_bounds__(RX_BLOCK)
 gemv16_bwd_x_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const float* __restrict__ w, const uint16_t* __restrict__ gate,
-                    int64_t ldg, uint16_t* __restrict__ dZ, int64_t ldz, int64_t M, int K) {
-  const int kq = K / 8;
+                    int64_t ldg, void* __restrict__ dZ_, int64_t ldz, int64_t M, int K) {
+  uint16_t* dZ = reinterpret_cast<uint16_t*>(dZ_);
+  const int kq = (K + 7) / 8;
   const int64_t total = M * kq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / kq;
     const int k0 = (int)(i - m * kq) * 8;
     const float gy = bf16_bits_to_f32(dY[m * ldd]);
+    float wr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wr[e] = k0 + e < K ? round_bf16(w[k0 + e]) : 0.f;
     uint4 gt = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
     if (gate) gt = *reinterpret_cast<const uint4*>(gate + m * ldg + k0);
     const uint32_t gs[4] = {gt.x, gt.y, gt.z, gt.w};
     uint32_t o[4];
+    float f[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t lo = gs[e] & 0xffffu, hi = gs[e] >> 16;
-      const float a = (lo != 0 && !(lo & 0x8000u)) ? gy * round_bf16(w[k0 + 2 * e]) : 0.f;
-      const float c = (hi != 0 && !(hi & 0x8000u)) ? gy * round_bf16(w[k0 + 2 * e + 1]) : 0.f;
+      const float a = (lo != 0 && !(lo & 0x8000u)) ? gy * wr[2 * e] : 0.f;
+      const float c = (hi != 0 && !(hi & 0x8000u)) ? gy * wr[2 * e + 1] : 0.f;
+      f[2 * e] = a; f[2 * e + 1] = c;
       o[e] = (uint32_t)f32_to_bf16_rne(a) | ((uint32_t)f32_to_bf16_rne(c) << 16);
     }
-    *reinterpret_cast<uint4*>(dZ + m * ldz + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+    if constexpr (OUT32) {
+      float* dst = reinterpret_cast<float*>(dZ_) + m * ldz + k0;
+      *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+      if (k0 + 4 < K) *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);   // K % 4 == 0
+    } else {
+      *reinterpret_cast<uint4*>(dZ + m * ldz + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -1613,7 +1627,7 @@ static inline int gemv16_lpr(int K) {
   while (l * 8 < K) l <<= 1;
   return l;
 }
-static inline bool gemv16_ok(int32_t N, int32_t K) { return N == 1 && K % 8 == 0 && K >= 8 && K <= 512; }
+static inline bool gemv16_ok(int32_t N, int32_t K) { return N == 1 && K % 4 == 0 && K >= 8 && K <= 512; }
 
 // ---- column sums of a bf16 matrix: partial[z][j]; a block covers 128 columns with 16 row lanes of 16-byte loads
 template <int DUMMY>
@@ -1661,7 +1675,7 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
                                void* Y, int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int out_bf16, int device,
                                void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 8 == 0 && ldx >= K && ldy >= N, "rx_linear16_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+  RX_REQUIRE(M >= 0 && N >= 1 && K >= 8 && K % 4 == 0 && ldx >= K && ldy >= N, "rx_linear16_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
   RX_REQUIRE(act == 0 || act == 1, "rx_linear16_fwd: unknown activation %d", act);
   if (M == 0) return 0;
   RX_REQUIRE(X16 && Y && h16_ok(X16, ldx), "rx_linear16_fwd: null or unaligned activations");
@@ -1676,10 +1690,10 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
     return 0;
   }
   RX_REQUIRE(W16 && rx_aligned16(W16), "rx_linear16_fwd: null or unaligned bf16 weights");
-  RX_REQUIRE(out_bf16 ? (N % 8 == 0 && h16_ok(Y, ldy)) : (N % 4 == 0 && f4_ok(Y, ldy)),
-             "rx_linear16_fwd: output rows must be whole 16-byte pieces (N a multiple of 8 for bf16, 4 for fp32)");
+  RX_REQUIRE(N % 4 == 0 && (out_bf16 ? h16_ok(Y, ldy) : f4_ok(Y, ldy)),
+             "rx_linear16_fwd: N must be a multiple of 4 and output rows 16-byte addressable");
   Gemm16Args g{};
-  g.A = X16; g.lda = ldx; g.B = W16; g.ldb = K; g.C = Y; g.ldc = ldy; g.bias = b;
+  g.A = X16; g.lda = ldx; g.B = W16; g.ldb = rx_cdiv(K, 8) * 8; g.C = Y; g.ldc = ldy; g.bias = b;
   g.M = M; g.N = N; g.K = K; g.act = act; g.k_per_slab = K;
   return out_bf16 ? gemm_h16_launch<true, true, false, false>(g, 1, st) : gemm_h16_launch<true, false, false, false>(g, 1, st);
 }
@@ -1707,23 +1721,25 @@ extern "C" int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16
   RX_ENTER(device);
   RX_REQUIRE(M >= 0 && N >= 1 && K >= 1 && ldd >= N && ldx >= K, "rx_linear16_bwd_x: bad shape");
   RX_REQUIRE(!(accumulate && (out_bf16 || gate16)), "rx_linear16_bwd_x: accumulation is for ungated fp32 outputs");
-  RX_REQUIRE(!gate16 || out_bf16, "rx_linear16_bwd_x: the gated form writes bf16");
+  RX_REQUIRE(!gate16 || out_bf16 || N == 1, "rx_linear16_bwd_x: the gated form writes bf16 (fp32 only for the one-column layer)");
   if (M == 0) return 0;
   RX_REQUIRE(dY16 && dX, "rx_linear16_bwd_x: null argument");
   hipStream_t st = (hipStream_t)stream;
-  if (gemv16_ok(N, K) && out_bf16) {
-    RX_REQUIRE(W && h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg)), "rx_linear16_bwd_x: one-column layer: fp32 weights and aligned rows");
-    int64_t grid = rx_cdiv(M * (K / 8), RX_BLOCK);
+  if (gemv16_ok(N, K) && !accumulate) {
+    RX_REQUIRE(W && (out_bf16 ? h16_ok(dX, ldx) : f4_ok(dX, ldx)) && (!gate16 || h16_ok(gate16, ldg)),
+               "rx_linear16_bwd_x: one-column layer: fp32 weights and aligned rows");
+    int64_t grid = rx_cdiv(M * ((K + 7) / 8), RX_BLOCK);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(gemv16_bwd_x_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, dY16, ldd, W, gate16, ldg, (uint16_t*)dX, ldx, M, (int)K);
+    if (out_bf16) hipLaunchKernelGGL(gemv16_bwd_x_kernel<false>, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, dY16, ldd, W, gate16, ldg, dX, ldx, M, (int)K);
+    else hipLaunchKernelGGL(gemv16_bwd_x_kernel<true>, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, dY16, ldd, W, gate16, ldg, dX, ldx, M, (int)K);
     RX_LAUNCH_CHECK();
     return 0;
   }
-  RX_REQUIRE(N % 8 == 0 && h16_ok(dY16, ldd) && W16T && rx_aligned16(W16T), "rx_linear16_bwd_x: N must be a multiple of 8, operands 16-byte aligned");
-  RX_REQUIRE(out_bf16 ? (K % 8 == 0 && h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg))) : (K % 4 == 0 && f4_ok(dX, ldx)),
-             "rx_linear16_bwd_x: output (and gate) rows must be whole 16-byte pieces");
+  RX_REQUIRE(N % 4 == 0 && h16_ok(dY16, ldd) && W16T && rx_aligned16(W16T), "rx_linear16_bwd_x: N must be a multiple of 4, operands 16-byte aligned");
+  RX_REQUIRE(K % 4 == 0 && (out_bf16 ? (h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg))) : f4_ok(dX, ldx)),
+             "rx_linear16_bwd_x: K must be a multiple of 4 and output (and gate) rows 16-byte addressable");
   Gemm16Args g{};
-  g.A = dY16; g.lda = ldd; g.B = W16T; g.ldb = N; g.C = dX; g.ldc = ldx; g.bias = nullptr; g.gate = gate16; g.ldg = ldg;
+  g.A = dY16; g.lda = ldd; g.B = W16T; g.ldb = rx_cdiv(N, 8) * 8; g.C = dX; g.ldc = ldx; g.bias = nullptr; g.gate = gate16; g.ldg = ldg;
   g.M = M; g.N = K; g.K = N; g.act = 0; g.k_per_slab = N;
   if (gate16) return gemm_h16_launch<true, true, true, false>(g, 1, st);
   if (out_bf16) return gemm_h16_launch<true, true, false, false>(g, 1, st);
@@ -1751,7 +1767,7 @@ extern "C" size_t rx_linear16_bwd_w_workspace_bytes(int64_t M, int32_t N, int32_
 extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16_t* X16, int64_t ldx, float* dW, float* db,
                                  int64_t M, int32_t N, int32_t K, void* ws, size_t ws_bytes, int device, void* stream) {
   RX_ENTER(device);
-  RX_REQUIRE(M >= 1 && N >= 1 && K >= 8 && K % 8 == 0 && ldd >= N && ldx >= K, "rx_linear16_bwd_w: bad shape");
+  RX_REQUIRE(M >= 1 && N >= 1 && K >= 8 && K % 4 == 0 && ldd >= N && ldx >= K, "rx_linear16_bwd_w: bad shape");
   RX_REQUIRE(dY16 && X16 && dW && ws && h16_ok(X16, ldx), "rx_linear16_bwd_w: null or unaligned argument");
   RX_REQUIRE(ws_bytes >= rx_linear16_bwd_w_workspace_bytes(M, N, K), "rx_linear16_bwd_w: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -1772,7 +1788,7 @@ extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16
     RX_LAUNCH_CHECK();
     return 0;
   }
-  RX_REQUIRE(N % 8 == 0 && h16_ok(dY16, ldd), "rx_linear16_bwd_w: N must be a multiple of 8 and dY 16-byte aligned");
+  RX_REQUIRE(N % 4 == 0 && h16_ok(dY16, ldd), "rx_linear16_bwd_w: N must be a multiple of 4 and dY 16-byte aligned");
   Gemm16Args g{};
   g.A = dY16; g.lda = ldd; g.B = X16; g.ldb = ldx; g.C = slabs; g.ldc = K; g.bias = nullptr;
   g.M = N; g.N = K; g.K = M; g.act = 0; g.k_per_slab = rows_per_slab; g.c_slab_stride = nk;

@@ -19,6 +19,24 @@ __device__ __forceinline__ float4 bn_ld4(const float* p, bool vec, int valid) {
   return r;
 }
 
+// bf16 side of the towers that keep their activations in bf16 (H16 variants below): the normalised
+// output is written, and later read back as the ReLU / dropout gate, as 4 bf16 values (8 bytes);
+// the gradient that leaves the backward pass is written the same way.
+__device__ __forceinline__ uint32_t bn_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void bn_st4_bf16(uint16_t* p, const float o[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(bn_bf16_rne(o[0]) | (bn_bf16_rne(o[1]) << 16), bn_bf16_rne(o[2]) | (bn_bf16_rne(o[3]) << 16));
+}
+// the four values as floats that are non-zero exactly where the bf16 value is
+__device__ __forceinline__ float4 bn_ld4_gate16(const uint16_t* p) {
+  const uint2 g = *reinterpret_cast<const uint2*>(p);
+  return make_float4((g.x & 0x7fffu) ? 1.f : 0.f, (g.x & 0x7fff0000u) ? 1.f : 0.f, (g.y & 0x7fffu) ? 1.f : 0.f, (g.y & 0x7fff0000u) ? 1.f : 0.f);
+}
+
 // partial[z][c][0..1] = (sum x, sum x^2) over the slab's rows
 template <bool VEC>
 __global__ void __launch_bounds__(RX_BLOCK)
@@ -106,12 +124,13 @@ bn_stats_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M
 // out = keep * keep_scale * act(gamma * (x - mean) * rstd + beta).  Same geometry as the statistics
 // pass (64 columns x 16 row lanes per block, a slab of rows per blockIdx.z): the per-column
 // constants are read once per thread and no index arithmetic is left in the row loop.
-template <bool VEC>
+template <bool VEC, bool H16 = false>
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, const float* __restrict__ mean,
                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                int relu, const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ out, int64_t ldo,
+                int relu, const uint8_t* __restrict__ keep, float keep_scale, void* __restrict__ out_, int64_t ldo,
                 int64_t rows_per_slab) {
+  float* out = reinterpret_cast<float*>(out_);
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int j0 = blockIdx.x * BN_COLS + cq * 4;
   const int valid = C - j0;
@@ -156,6 +175,10 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, cons
         if (keep) y = ((kp[u] >> (8 * t)) & 0xffu) ? y * keep_scale : 0.f;
         o[t] = y;
       }
+      if constexpr (H16) {
+        bn_st4_bf16(reinterpret_cast<uint16_t*>(out_) + (r + 16 * u) * ldo + j0, o);
+        continue;
+      }
       float* dst = out + (r + 16 * u) * ldo + j0;
       if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
       else
@@ -165,13 +188,14 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, int C, cons
 }
 
 // dz = gate ? dout * keep_scale * (out != 0) : dout ;  partial sums of (dz, dz * xhat)
-template <bool VEC>
+template <bool VEC, bool H16 = false>
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_bwd_sums_kernel(const float* __restrict__ dout, int64_t ldd, const float* __restrict__ x, int64_t ldx,
-                   const float* __restrict__ out, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
+                   const void* __restrict__ out_, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
                    const float* __restrict__ rstd, int gate, float keep_scale, int64_t rows_per_slab,
                    double* __restrict__ partial) {
   __shared__ double red[16][BN_COLS + 1][2];
+  const float* out = reinterpret_cast<const float*>(out_);
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int j0 = blockIdx.x * BN_COLS + cq * 4;
   const int valid = C - j0;
@@ -189,7 +213,8 @@ bn_bwd_sums_kernel(const float* __restrict__ dout, int64_t ldd, const float* __r
         const int64_t rr = (r + 16 * u < hi) ? r + 16 * u : r;
         vd[u] = bn_ld4(dout + rr * ldd + j0, VEC, valid);
         vx[u] = bn_ld4(x + rr * ldx + j0, VEC, valid);
-        vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (H16) vo[u] = gate ? bn_ld4_gate16(reinterpret_cast<const uint16_t*>(out_) + rr * ldo + j0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        else vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -238,13 +263,15 @@ bn_bwd_final_kernel(const double* __restrict__ partial, int n_slabs, int64_t M, 
 }
 
 // batch statistics: dx = gamma rstd (dz - mean(dz) - xhat mean(dz xhat)); fixed statistics: gamma rstd dz
-template <bool VEC>
+template <bool VEC, bool H16 = false>
 __global__ void __launch_bounds__(RX_BLOCK)
 bn_bwd_dx_kernel(const float* __restrict__ dout, int64_t ldd, const float* __restrict__ x, int64_t ldx,
-                 const float* __restrict__ out, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
+                 const void* __restrict__ out_, int64_t ldo, int64_t M, int C, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ coef,
-                 int gate, float keep_scale, int batch_stats, float* __restrict__ dx, int64_t lddx,
+                 int gate, float keep_scale, int batch_stats, void* __restrict__ dx_, int64_t lddx,
                  int64_t rows_per_slab) {
+  const float* out = reinterpret_cast<const float*>(out_);
+  float* dx = reinterpret_cast<float*>(dx_);
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int j0 = blockIdx.x * BN_COLS + cq * 4;
   const int valid = C - j0;
@@ -268,7 +295,8 @@ bn_bwd_dx_kernel(const float* __restrict__ dout, int64_t ldd, const float* __res
       const int64_t rr = (u == 0 || second) ? r + 16 * u : r;
       vd[u] = bn_ld4(dout + rr * ldd + j0, VEC, valid);
       vx[u] = bn_ld4(x + rr * ldx + j0, VEC, valid);
-      vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (H16) vo[u] = gate ? bn_ld4_gate16(reinterpret_cast<const uint16_t*>(out_) + rr * ldo + j0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      else vo[u] = gate ? bn_ld4(out + rr * ldo + j0, VEC, valid) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -282,6 +310,10 @@ bn_bwd_dx_kernel(const float* __restrict__ dout, int64_t ldd, const float* __res
         const float dz = gate ? (oe[t] != 0.f ? d[t] * keep_scale : 0.f) : d[t];
         const float xh = (xe[t] - mu[t]) * rs[t];
         o[t] = gg[t] * (dz - c0[t] - xh * c1[t]);
+      }
+      if constexpr (H16) {
+        bn_st4_bf16(reinterpret_cast<uint16_t*>(dx_) + (r + 16 * u) * lddx + j0, o);
+        continue;
       }
       float* dst = dx + (r + 16 * u) * lddx + j0;
       if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -380,6 +412,62 @@ extern "C" int rx_bn_bwd(const float* d_dout, int64_t ldd, const float* d_x, int
   const dim3 egrid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)eslabs);
   if (vec) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, egrid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx, erows);
   else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, egrid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, d_out, ldo, M, C, d_mean, d_rstd, d_gamma, (const float*)coef, gate, keep_scale, batch_stats, d_dx, lddx, erows);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- the same two passes for towers that keep their activations in bf16: the normalised output is
+// written as bf16 only (the next matrix product rounds it to bf16 anyway; the ReLU / dropout gate
+// only needs to know where it is zero), and the backward pass reads that gate and writes its
+// gradient -- an operand of the two products behind it -- as bf16
+static inline bool bn_vec16(const void* p, int64_t ld, int C) { return (ld % 4 == 0) && (C % 4 == 0) && ((uintptr_t)p % 8 == 0); }
+
+extern "C" int rx_bn_apply16(const float* d_x, int64_t ldx, int64_t M, int32_t C, const float* d_mean,
+                             const float* d_rstd, const float* d_gamma, const float* d_beta, int relu,
+                             const uint8_t* d_keep, float keep_scale, uint16_t* d_out16, int64_t ldo, int device,
+                             void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0 && ldx >= C && ldo >= C, "rx_bn_apply16: bad shape (C a multiple of 4)");
+  if (M == 0) return 0;
+  RX_REQUIRE(d_x && d_mean && d_rstd && d_out16, "rx_bn_apply16: null argument");
+  RX_REQUIRE(bn_vec(d_x, ldx, C) && bn_vec16(d_out16, ldo, C), "rx_bn_apply16: rows must be 16-byte (input) and 8-byte (output) addressable");
+  int64_t rows;
+  const int slabs = bn_ew_slabs(M, C, &rows);
+  const dim3 grid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)slabs);
+  hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(RX_BLOCK), 0, (hipStream_t)stream, d_x, ldx, M, C, d_mean, d_rstd, d_gamma, d_beta,
+                     relu, d_keep, keep_scale, (void*)d_out16, ldo, rows);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_bn_bwd16(const float* d_dout, int64_t ldd, const float* d_x, int64_t ldx, const uint16_t* d_out16,
+                           int64_t ldo, int64_t M, int32_t C, const float* d_mean, const float* d_rstd,
+                           const float* d_gamma, int gate, float keep_scale, int batch_stats, uint16_t* d_dx16,
+                           int64_t lddx, float* d_dgamma, float* d_dbeta, void* ws, size_t ws_bytes, int device,
+                           void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(M >= 1 && C >= 4 && C % 4 == 0 && ldd >= C && ldx >= C && lddx >= C && (!gate || ldo >= C), "rx_bn_bwd16: bad shape (C a multiple of 4)");
+  RX_REQUIRE(d_dout && d_x && d_mean && d_rstd && d_dx16 && ws && (!gate || d_out16), "rx_bn_bwd16: null argument");
+  RX_REQUIRE(ws_bytes >= rx_bn_workspace_bytes(M, C), "rx_bn_bwd16: workspace too small");
+  RX_REQUIRE(bn_vec(d_dout, ldd, C) && bn_vec(d_x, ldx, C) && bn_vec16(d_dx16, lddx, C) && (!gate || bn_vec16(d_out16, ldo, C)),
+             "rx_bn_bwd16: rows must be 16-byte (fp32) and 8-byte (bf16) addressable");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t rows;
+  const int slabs = bn_slabs(M, &rows);
+  double* partial = (double*)ws;
+  float* coef = (float*)((char*)ws + rx_align_up((size_t)BN_SLABS * C * 2 * sizeof(double), 256));
+  const dim3 grid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)slabs);
+  hipLaunchKernelGGL((bn_bwd_sums_kernel<true, true>), grid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, (const void*)d_out16, ldo, M, C, d_mean, d_rstd,
+                     gate, keep_scale, rows, partial);
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)rx_cdiv(C, 64)), dim3(RX_BLOCK), 0, st, (const double*)partial, slabs, M, C, d_dgamma, d_dbeta, coef);
+  RX_LAUNCH_CHECK();
+  int64_t erows;
+  const int eslabs = bn_ew_slabs(M, C, &erows);
+  const dim3 egrid((unsigned)rx_cdiv(C, BN_COLS), 1, (unsigned)eslabs);
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<true, true>), egrid, dim3(RX_BLOCK), 0, st, d_dout, ldd, d_x, ldx, (const void*)d_out16, ldo, M, C, d_mean, d_rstd,
+                     d_gamma, (const float*)coef, gate, keep_scale, batch_stats, (void*)d_dx16, lddx, erows);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -82,6 +82,10 @@ def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = N
         for m in chain:
             wb += [m.weight, m.bias]
         return rxa.MLPStack16.apply(x, x16, *wb)
+    if bf16 and os.environ.get("RX_NO_BF16_STORAGE") != "1" and x.dim() == 2 and x.is_cuda:
+        y = rxa.bn_tower16(seq, x)      # the reference's BatchNorm tower with bf16 operand storage
+        if y is not None:
+            return y
     i = 0
     while i < len(mods):
         m = mods[i]

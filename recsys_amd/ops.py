@@ -1105,10 +1105,12 @@ def _mat16(t: Tensor, name: str) -> Tuple[Tensor, int]:
 
 
 def _padded16(rows: int, cols: int, device) -> Tensor:
-    """bf16 [rows, cols] whose row stride is a multiple of 8 elements (16 bytes)."""
+    """bf16 [rows, cols] whose row stride is a multiple of 8 elements (16 bytes); padding columns are
+    zero and stay zero (the kernels read and write whole 16-byte pieces)."""
     cp = (cols + 7) // 8 * 8
-    buf = torch.empty(rows, cp, dtype=torch.bfloat16, device=device)
-    return buf if cp == cols else buf[:, :cols]
+    if cp == cols:
+        return torch.empty(rows, cp, dtype=torch.bfloat16, device=device)
+    return torch.zeros(rows, cp, dtype=torch.bfloat16, device=device)[:, :cols]
 
 
 def to_bf16(x: Tensor, transpose: bool = False) -> Tensor:
@@ -1214,3 +1216,35 @@ def cross16_bwd(dxn, x0, u, dx0_acc, accumulate: bool, identity: bool, want_dxl:
     check(lib.rx_cross16_bwd(_p(dxn), ldd, _p(x0), ld0, _p(u), ldu, _p(du16), du16.stride(0), _p(dx0_acc), ldx0, _p(dxl), ldxl,
                              rows, cols, int(accumulate), int(identity), _dev(dxn), _stream(dxn)), "rx_cross16_bwd")
     return du16, dxl
+
+
+def bn_apply16(x: Tensor, mean: Tensor, rstd: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], relu: bool,
+               keep: Optional[Tensor] = None, keep_scale: float = 1.0) -> Tensor:
+    """rx_bn_apply16: the normalised (+ ReLU, + dropout) output as bf16 only."""
+    x, ldx = _mat(x, "x")
+    M, C = x.shape
+    if keep is not None and not (keep.dtype == torch.uint8 and keep.is_contiguous() and tuple(keep.shape) == (M, C)):
+        raise ValueError("keep: expected a contiguous uint8 [M, C] mask")
+    out = _padded16(M, C, x.device)
+    check(lib.rx_bn_apply16(_p(x), ldx, M, C, _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(keep), keep_scale,
+                            _p(out), out.stride(0) if M > 1 else max(C, out.stride(0)), _dev(x), _stream(x)), "rx_bn_apply16")
+    return out
+
+
+def bn_bwd16(dout: Tensor, x: Tensor, out16: Optional[Tensor], mean: Tensor, rstd: Tensor, gamma: Optional[Tensor],
+             gate: bool, keep_scale: float, batch_stats: bool):
+    """rx_bn_bwd16: (dx as bf16, dgamma, dbeta); ``out16`` is the bf16 output of bn_apply16 (the gate)."""
+    dout, ldd = _mat(dout, "dout")
+    x, ldx = _mat(x, "x")
+    M, C = x.shape
+    ldo = 0
+    if gate:
+        out16, ldo = _mat16(out16, "out16")
+    dx = _padded16(M, C, x.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _ws(int(lib.rx_bn_workspace_bytes(M, C)), x.device)
+    check(lib.rx_bn_bwd16(_p(dout), ldd, _p(x), ldx, _p(out16) if gate else None, ldo, M, C, _p(mean), _p(rstd), _p(gamma),
+                          int(gate), keep_scale, int(batch_stats), _p(dx), dx.stride(0) if M > 1 else max(C, dx.stride(0)),
+                          _p(dgamma), _p(dbeta), _p(ws), ws.numel(), _dev(x), _stream(x)), "rx_bn_bwd16")
+    return dx, dgamma, dbeta

@@ -49,6 +49,56 @@ def test_forward_loss_grads(name, kw, rtol):
         assert_close(m(dbatch).cpu().numpy(), oracle(batch).numpy(), rtol=rtol, what="eval logits")
 
 
+def test_deepfm_benchmark_shape_bf16_operands():
+    """FieldDeepFM with bf16 tower operands (autograd.BNTower16: bf16 activation storage between the
+    layers) at the benchmark's architecture -- 26 fields, D = 16, 13 dense features, BatchNorm tower
+    432-432-216-108-1 -- at batch 4096: loss, logits and every gradient within 1e-2 of the oracle that
+    rounds the operands of every matrix product to bfloat16; BatchNorm buffers like the oracle's."""
+    from oracle.fields import FieldOracle
+    from recsys_amd import synthetic
+    from recsys_amd.models import fields
+    dims = synthetic.criteo_field_dims(total_rows=2_000_000)
+    B = 4096
+    torch.manual_seed(10)
+    m = fields.FieldDeepFM(dims, 16, n_dense=13, dropout=0.0, bf16=True)
+    with torch.no_grad():
+        m.feature_embedding.weight.mul_(0.05)      # N(0, 1) rows over 26 fields saturate the FM term
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    oracle = FieldOracle("FieldDeepFM", state, dims, bf16=True)
+    batch = synthetic.criteo_batch(dims, B, seed=6, device="cpu")
+    dbatch = {k: v.cuda() for k, v in batch.items()}
+    m = m.cuda()
+    oracle.train(); m.train()
+    lo, lm = oracle.loss(batch), m.loss(dbatch)
+
+    def nodes(fn, seen):
+        if fn is not None and fn not in seen:
+            seen.add(fn)
+            for nxt, _ in fn.next_functions:
+                nodes(nxt, seen)
+        return seen
+    assert any(type(f).__name__ == "BNTower16Backward" for f in nodes(lm.grad_fn, set())), "the bf16-storage tower did not run"
+    assert_close(lm.item(), lo.item(), rtol=1e-2, what="loss")
+    lo.backward(); lm.backward()
+    params = dict(m.named_parameters())
+    for k, p in oracle.params.items():
+        # Linear biases in front of BatchNorm have a zero gradient in exact arithmetic: both sides hold
+        # rounding noise only -- here the column sums of a bf16-rounded gradient whose exact sum is 0,
+        # i.e. up to 2^-9 of the summed magnitudes (the weights' gradients are 1e-3 .. 1e-2)
+        zero_grad_bias = k.endswith(".bias") and k != "deep_mlp.12.bias" and "deep_mlp" in k and int(k.split(".")[1]) % 4 == 0
+        assert_close(params[k].grad.cpu().numpy(), p.grad.numpy(), rtol=1e-2, what=f"grad {k}", elem_rtol=False,
+                     atol=1e-4 if zero_grad_bias else 0.0)
+    sd = m.state_dict()
+    for k, v in oracle.buffers.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v)
+        else:
+            assert_close(sd[k].cpu().numpy(), v.numpy(), rtol=1e-2, what=k)
+    oracle.eval(); m.eval()
+    with torch.no_grad():
+        assert_close(m(dbatch).cpu().numpy(), oracle(batch).numpy(), rtol=1e-2, what="eval logits")
+
+
 def test_dcnv2_benchmark_shape_bf16_operands():
     """DCN-v2 at the benchmark's architecture -- 26 fields, D = 16, 13 dense features, 3 cross layers,
     MLP 1024-512-256, bf16 GEMM operands with fp32 accumulation -- at batch 4096: logits, loss and

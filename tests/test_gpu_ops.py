@@ -652,45 +652,56 @@ def test_to_bf16_and_transposed_copy(ops):
     assert torch.equal(ops.to_bf16(view), view.bfloat16())
 
 
+def _dev16(t):
+    """A bf16 matrix on the device the way the kernels want it: rows padded with zeros to 8 elements."""
+    from recsys_amd import ops as o
+    out = o._padded16(t.shape[0], t.shape[1], "cuda")
+    out.copy_(t)
+    return out
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 432, 432), (513, 104, 216), (4096, 1024, 432), (130, 256, 512), (129, 8, 8),
-                                   (300, 1, 256), (4097, 1, 64)])
+                                   (300, 1, 256), (4097, 1, 64), (777, 108, 216), (777, 216, 108), (300, 1, 108), (200, 12, 20)])
 def test_linear16_matches_products_of_the_rounded_operands(ops, M, N, K):
     """Forward (bf16 and fp32 output, bias, ReLU), input gradient (fp32, accumulated, and bf16 with the
-    ReLU gate) and weight gradient + column sums against fp64 products of the bf16-rounded operands."""
+    ReLU gate) and weight gradient + column sums against fp64 products of the bf16-rounded operands;
+    widths that are multiples of 4 but not of 8 ride on the zero padding of the bf16 rows."""
     g = _gen(M + N + K)
     x16 = torch.randn(M, K, generator=g).bfloat16()
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
     ref = x16.double() @ _r16(w).double().t() + b.double()
-    y32 = ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=False, out_bf16=False)
+    y32 = ops.linear16_fwd(_dev16(x16), w.cuda(), b.cuda(), relu=False, out_bf16=False)
     assert y32.dtype == torch.float32
     assert_close(y32.cpu().numpy(), ref.numpy(), rtol=1e-5, what="linear16 fwd fp32")
     if N > 1:
-        y16 = ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=True, out_bf16=True)
+        y16 = ops.linear16_fwd(_dev16(x16), w.cuda(), b.cuda(), relu=True, out_bf16=True)
         assert y16.dtype == torch.bfloat16
         # one bf16 rounding of the fp32 result: within half a bf16 ulp (2^-9) of the exact value
         assert_close(y16.float().cpu().numpy(), ref.relu().numpy(), rtol=2.0 ** -8, what="linear16 fwd bf16", elem_rtol=False)
-        assert torch.equal(y16.cpu(), ops.linear16_fwd(x16.cuda(), w.cuda(), b.cuda(), relu=True, out_bf16=False).bfloat16().cpu())
+        assert torch.equal(y16.cpu(), ops.linear16_fwd(_dev16(x16), w.cuda(), b.cuda(), relu=True, out_bf16=False).bfloat16().cpu())
+        assert not y16.as_strided((M, (N + 7) // 8 * 8), (y16.stride(0), 1))[:, N:].any(), "row padding must stay zero"
     dy16 = torch.randn(M, N, generator=g).bfloat16()
     refx = dy16.double() @ _r16(w).double()
     if N > 1:
-        dx = ops.linear16_bwd_x(dy16.cuda(), w.cuda(), out_bf16=False)
+        dx = ops.linear16_bwd_x(_dev16(dy16), w.cuda(), out_bf16=False)
         assert_close(dx.cpu().numpy(), refx.numpy(), rtol=1e-5, what="linear16 bwd x")
         base = torch.randn(M, K, generator=g)
         acc = base.clone().cuda()
-        ops.linear16_bwd_x(dy16.cuda(), w.cuda(), out=acc, accumulate=True)
+        ops.linear16_bwd_x(_dev16(dy16), w.cuda(), out=acc, accumulate=True)
         assert_close(acc.cpu().numpy(), (base.double() + refx).numpy(), rtol=1e-5, what="linear16 bwd x accumulated")
     gate = torch.randn(M, K, generator=g).relu().bfloat16()
     gate[0, 0] = -0.0
-    dz = ops.linear16_bwd_x(dy16.cuda(), w.cuda(), gate16=gate.cuda(), out_bf16=True)
+    dz = ops.linear16_bwd_x(_dev16(dy16), w.cuda(), gate16=_dev16(gate), out_bf16=True)
     expz = torch.where(gate.float() > 0, refx, torch.zeros_like(refx))
     assert dz.dtype == torch.bfloat16
     assert_close(dz.float().cpu().numpy(), expz.numpy(), rtol=2.0 ** -8, what="linear16 bwd x gated", elem_rtol=False)
     assert not dz.float().cpu()[gate.float() <= 0].any()
-    dw, db = ops.linear16_bwd_w(dy16.cuda(), x16.cuda(), True)
+    assert not dz.as_strided((M, (K + 7) // 8 * 8), (dz.stride(0), 1))[:, K:].any(), "row padding must stay zero"
+    dw, db = ops.linear16_bwd_w(_dev16(dy16), _dev16(x16), True)
     assert_close(dw.cpu().numpy(), (dy16.double().t() @ x16.double()).numpy(), rtol=1e-5, what="linear16 bwd w")
     assert_close(db.cpu().numpy(), dy16.double().sum(0).numpy(), rtol=1e-5, what="linear16 bias grad")
-    dw2, _ = ops.linear16_bwd_w(dy16.cuda(), x16.cuda(), True)
+    dw2, _ = ops.linear16_bwd_w(_dev16(dy16), _dev16(x16), True)
     assert torch.equal(dw, dw2)
 
 
