@@ -485,7 +485,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded",
+    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
@@ -674,6 +674,8 @@ def main():
                 continue
             # the 64 GB-table workloads need a longer warm-up (allocator growth, first touches)
             n2, wu2 = (96, 24) if name in ("fm_wide_d128", "fm_criteo_sharded") else (30, 5)
+            if name == "deepfm_wide_d128_sharded":
+                n2, wu2 = 12, 3        # 20-30 ms per step; the 24 set-up steps of run() come on top
             if name in ("mf_ml1m", "neumf_ml1m"):
                 n2, wu2 = 200, 20      # steps of 0.1-0.4 ms: a 30-step region is a few ms and one hiccup doubles it
             w2, el2, _, _ = run(name, n2, wu2)
@@ -684,6 +686,9 @@ def main():
                 b2 = embedding_bytes_per_sample(w2["desc"], r2)
                 entry["embedding_hbm_frac"] = b2 * entry["samples_per_s"] / 1e9 / HBM_PEAK_GBS
                 entry["distinct_row_fraction"] = r2
+            if name == "deepfm_wide_d128_sharded":
+                entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"],
+                             role="the 1 B-row x 128 DeepFM as named, one rank's share (125 M rows, tower 3344-3344-1672-836-1)")
             if name == "fm_criteo_sharded":
                 # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
                 entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")
