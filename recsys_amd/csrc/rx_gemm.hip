@@ -1187,7 +1187,7 @@ extern "C" int rx_cross_combine_bwd_stack(const float* dxn, int64_t ldd, const f
 #define H_NP (H_BK / 16)        // pieces per thread and operand
 #define H_T 128
 #define H_LDR (H_T + 32)
-#define H_LDC (H_T + 8)   // fp32 image of the output tile: rows 4 apart land 32 banks apart
+#define H_LDC (H_T + 4)   // fp32 image of the output tile: 16 consecutive rows of one 16-byte column piece cover all 64 banks
 
 struct Gemm16Args {
   const uint16_t* A; int64_t lda;   // K-contiguous: A(i,k) = A[i*lda + k]; else A(i,k) = A[k*lda + i]
@@ -1297,6 +1297,16 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // the bias entries of this thread's epilogue columns, fetched now: behind the K loop their latency
+  // would sit between the tile's last MFMA and its first store
+  constexpr bool BIAS = KC && !GATE && !ACCUM;   // the instantiations a forward product can take
+  float bias_r[BIAS ? (OUT16 ? 8 : 4) : 1];
+  if constexpr (BIAS) {
+    const int64_t col = n0 + (OUT16 ? (tid & 15) * 8 : (tid & 31) * 4);
+#pragma unroll
+    for (int e = 0; e < (OUT16 ? 8 : 4); ++e) bias_r[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+  }
+
   HRegs ra, rb;
   auto fetch = [&](int64_t k0) {
     if constexpr (KC) {
@@ -1332,16 +1342,18 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T tile: see the epilogue
     }
     if (more) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
-  // epilogue: the accumulators (C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) go
-  // through an fp32 LDS image of the tile, so that the output, the gate and the accumulate operand
-  // are all touched as whole 16-byte pieces of contiguous rows
+  // epilogue: the products were issued with the operands swapped, so an accumulator tile is C^T in the
+  // C/D layout: a lane holds ONE output row (lane & 31) and, per group q = r >> 2, four consecutive
+  // output columns 8 q + 4 (lane >> 5) + (r & 3).  They go through an fp32 LDS image of the tile with
+  // 16-byte writes, so that the output, the gate and the accumulate operand are all touched as whole
+  // 16-byte pieces of contiguous rows
   float* ct = reinterpret_cast<float*>(h_lds);
   const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll 1
@@ -1353,8 +1365,9 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * H_LDC + (wave_n * 2 + j) * 32 + l31] = acc[i][j][r];
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(&ct[(i * 32 + l31) * H_LDC + (wave_n * 2 + j) * 32 + 8 * q + 4 * h]) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }
     __syncthreads();
     const int64_t mh = m0 + 64 * half;
@@ -1365,7 +1378,7 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
       if (col < g.N) {   // a piece that straddles N ends in the row's zero padding (leading dimensions are multiples of 8)
         float bv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bv[e] = BIAS ? bias_r[BIAS ? e : 0] : 0.f;
         uint16_t* C16 = reinterpret_cast<uint16_t*>(g.C);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1401,8 +1414,7 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
       const int c4 = (tid & 31) * 4;
       const int64_t col = n0 + c4;
       if (col < g.N) {
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.bias) bv = make_float4(g.bias[col], g.bias[col + 1], g.bias[col + 2], g.bias[col + 3]);
+        const float4 bv = BIAS ? make_float4(bias_r[0], bias_r[BIAS ? 1 : 0], bias_r[BIAS ? 2 : 0], bias_r[BIAS ? 3 : 0]) : make_float4(0.f, 0.f, 0.f, 0.f);
         float* Cf = reinterpret_cast<float*>(g.C) + (int64_t)blockIdx.z * g.c_slab_stride;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {

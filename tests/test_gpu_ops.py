@@ -705,6 +705,19 @@ def test_linear16_matches_products_of_the_rounded_operands(ops, M, N, K):
     assert torch.equal(dw, dw2)
 
 
+def test_linear16_tile_layout_asymmetric(ops):
+    """A = I against an asymmetric integer-valued B: exact in bf16, so a transposed or permuted
+    accumulator write in the LDS-staged epilogue shows as a wrong entry, in every output form."""
+    n = 200
+    x16 = _dev16(torch.eye(n).bfloat16())
+    w = ((torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 40.0).cuda()
+    assert torch.equal(ops.linear16_fwd(x16, w, None, relu=False, out_bf16=False), w.t())
+    assert torch.equal(ops.linear16_fwd(x16, w, None, relu=False, out_bf16=True).float(), w.t())
+    assert torch.equal(ops.linear16_bwd_x(x16, w, out_bf16=False), w)                      # dX = I W
+    dw, _ = ops.linear16_bwd_w(_dev16(w.bfloat16().cpu()), x16, False)                     # dW = W^T I
+    assert torch.equal(dw, w.t())
+
+
 def test_cross16_combine_matches_torch(ops):
     g = _gen(11)
     rows, cols = 777, 432
