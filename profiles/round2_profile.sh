@@ -14,7 +14,9 @@ if [ "$what" = stats ]; then
   cat $O/fm_criteo_dominant_kernel_durations.txt
 else
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --gpus 1 --steps 6 --warmup 2 --repeats 1 --no-graph --extra none --no-cpu-baseline > $O/pmc_$c.log 2>&1 || exit 1
+    # few resident batches: under --pmc every dispatch is serialised and takes about a millisecond
+    RX_BENCH_BATCHES=4 timeout -s KILL 170 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --gpus 1 --steps 4 --warmup 1 --repeats 1 --no-graph --extra none --no-cpu-baseline > $O/pmc_$c.log 2>&1 || exit 1
+    echo pass $c done
   done
   python3 $R/profiles/pmc_traffic.py $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv | head -n 1) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv | head -n 1) > $O/fm_criteo_eager_pmc_traffic.txt || exit 1
   cp $R/profiles/pmc_traffic.json $O/pmc_traffic.json
