@@ -287,6 +287,32 @@ int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
                  float* d_state2, int64_t n_rows, float lr, float eps, const float* d_scale,
                  float* d_sq_part, void* ws, size_t ws_bytes, int device, void* stream);
 
+/* Up to RX_SEG_MULTI_MAX tables in one pair of launches (the user / item tables of the MF and NCF
+ * families, recsys/models/matrix_factorization/ and recsys/models/neuralcf/: a few thousand
+ * occurrences per table, where a launch per table costs more than its work).  Every field as in
+ * rx_segreduce; mode, lr, eps and the clip factor are shared.  Each table keeps its own blocks,
+ * pieces and partials, so every result equals that of one rx_segreduce call per table bit for bit.
+ * The widths of one call must share the lane layout (equal widths always do).  sq_part of table i
+ * (may be NULL) has rx_segreduce_grid(n_i, dim_i) entries; ws holds the tables' workspaces back to
+ * back: sum of rx_segreduce_workspace_bytes(n_i, dim_i).
+ * rx_row_update_multi: rx_row_update for the same list, where occ / occ2 are the compact gradients
+ * [*n_uniq, dim] / [*n_uniq], n the capacity of those buffers, target / target2 the tables; a
+ * table may appear once per call. */
+#define RX_SEG_MULTI_MAX 8
+typedef struct rx_seg_table {
+  const float* occ; int64_t occ_ld; int64_t n; int32_t dim;
+  const int32_t* sorted_pos; const int32_t* sorted_slot; const int64_t* uniq_rows;
+  const int32_t* seg_off; const int32_t* n_uniq;
+  float* target; float* state;
+  const float* occ2; float* target2; float* state2;
+  int64_t n_rows;
+  float* sq_part;
+} rx_seg_table;
+int rx_segreduce_multi(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps,
+                       const float* d_scale, void* ws, size_t ws_bytes, int device, void* stream);
+int rx_row_update_multi(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps,
+                        const float* d_scale, int device, void* stream);
+
 /* FM-fused variant for N == 1 (every sample contributes one row per field, e.g. the 26-field
  * Criteo-shaped FM): the gradient of row r in sample b is g_b * (T_b - e_r), so
  *   G_r = sum_b g_b T_b  -  (sum_b g_b) * e_r        and the bias gradient is sum_b g_b.

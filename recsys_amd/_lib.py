@@ -61,6 +61,16 @@ class TensorList(C.Structure):
                 ("n", i64 * RX_MULTI_MAX), ("count", i32)]
 
 
+RX_SEG_MULTI_MAX = 8
+
+
+class SegTable(C.Structure):
+    _fields_ = [("occ", vp), ("occ_ld", i64), ("n", i64), ("dim", i32),
+                ("sorted_pos", vp), ("sorted_slot", vp), ("uniq_rows", vp), ("seg_off", vp), ("n_uniq", vp),
+                ("target", vp), ("state", vp), ("occ2", vp), ("target2", vp), ("state2", vp),
+                ("n_rows", i64), ("sq_part", vp)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/recsys_hip.h
 PROTOTYPES = {
     "rx_abi_version": (C.c_int, []),
@@ -98,6 +108,8 @@ PROTOTYPES = {
     "rx_fm2_fwd_bce": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp, vp, i64, vp, vp, sz, vp, C.c_int, vp]),
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_segreduce_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, vp, sz, C.c_int, vp]),
+    "rx_row_update_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),
     "rx_bn_apply16": (C.c_int, [vp, i64, i64, i32, vp, vp, vp, vp, C.c_int, vp, f32, vp, i64, C.c_int, vp]),
     "rx_bn_bwd16": (C.c_int, [vp, i64, vp, i64, vp, i64, i64, i32, vp, vp, vp, C.c_int, f32, C.c_int, vp, i64, vp, vp, vp, sz,

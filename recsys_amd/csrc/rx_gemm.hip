@@ -1452,11 +1452,14 @@ static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
   const int64_t blocks = rx_cdiv(g.M, H_T) * g.tiles_n;
   RX_REQUIRE(blocks < (1ll << 31), "gemm16: grid too large");
   const size_t lds = H_LDS_BYTES(KC);
-  static bool raised = false;   // per instantiation: 72 KB / 80 KB of dynamic LDS need the attribute once
-  if (!raised) {
+  // 72 KB / 80 KB of dynamic LDS need the attribute once per instantiation and device
+  static bool raised[64] = {};
+  int device = 0;
+  RX_HIP(hipGetDevice(&device));
+  if (device < 0 || device >= 64 || !raised[device]) {
     RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = true;
+    if (device >= 0 && device < 64) raised[device] = true;
   }
   const int swz = (blocks % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);

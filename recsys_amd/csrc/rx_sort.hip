@@ -479,6 +479,214 @@ add_tile_offsets_kernel(uint32_t* __restrict__ data, int64_t total, const uint32
     if (base + e < total) data[base + e] += off;
 }
 
+// ---------------------------------------------------------------- short lists: one launch
+// A list of at most SMALL_MAX positions (the user / item lists of a MovieLens-sized batch) is
+// sorted and compacted by ONE workgroup: 16 wavefronts, 8 keys per lane, the pairs staged in LDS
+// between the passes.  The ranking is the one of sort_scatter_kernel (ballot match inside the
+// wavefront, wavefront-private digit counters, prefix over the wavefronts), so the order is the
+// same stable order and every output equals that of the multi-launch path; what goes away is a
+// chain of about ten dependent launches that cost more than the work.
+#define SMALL_THREADS 1024
+#define SMALL_ITEMS 8
+#define SMALL_MAX (SMALL_THREADS * SMALL_ITEMS)
+#define SMALL_WAVES (SMALL_THREADS / 64)
+#define SMALL_WAVE_KEYS (64 * SMALL_ITEMS)
+#define SMALL_BITS 8
+#define SMALL_BINS (1 << SMALL_BITS)
+
+__device__ __forceinline__ uint32_t small_block_scan(uint32_t v, uint32_t* lds16, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) lds16[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < SMALL_WAVES; ++w) {
+    const uint32_t c = lds16[w];
+    base += w < wave ? c : 0u;
+    all += c;
+  }
+  if (total) *total = all;
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <int BITS>
+__device__ __forceinline__ void small_match(const uint32_t (&key)[SMALL_ITEMS], int shift, int wbase, int lane, int n,
+                                            unsigned long long (&peers)[SMALL_ITEMS]) {
+#pragma unroll
+  for (int it = 0; it < SMALL_ITEMS; ++it) {
+    const bool live = (wbase + it * 64 + lane) < n;
+    const uint32_t d = (key[it] >> shift) & ((1u << BITS) - 1);
+    unsigned long long p = __ballot(live);
+#pragma unroll
+    for (int bit = 0; bit < BITS; ++bit) {
+      const int32_t sb = (int32_t)(d << (31 - bit)) >> 31;
+      const unsigned long long m = __ballot(sb != 0);
+      p &= ~(m ^ (unsigned long long)(long long)sb);
+    }
+    peers[it] = live ? p : 0ull;
+  }
+}
+
+template <int RAW>
+__global__ void __launch_bounds__(SMALL_THREADS)
+sort_dedup_small_kernel(RawSrc src, int n, int64_t n_rows, int passes, int bits, int32_t* __restrict__ sorted_pos,
+                        int32_t* __restrict__ sorted_slot, int64_t* __restrict__ uniq_rows,
+                        int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq, int32_t* __restrict__ inverse,
+                        int32_t* err_flag) {
+  // dynamic LDS: [SMALL_MAX] keys | [SMALL_MAX] positions | [SMALL_WAVES][SMALL_BINS] counters | [SMALL_BINS] digit starts
+  extern __shared__ uint32_t dyn[];
+  __shared__ uint32_t lds16[SMALL_WAVES];
+  uint32_t* sk = dyn;
+  uint32_t* sv = dyn + SMALL_MAX;
+  uint32_t* wave_cnt = dyn + 2 * SMALL_MAX;
+  uint32_t* dstart = wave_cnt + SMALL_WAVES * SMALL_BINS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wbase = wave * SMALL_WAVE_KEYS;
+  const int bins = 1 << bits;
+  uint32_t* my_cnt = wave_cnt + wave * bins;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t key[SMALL_ITEMS], val[SMALL_ITEMS], rank[SMALL_ITEMS];
+  bool any_bad = false;
+#pragma unroll
+  for (int it = 0; it < SMALL_ITEMS; ++it) {
+    const int i = wbase + it * 64 + lane;
+    const int ii = i < n ? i : n - 1;
+    bool bad;
+    key[it] = raw_key<RAW>(src, ii, n_rows, &bad);
+    any_bad |= bad;
+    val[it] = (uint32_t)ii;
+  }
+  if (any_bad && err_flag) atomicOr(err_flag, RX_ERR_INDEX);
+  for (int p = 0; p < passes; ++p) {
+    const int shift = p * bits;
+    for (int i = threadIdx.x; i < SMALL_WAVES * bins; i += SMALL_THREADS) wave_cnt[i] = 0;
+    __syncthreads();
+    unsigned long long peers[SMALL_ITEMS];
+    switch (bits) {
+#define SMALL_CASE(B) case B: small_match<B>(key, shift, wbase, lane, n, peers); break;
+      SMALL_CASE(1) SMALL_CASE(2) SMALL_CASE(3) SMALL_CASE(4) SMALL_CASE(5) SMALL_CASE(6) SMALL_CASE(7) SMALL_CASE(8)
+#undef SMALL_CASE
+    }
+#pragma unroll
+    for (int it = 0; it < SMALL_ITEMS; ++it) {
+      const uint32_t d = (key[it] >> shift) & (bins - 1);
+      const unsigned long long pe = peers[it];
+      uint32_t base = 0;
+      if (pe) base = my_cnt[d];
+      if (pe && lane == __ffsll((long long)pe) - 1) my_cnt[d] = base + (uint32_t)__popcll(pe);
+      rank[it] = base + (uint32_t)__popcll(pe & lt_mask);
+    }
+    __syncthreads();
+    // per digit: exclusive prefix over the wavefronts, and the digit's total
+    uint32_t total_d = 0;
+    if ((int)threadIdx.x < bins) {
+      const int d = threadIdx.x;
+#pragma unroll
+      for (int w = 0; w < SMALL_WAVES; ++w) {
+        const uint32_t c = wave_cnt[w * bins + d];
+        wave_cnt[w * bins + d] = total_d;
+        total_d += c;
+      }
+    }
+    const uint32_t start_d = small_block_scan(total_d, lds16, nullptr);   // (syncs inside)
+    if ((int)threadIdx.x < bins) dstart[threadIdx.x] = start_d;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < SMALL_ITEMS; ++it) {
+      const uint32_t d = (key[it] >> shift) & (bins - 1);
+      if (wbase + it * 64 + lane < n) {
+        const uint32_t r = rank[it] + dstart[d] + my_cnt[d];
+        sk[r] = key[it];
+        sv[r] = val[it];
+      }
+    }
+    __syncthreads();
+    if (p + 1 < passes) {
+#pragma unroll
+      for (int it = 0; it < SMALL_ITEMS; ++it) {
+        const int i = wbase + it * 64 + lane;
+        const int ii = i < n ? i : n - 1;
+        key[it] = sk[ii];
+        val[it] = sv[ii];
+      }
+      __syncthreads();
+    }
+  }
+  // run-length compaction: a thread takes SMALL_ITEMS consecutive sorted entries
+  const int base = threadIdx.x * SMALL_ITEMS;
+  uint32_t k[SMALL_ITEMS], v[SMALL_ITEMS];
+  bool head[SMALL_ITEMS];
+  uint32_t c = 0;
+  const uint32_t prev = (base > 0 && base < n) ? sk[base - 1] : 0u;
+#pragma unroll
+  for (int it = 0; it < SMALL_ITEMS; ++it) {
+    const int i = base + it;
+    k[it] = i < n ? sk[i] : 0u;
+    v[it] = i < n ? sv[i] : 0u;
+    const uint32_t before = it == 0 ? prev : k[it - 1];
+    head[it] = i < n && (i == 0 || k[it] != before);
+    c += head[it] ? 1u : 0u;
+  }
+  uint32_t total;
+  uint32_t slot = small_block_scan(c, lds16, &total);
+#pragma unroll
+  for (int it = 0; it < SMALL_ITEMS; ++it) {
+    const int i = base + it;
+    if (head[it]) {
+      uniq_rows[slot] = (int64_t)k[it];
+      seg_off[slot] = i;
+      ++slot;
+    }
+    if (i < n) {
+      sorted_pos[i] = (int32_t)v[it];
+      if (sorted_slot) sorted_slot[i] = (int32_t)(slot - 1);
+      if (inverse) inverse[v[it]] = (int32_t)(slot - 1);
+    }
+  }
+  if (threadIdx.x == 0) {
+    n_uniq[0] = (int32_t)total;
+    seg_off[total] = n;
+  }
+}
+
+static int sort_dedup_small(const RawSrc& raw, int raw_mode, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
+                            int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
+                            int32_t* d_inverse, int32_t* err_flag, hipStream_t st) {
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)n_rows) ++bits;
+  const int passes = (bits + SMALL_BITS - 1) / SMALL_BITS;
+  const int per = (bits + passes - 1) / passes;
+  const size_t lds = (2 * (size_t)SMALL_MAX + SMALL_WAVES * SMALL_BINS + SMALL_BINS) * sizeof(uint32_t);
+  // LDS beyond 64 KiB per block has to be asked for, per kernel and device
+  static bool attr_set[2][64] = {};
+  int device = 0;
+  RX_HIP(hipGetDevice(&device));
+  const bool known = device >= 0 && device < 64;
+  if (raw_mode == 2) {
+    if (!known || !attr_set[1][device]) {
+      RX_HIP(hipFuncSetAttribute((const void*)sort_dedup_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (known) attr_set[1][device] = true;
+    }
+    hipLaunchKernelGGL(sort_dedup_small_kernel<2>, dim3(1), dim3(SMALL_THREADS), lds, st, raw, (int)n, n_rows, passes, per,
+                       d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, err_flag);
+  } else {
+    if (!known || !attr_set[0][device]) {
+      RX_HIP(hipFuncSetAttribute((const void*)sort_dedup_small_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (known) attr_set[0][device] = true;
+    }
+    hipLaunchKernelGGL(sort_dedup_small_kernel<1>, dim3(1), dim3(SMALL_THREADS), lds, st, raw, (int)n, n_rows, passes, per,
+                       d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, err_flag);
+  }
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 // Digit width: the fewest passes with digits of at most SORT_MAX_BITS bits, spread evenly.
 static void sort_plan(int64_t n_rows, int* passes, int* bits_per_pass) {
   int bits = 1;
@@ -551,11 +759,17 @@ static int sort_pass(const SortWs& w, const RawSrc& raw, int raw_mode, int64_t n
   return 0;
 }
 
+// RX_SORT_GENERAL=1 in the environment keeps short lists on the multi-launch path (A/B timing, and the
+// test that compares the two paths)
+static const bool rx_sort_force_general = [] { const char* e = getenv("RX_SORT_GENERAL"); return e && e[0] == '1'; }();
+
 // rows given by `raw` (mode 1 or 2) -> sorted positions, distinct rows, run offsets
 static int sort_dedup_run(const RawSrc& raw, int raw_mode, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
                           int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                           int32_t* d_inverse, void* ws, int32_t* err_flag, hipStream_t st) {
   RX_REQUIRE(((uintptr_t)ws & 15) == 0, "sort workspace must be 16-byte aligned");
+  if (n <= SMALL_MAX && !rx_sort_force_general)
+    return sort_dedup_small(raw, raw_mode, n, n_rows, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, err_flag, st);
   SortWs w = sort_ws_layout(ws, n);
   int passes, bits;
   sort_plan(n_rows, &passes, &bits);

@@ -199,15 +199,15 @@ __device__ __forceinline__ float finish_run(const SegArgs& a, Acc<VEC, CH>& g, f
 #define SEG_CHUNK 32
 #endif
 
-__device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* sq_lds) {
+__device__ __forceinline__ void block_sq_store(float sq, float* sq_part, float* sq_lds, unsigned blk) {
   sq = rx_wave_sum(sq);
   if ((threadIdx.x & 63) == 0) sq_lds[threadIdx.x >> 6] = sq;
   __syncthreads();
-  if (threadIdx.x == 0) sq_part[blockIdx.x] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
+  if (threadIdx.x == 0) sq_part[blk] = (sq_lds[0] + sq_lds[1]) + (sq_lds[2] + sq_lds[3]);
 }
 
 template <int VEC, int CH, int MODE, bool FM, bool DEEP>
-__device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a) {
+__device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a, const unsigned blk) {
   // LDS tile of the block's sorted positions, staged by one coalesced sweep.  Each piece owns
   // PS = SEG_CHUNK + 1 consecutive entries: (slot, position) of its positions (slot -1 past the end
   // of the list) and, in the extra entry, the slot of its right neighbour.  The odd stride puts
@@ -224,7 +224,7 @@ __device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a) {
   int2* tile = meta + 2;
   uint32_t* rowid = reinterpret_cast<uint32_t*>(tile + gpb * PS);
   uint32_t* deepoff = rowid + gpb * PS;   // DEEP only: element offset of the occurrence's slice of fm_deep
-  const int64_t piece0 = (int64_t)blockIdx.x * gpb;
+  const int64_t piece0 = (int64_t)blk * gpb;
   {
     // Eight entries per thread and round: all index loads of a round are issued before the
     // dependent row-id gathers, and those before the LDS stores, so a round costs two memory
@@ -445,25 +445,48 @@ __device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a) {
     }
     if (lg == 0) a.tail_row[piece] = tail;
   }
-  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
+  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds, blk);
 }
 
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_kernel(SegArgs a) {
-  segreduce_chunk_body<VEC, CH, MODE, FM, false>(a);
+  segreduce_chunk_body<VEC, CH, MODE, FM, false>(a, blockIdx.x);
+}
+
+// Several tables in one launch (the user / item tables of the MF and NCF families: a few thousand
+// occurrences each, where a launch per table costs more than the work).  Each table keeps its own
+// blocks, pieces, workspace and partials, so results are those of one launch per table, bit for bit.
+#define SEG_MULTI_MAX 8
+struct SegMulti {
+  SegArgs t[SEG_MULTI_MAX];
+  int64_t pieces[SEG_MULTI_MAX];
+  unsigned first[SEG_MULTI_MAX + 1];  // first block of each table; first[count] = grid size
+  int count;
+};
+
+__device__ __forceinline__ int seg_multi_table(const SegMulti& m) {
+  int t = 0;
+  while (t + 1 < m.count && blockIdx.x >= m.first[t + 1]) ++t;
+  return t;
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_chunk_multi_kernel(SegMulti m) {
+  const int t = seg_multi_table(m);
+  segreduce_chunk_body<VEC, CH, MODE, false, false>(m.t[t], blockIdx.x - m.first[t]);
 }
 
 // FM synthesis plus the tower-input gradient slice of every occurrence (FM is implied)
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_deep_kernel(SegArgs a) {
-  segreduce_chunk_body<VEC, CH, MODE, true, true>(a);
+  segreduce_chunk_body<VEC, CH, MODE, true, true>(a, blockIdx.x);
 }
 
 template <int VEC, int CH, int MODE, bool FM>
-__global__ void __launch_bounds__(RX_BLOCK)
-segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
+__device__ __forceinline__ void segreduce_combine_body(const SegArgs& a, const int64_t n_pieces, const unsigned blk) {
   // A wavefront looks after 64/group consecutive pieces.  Each lane group first fetches what its
   // own piece's tail run needs (length, row, the row's current value), all groups at once; the
   // wavefront then takes the tails one by one, all lane slots adding that run's partials.
@@ -472,7 +495,7 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
   const int lane = threadIdx.x & 63;
   const int slots = 64 / group;
   const int s = lane / group, lg = lane % group;
-  const int64_t base = ((int64_t)blockIdx.x * (RX_BLOCK / 64) + (threadIdx.x >> 6)) * slots;
+  const int64_t base = ((int64_t)blk * (RX_BLOCK / 64) + (threadIdx.x >> 6)) * slots;
   const int64_t mine = base + s;
   const bool has2 = a.target2 != nullptr;
   const bool keep2 = FM || has2;
@@ -549,7 +572,20 @@ segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
     if (FM) g2 = __shfl(g2, lane - lg, 64);  // every lane of a group needs the scalar sum
     if (s == owner && row_ok) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, scale, has2);
   }
-  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds);
+  if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds, blk);
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
+  segreduce_combine_body<VEC, CH, MODE, FM>(a, n_pieces, blockIdx.x);
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+segreduce_combine_multi_kernel(SegMulti m) {
+  const int t = seg_multi_table(m);
+  segreduce_combine_body<VEC, CH, MODE, false>(m.t[t], m.pieces[t], blockIdx.x - m.first[t]);
 }
 
 // 16-byte accesses need 16-byte aligned rows; widths that are not a multiple of 4 use
@@ -622,8 +658,8 @@ static int mode_check(int mode, const float* state, const char* who, bool allow_
   return 0;
 }
 
-// Shared driver of rx_segreduce and rx_segreduce_fm.
-static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t ws_bytes, hipStream_t st) {
+// Checks one table's arguments and places its cross-piece workspace at ws (a.n > 0).
+static int seg_place(SegArgs& a, bool fm, const char* who, void* ws, size_t ws_bytes, RxRowShape* shp) {
   const int64_t n = a.n;
   const int dim = a.dim;
   RX_REQUIRE(n >= 0 && dim >= 1 && dim <= RX_MAX_DIM && a.occ_ld >= dim, "%s: bad shape n=%lld dim=%d ld=%lld", who, (long long)n, dim, (long long)a.occ_ld);
@@ -634,15 +670,25 @@ static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t w
   RX_REQUIRE(a.occ && a.sorted_pos && a.sorted_slot && a.uniq_rows && a.seg_off && a.n_uniq && a.target && ws, "%s: null argument", who);
   RX_REQUIRE(a.n_rows >= 1, "%s: n_rows must be positive", who);
   RX_REQUIRE(ws_bytes >= rx_segreduce_workspace_bytes(n, dim) && rx_aligned16(ws), "%s: workspace too small or unaligned", who);
-  RxRowShape sh;
-  if (seg_shape(dim, a.occ_ld, a.occ, a.target, a.mode == RX_SEG_ADAGRAD ? a.state : nullptr, &sh, who)) return 1;
-  RX_REQUIRE(!fm || sh.vec == 1 || !a.fm_table || rx_aligned16(a.fm_table), "%s: table must be 16-byte aligned", who);
+  if (seg_shape(dim, a.occ_ld, a.occ, a.target, a.mode == RX_SEG_ADAGRAD ? a.state : nullptr, shp, who)) return 1;
+  RX_REQUIRE(!fm || shp->vec == 1 || !a.fm_table || rx_aligned16(a.fm_table), "%s: table must be 16-byte aligned", who);
   const size_t pieces = (size_t)seg_pieces(n);
   char* w = (char*)ws;
   a.partials = (float*)w; w += rx_align_up(pieces * 2 * dim * sizeof(float), 256);
   a.partials2 = (float*)w; w += rx_align_up(pieces * 2 * sizeof(float), 256);
   a.tail_row = (int32_t*)w;
-  a.group = sh.group;
+  a.group = shp->group;
+  return 0;
+}
+
+// Shared driver of rx_segreduce and rx_segreduce_fm.
+static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t ws_bytes, hipStream_t st) {
+  RxRowShape sh;
+  if (seg_place(a, fm, who, ws, ws_bytes, &sh)) return 1;
+  const int64_t n = a.n;
+  const int dim = a.dim;
+  if (n == 0) return 0;
+  const size_t pieces = (size_t)seg_pieces(n);
   const unsigned g1 = (unsigned)seg_grid1(n, dim), g2 = (unsigned)seg_grid2(n, dim);
   const size_t tile = (size_t)(RX_BLOCK / sh.group) * (SEG_CHUNK + 1);
   const bool deep = fm && a.fm_deep != nullptr;
@@ -652,6 +698,59 @@ static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t w
   RX_LAUNCH_CHECK();
   if (a.sq_part) a.sq_part = a.sq_part + g1;
   SEG_DISPATCH(a.mode, fm, sh, segreduce_combine_kernel, dim3(g2), 0, st, a, (int64_t)pieces);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+static void seg_from_table(const rx_seg_table& t, int mode, float lr, float eps, const float* d_scale, SegArgs* out) {
+  SegArgs a{};
+  a.occ = t.occ; a.occ_ld = t.occ_ld; a.n = t.n; a.dim = t.dim;
+  a.sorted_pos = t.sorted_pos; a.sorted_slot = t.sorted_slot; a.uniq_rows = t.uniq_rows;
+  a.seg_off = t.seg_off; a.n_uniq = t.n_uniq; a.mode = mode; a.target = t.target; a.state = t.state;
+  a.n_rows = t.n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale; a.sq_part = t.sq_part;
+  a.occ2 = t.occ2; a.target2 = t.target2; a.state2 = t.state2;
+  *out = a;
+}
+
+extern "C" int rx_segreduce_multi(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps,
+                                  const float* d_scale, void* ws, size_t ws_bytes, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(count >= 0 && count <= SEG_MULTI_MAX && (tables || count == 0), "rx_segreduce_multi: 0..%d tables per call", SEG_MULTI_MAX);
+  static_assert(SEG_MULTI_MAX == RX_SEG_MULTI_MAX, "header and kernel disagree on the table limit");
+  SegMulti m1{}, m2{};
+  RxRowShape sh0{};
+  char* w = (char*)ws;
+  size_t left = ws_bytes, lds = 0;
+  unsigned b1 = 0, b2 = 0;
+  int k = 0;
+  for (int i = 0; i < count; ++i) {
+    SegArgs a;
+    seg_from_table(tables[i], mode, lr, eps, d_scale, &a);
+    RxRowShape sh;
+    if (seg_place(a, false, "rx_segreduce_multi", w, left, &sh)) return 1;
+    if (a.n == 0) continue;
+    RX_REQUIRE(k == 0 || (sh.vec == sh0.vec && sh.chunks == sh0.chunks),
+               "rx_segreduce_multi: the tables of one call must share the row shape (widths %d and %d do not)", m1.t[0].dim, a.dim);
+    for (int j = 0; j < k; ++j)
+      RX_REQUIRE(m1.t[j].target != a.target, "rx_segreduce_multi: a target may appear once per call (two writers of one row would race)");
+    sh0 = sh;
+    const size_t need = rx_segreduce_workspace_bytes(a.n, a.dim);
+    w += need; left -= need;
+    const unsigned g1 = (unsigned)seg_grid1(a.n, a.dim), g2 = (unsigned)seg_grid2(a.n, a.dim);
+    const size_t tile = (size_t)(RX_BLOCK / sh.group) * (SEG_CHUNK + 1);
+    const size_t l = (tile + 2) * sizeof(int2) + tile * sizeof(uint32_t);
+    lds = l > lds ? l : lds;
+    m1.t[k] = a; m1.first[k] = b1; b1 += g1;
+    if (a.sq_part) a.sq_part += g1;            // the combine pass writes its partials behind those of pass 1
+    m2.t[k] = a; m2.first[k] = b2; m2.pieces[k] = seg_pieces(a.n); b2 += g2;
+    ++k;
+  }
+  if (k == 0) return 0;
+  m1.first[k] = b1; m2.first[k] = b2; m1.count = m2.count = k;
+  hipStream_t st = (hipStream_t)stream;
+  SEG_DISPATCH_F(mode, false, sh0, segreduce_chunk_multi_kernel, dim3(b1), lds, st, m1);
+  RX_LAUNCH_CHECK();
+  SEG_DISPATCH_F(mode, false, sh0, segreduce_combine_multi_kernel, dim3(b2), 0, st, m2);
   RX_LAUNCH_CHECK();
   return 0;
 }
@@ -703,11 +802,10 @@ extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g,
 }
 
 // ---------------------------------------------------------------- update from a compact gradient
-template <int VEC, int CH, int MODE, bool FM>
-__global__ void __launch_bounds__(RX_BLOCK)
-row_update_kernel(SegArgs a) {
+template <int VEC, int CH, int MODE>
+__device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned blk) {
   const int group = a.group, dim = a.dim;
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gid = (int64_t)blk * blockDim.x + threadIdx.x;
   const int64_t u = gid / group;
   const int lg = (int)(gid % group);
   if (u >= a.n_uniq[0]) return;
@@ -726,6 +824,19 @@ row_update_kernel(SegArgs a) {
   apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, scale);
   // companion scalar table addressed by the same rows
   if (a.target2 && lg == 0) apply_scalar<MODE>(a, a.occ2[u], row, u, scale);
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+row_update_kernel(SegArgs a) {
+  row_update_body<VEC, CH, MODE>(a, blockIdx.x);
+}
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+row_update_multi_kernel(SegMulti m) {
+  const int t = seg_multi_table(m);
+  row_update_body<VEC, CH, MODE>(m.t[t], blockIdx.x - m.first[t]);
 }
 
 extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
@@ -749,6 +860,42 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   a.group = sh.group;
   const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
   SEG_DISPATCH_F(mode, false, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int rx_row_update_multi(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps,
+                                   const float* d_scale, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(count >= 0 && count <= SEG_MULTI_MAX && (tables || count == 0), "rx_row_update_multi: 0..%d tables per call", SEG_MULTI_MAX);
+  SegMulti m{};
+  RxRowShape sh0{};
+  unsigned blocks = 0;
+  int k = 0;
+  for (int i = 0; i < count; ++i) {
+    const rx_seg_table& t = tables[i];
+    RX_REQUIRE(t.n >= 0 && t.dim >= 1 && t.dim <= RX_MAX_DIM, "rx_row_update_multi: bad shape");
+    if (mode_check(mode, t.state, "rx_row_update_multi", false)) return 1;
+    RX_REQUIRE((t.occ2 == nullptr) == (t.target2 == nullptr), "rx_row_update_multi: companion gradient and table come as a pair");
+    RX_REQUIRE(!t.target2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || t.state2, "rx_row_update_multi: companion Adagrad state missing");
+    if (t.n == 0) continue;
+    RX_REQUIRE(t.occ && t.uniq_rows && t.n_uniq && t.target && t.n_rows >= 1, "rx_row_update_multi: null argument");
+    for (int j = 0; j < k; ++j)
+      RX_REQUIRE(m.t[j].target != t.target, "rx_row_update_multi: a table may appear once per call (two updates of one row would race)");
+    RxRowShape sh;
+    if (seg_shape(t.dim, t.dim, t.occ, t.target, mode == RX_SEG_ADAGRAD ? t.state : nullptr, &sh, "rx_row_update_multi")) return 1;
+    RX_REQUIRE(k == 0 || (sh.vec == sh0.vec && sh.chunks == sh0.chunks), "rx_row_update_multi: the tables of one call must share the row shape");
+    sh0 = sh;
+    SegArgs a;
+    seg_from_table(t, mode, lr, eps, d_scale, &a);
+    a.occ_ld = t.dim; a.group = sh.group; a.sq_part = nullptr;
+    m.t[k] = a; m.first[k] = blocks;
+    blocks += (unsigned)rx_cdiv(t.n * sh.group, RX_BLOCK);
+    ++k;
+  }
+  if (k == 0) return 0;
+  m.first[k] = blocks; m.count = k;
+  SEG_DISPATCH_F(mode, false, sh0, row_update_multi_kernel, dim3(blocks), 0, (hipStream_t)stream, m);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -708,6 +708,62 @@ def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, st
                             _stream(table)), "rx_row_update")
 
 
+@dataclass
+class TableReduce:
+    """One table's share of a multi-table reduce / update (rx_seg_table in recsys_hip.h).  For
+    ``segreduce_multi``: ``occ`` the per-occurrence gradients, ``target`` the table / dense gradient /
+    compact buffer.  For ``row_update_multi``: ``occ`` the compact gradients, ``target`` the table."""
+    occ: Tensor
+    si: SortedIndex
+    target: Tensor
+    dim: int
+    occ_ld: Optional[int] = None
+    state: Optional[Tensor] = None
+    occ2: Optional[Tensor] = None
+    target2: Optional[Tensor] = None
+    state2: Optional[Tensor] = None
+    sq: Optional[Tensor] = None
+
+
+def _seg_tables(items: Sequence[TableReduce], compact: bool):
+    from ._lib import SegTable, RX_SEG_MULTI_MAX
+    if not 1 <= len(items) <= RX_SEG_MULTI_MAX:
+        raise ValueError(f"1..{RX_SEG_MULTI_MAX} tables per launch")
+    arr = (SegTable * len(items))()
+    for k, t in enumerate(items):
+        _req(t.occ, torch.float32, "gradients"); _req(t.target, torch.float32, "target")
+        ld = t.dim if (compact or t.occ_ld is None) else t.occ_ld
+        if t.si.n > 0 and t.occ.numel() < (t.si.n - 1) * ld + t.dim and not compact:
+            raise ValueError("occurrence gradients: too few elements for the index list")
+        if t.occ2 is not None:
+            _req(t.occ2, torch.float32, "companion gradients"); _req(t.target2, torch.float32, "companion target")
+        if t.sq is not None and (t.sq.numel() != segreduce_grid(t.si.n, t.dim) or not t.sq.is_contiguous()):
+            raise ValueError("sq: expected segreduce_grid(n, dim) contiguous floats")
+        arr[k] = SegTable(_p(t.occ), ld, t.si.n, t.dim, _p(t.si.sorted_pos), _p(t.si.sorted_slot), _p(t.si.uniq_rows),
+                          _p(t.si.seg_off), _p(t.si.n_uniq), _p(t.target), _p(t.state), _p(t.occ2), _p(t.target2),
+                          _p(t.state2), t.si.n_rows, _p(t.sq))
+    return arr
+
+
+def segreduce_multi(items: Sequence[TableReduce], mode: int, *, lr: float = 0.0, eps: float = 0.0,
+                    scale: Optional[Tensor] = None) -> None:
+    """rx_segreduce for several tables of one lane layout (equal widths always qualify) in one pair
+    of launches; results equal one ``segreduce`` per table bit for bit."""
+    arr = _seg_tables(items, compact=False)
+    dev = items[0].occ.device
+    ws = _ws(sum(int(lib.rx_segreduce_workspace_bytes(t.si.n, t.dim)) for t in items), dev)
+    check(lib.rx_segreduce_multi(arr, len(items), mode, lr, eps, _p(scale), _p(ws), ws.numel(), _dev(items[0].occ),
+                                 _stream(items[0].occ)), "rx_segreduce_multi")
+
+
+def row_update_multi(items: Sequence[TableReduce], mode: int, *, lr: float = 0.0, eps: float = 0.0,
+                     scale: Optional[Tensor] = None) -> None:
+    """rx_row_update for several tables in one launch (``occ`` / ``occ2``: compact gradients)."""
+    arr = _seg_tables(items, compact=True)
+    check(lib.rx_row_update_multi(arr, len(items), mode, lr, eps, _p(scale), _dev(items[0].target),
+                                  _stream(items[0].target)), "rx_row_update_multi")
+
+
 # ------------------------------------------------------------------ dense optimizers / reductions
 def dense_adam(w, g, m, v, lr, beta1, beta2, eps, step, scale=None):
     """``step``: the step count t >= 1 as an int, or an int32 device tensor holding it (the form a

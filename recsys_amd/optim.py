@@ -16,9 +16,13 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
+import os
+
 import torch
 
 from . import _lib, ops
+
+_ONE_LAUNCH_PER_TABLE = os.environ.get("RX_NO_MULTI_TABLE") == "1"   # A/B timing of the multi-table launches
 
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
 
@@ -50,12 +54,12 @@ class SparseRule:
             ops.segreduce(occ, si, self.mode, table, state=state, lr=self.lr, eps=self.eps, dim=dim, occ_ld=occ_ld,
                           occ2=occ2, target2=table2, state2=state2)
             return
+        # With a clip pending nothing can move before the global norm is known: the reduce itself is
+        # left to step(), which takes the tables of equal width in one launch.
         d = dim if dim is not None else (occ.shape[1] if occ.dim() == 2 else 1)
-        compact = torch.empty(max(si.n, 1), d, dtype=torch.float32, device=table.device)
-        compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if param2 is not None else None
-        sq = ops.segreduce(occ, si, _lib.RX_SEG_COMPACT, compact, dim=dim, occ_ld=occ_ld, want_sq=True,
-                           occ2=occ2, target2=compact2, sq_out=self.owner._sq_slice(si.n, d, table.device))
-        self.owner._pending.append((self, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
+        self.owner._deferred.append((self, param, occ, si, d, occ_ld, rule2, param2, occ2))
+        if _ONE_LAUNCH_PER_TABLE:
+            self.owner._reduce_deferred()
 
 
 def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, premultiplied=False):
@@ -120,6 +124,7 @@ class FusedOptimizer:
             p._rx_sparse = rule
             self.rules.append(rule)
         self._pending = []
+        self._deferred = []                            # reduces queued by the backward while a clip is set
         self._sq_buf: Optional[torch.Tensor] = None   # norm partials of all table reduces of a step, back to back
         self._sq_used = 0
         self._dense_state = {}
@@ -137,7 +142,69 @@ class FusedOptimizer:
         for p in self.dense:
             p.grad = None
         self._pending.clear()
+        self._deferred.clear()
         self._sq_used = 0
+
+    def _reduce_deferred(self):
+        """Compact gradients + norm partials of every queued table: tables of equal width share a
+        launch pair (rx_segreduce_multi; up to 8, a table at most once per launch)."""
+        todo, self._deferred = self._deferred, []
+        while todo:
+            d0, batch, rest, seen = todo[0][4], [], [], set()
+            for e in todo:
+                if e[4] == d0 and id(e[1]) not in seen and len(batch) < _lib.RX_SEG_MULTI_MAX:
+                    batch.append(e)
+                    seen.add(id(e[1]))
+                else:
+                    rest.append(e)
+            todo = rest
+            items, made = [], []
+            for (rule, param, occ, si, d, occ_ld, rule2, param2, occ2) in batch:
+                dev = param.device
+                compact = torch.empty(max(si.n, 1), d, dtype=torch.float32, device=dev)
+                compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=dev) if param2 is not None else None
+                sq = self._sq_slice(si.n, d, dev)
+                if sq is None:
+                    sq = torch.empty(ops.segreduce_grid(si.n, d), dtype=torch.float32, device=dev)
+                items.append(ops.TableReduce(occ, si, compact, d, occ_ld=occ_ld, occ2=occ2, target2=compact2, sq=sq))
+                made.append((rule, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
+            ops.segreduce_multi(items, _lib.RX_SEG_COMPACT)
+            self._pending.extend(made)
+
+    def _update_pending_rows(self, scale):
+        """Row updates left pending by a backward pass that ran with a clip set: applied with the clip
+        factor, or unscaled when the clip was switched off between backward and step.  Tables of one
+        width and rule share a launch."""
+        plain = []
+        for (rule, param, compact, si, _, comp) in self._pending:
+            if isinstance(si, ops.FieldGroups):
+                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+                ops.fg_row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                                  eps=rule.eps, scale=scale, compact2=compact2,
+                                  table2=param2.data if param2 is not None else None,
+                                  state2=rule2._state_for(param2) if rule2 is not None else None)
+            else:
+                plain.append((rule, param, compact, si, comp))
+        while plain:
+            r0, d0 = plain[0][0], plain[0][2].shape[1]
+            key0 = (r0.mode, r0.lr, r0.eps, d0)
+            batch, rest, seen = [], [], set()
+            for e in plain:
+                rule = e[0]
+                if ((rule.mode, rule.lr, rule.eps, e[2].shape[1]) == key0 and id(e[1]) not in seen
+                        and len(batch) < (1 if _ONE_LAUNCH_PER_TABLE else _lib.RX_SEG_MULTI_MAX)):
+                    batch.append(e)
+                    seen.add(id(e[1]))
+                else:
+                    rest.append(e)
+            plain = rest
+            items = []
+            for (rule, param, compact, si, comp) in batch:
+                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+                items.append(ops.TableReduce(compact, si, param.data, d0, state=rule._state_for(param), occ2=compact2,
+                                             target2=param2.data if param2 is not None else None,
+                                             state2=rule2._state_for(param2) if rule2 is not None else None))
+            ops.row_update_multi(items, r0.mode, lr=r0.lr, eps=r0.eps, scale=scale)
 
     def _sq_slice(self, n: int, dim: int, device, need: Optional[int] = None):
         """Room for one reduce's norm partials in the step's shared buffer (None when it is full: the
@@ -207,6 +274,8 @@ class FusedOptimizer:
                 self._step_dev = torch.full((1,), self._step - 1, dtype=torch.int32, device=self.dense[0].device)
             self._step_dev.add_(1)
         scale = None
+        if self._deferred:
+            self._reduce_deferred()
         if self.clip_norm is not None:
             # Global norm.  Dense gradients: one launch leaves fp64 partials for up to 24 tensors;
             # they and the per-block partials of the last table reduce ride in the launch that forms
@@ -235,23 +304,7 @@ class FusedOptimizer:
                 dev = (self.dense[0] if self.dense else self.sparse[0]).device
                 scale, self.last_total_norm = ops.clip_scale(torch.zeros(1, dtype=torch.float64, device=dev),
                                                              float(self.clip_norm))
-        # Row updates left pending by a backward pass that ran with a clip set: applied here with the
-        # clip factor, or unscaled when the clip was switched off between backward and step.
-        for (rule, param, compact, si, _, comp) in self._pending:
-            if isinstance(si, ops.FieldGroups):
-                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
-                ops.fg_row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                                  eps=rule.eps, scale=scale, compact2=compact2,
-                                  table2=param2.data if param2 is not None else None,
-                                  state2=rule2._state_for(param2) if rule2 is not None else None)
-            elif comp is not None:
-                rule2, param2, compact2 = comp
-                ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                               eps=rule.eps, scale=scale, compact2=compact2, table2=param2.data,
-                               state2=rule2._state_for(param2))
-            else:
-                ops.row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                               eps=rule.eps, scale=scale)
+        self._update_pending_rows(scale)
         self._pending.clear()
         self._sq_used = 0
         self._dense_step_all(scale)

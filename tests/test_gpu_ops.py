@@ -116,7 +116,11 @@ def test_empty_batch(ops):
 # ------------------------------------------------------------------ sort / dedup
 @pytest.mark.parametrize("n,n_rows", [(1, 1), (5, 3), (64, 7), (1000, 50), (4096, 4096), (4097, 100000),
                                       (70001, 6040), (300000, 33_000_000), (200000, 2**32),
-                                      (2047, 9), (2048, 2000), (2049, 5), (2_100_003, 33_000_000)])
+                                      (2047, 9), (2048, 2000), (2049, 5), (2_100_003, 33_000_000),
+                                      # around the limit of the one-launch path (8192 positions), with one,
+                                      # two, three and four 8-bit passes
+                                      (63, 200), (65, 256), (511, 257), (513, 70000), (5120, 3706), (8191, 6040),
+                                      (8192, 2**24), (8192, 2**32), (8193, 6040), (7000, 2**32)])
 def test_sort_dedup_bit_exact(ops, n, n_rows):
     g = _gen(n)
     if n_rows > 2**31:
@@ -578,6 +582,82 @@ def test_segreduce_companion_and_long_runs(ops, skew, mode):
         assert_close(st.cpu().numpy(), (G ** 2).numpy(), what="adagrad state")
         assert_close(w.cpu().numpy(), (w0.double() - lr * G / (G.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad rows")
         assert_close(b.cpu().numpy()[:, 0], (b0[:, 0].double() - lr * G2 / (G2.abs() + 1e-10)).numpy(), rtol=1e-4, what="adagrad companion")
+
+
+@pytest.mark.parametrize("mode", ["compact", "sgd", "adagrad"])
+def test_multi_table_reduce_and_update_equal_one_launch_per_table_bitwise(ops, mode):
+    """rx_segreduce_multi / rx_row_update_multi over tables of different heights, list lengths, lane
+    groups (widths 64 and 32 share a layout class, 16-byte lanes with one step) and a companion on
+    one of them: every output must equal the per-table launches bit for bit, partials included."""
+    from recsys_amd import _lib
+    g = _gen(77)
+    shapes = [(5000, 700, 64, True), (1234, 90, 64, False), (40000, 3000, 32, False), (33, 5, 64, False)]
+    lr, eps = 0.05, 1e-10
+    tabs = []
+    for (n, rows, dim, comp) in shapes:
+        idx = torch.where(torch.rand(n, generator=g) < 0.3, torch.randint(0, 3, (n,), generator=g),
+                          torch.randint(0, rows, (n,), generator=g)).cuda()
+        tabs.append(dict(si=ops.sort_dedup(idx, rows), occ=torch.randn(n, dim, generator=g).cuda(),
+                         occ2=torch.randn(n, generator=g).cuda() if comp else None,
+                         w=torch.randn(rows, dim, generator=g).cuda(), b=torch.randn(rows, 1, generator=g).cuda() if comp else None,
+                         n=n, rows=rows, dim=dim))
+    scale = torch.tensor([0.37], device="cuda")
+    M = {"compact": _lib.RX_SEG_COMPACT, "sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD}[mode]
+
+    def fresh(t):
+        return (t["w"].clone(), None if t["b"] is None else t["b"].clone(), torch.zeros_like(t["w"]),
+                None if t["b"] is None else torch.zeros_like(t["b"]))
+
+    if mode == "compact":
+        single, items, multi = [], [], []
+        for t in tabs:
+            c, c2 = torch.zeros(t["n"], t["dim"]).cuda(), torch.zeros(t["n"]).cuda() if t["occ2"] is not None else None
+            sq = ops.segreduce(t["occ"], t["si"], M, c, occ2=t["occ2"], target2=c2, want_sq=True)
+            single.append((c, c2, sq))
+            cm, cm2 = torch.zeros_like(c), None if c2 is None else torch.zeros_like(c2)
+            sqm = torch.empty_like(sq)
+            items.append(ops.TableReduce(t["occ"], t["si"], cm, t["dim"], occ2=t["occ2"], target2=cm2, sq=sqm))
+            multi.append((cm, cm2, sqm))
+        ops.segreduce_multi(items, M)
+        for (c, c2, sq), (cm, cm2, sqm), t in zip(single, multi, tabs):
+            nu = int(t["si"].n_uniq.item())
+            assert torch.equal(c[:nu], cm[:nu]) and torch.equal(sq, sqm)
+            assert c2 is None or torch.equal(c2[:nu], cm2[:nu])
+        # the update from those compact gradients, one launch for all tables
+        for rule in (_lib.RX_SEG_SGD, _lib.RX_SEG_ADAGRAD):
+            ones, ups = [], []
+            for (c, c2, _), t in zip(single, tabs):
+                w, b, st, st2 = fresh(t)
+                ops.row_update(c, t["si"], rule, w, state=st, lr=lr, eps=eps, scale=scale, compact2=c2, table2=b, state2=st2)
+                ones.append((w, b, st, st2))
+                wm, bm, stm, st2m = fresh(t)
+                ups.append((ops.TableReduce(c, t["si"], wm, t["dim"], state=stm, occ2=c2, target2=bm, state2=st2m), (wm, bm, stm, st2m)))
+            ops.row_update_multi([u[0] for u in ups], rule, lr=lr, eps=eps, scale=scale)
+            for one, (_, many) in zip(ones, ups):
+                for x, y in zip(one, many):
+                    assert (x is None and y is None) or torch.equal(x, y)
+        return
+    ones, items, many = [], [], []
+    for t in tabs:
+        w, b, st, st2 = fresh(t)
+        ops.segreduce(t["occ"], t["si"], M, w, state=st, lr=lr, eps=eps, scale=scale, occ2=t["occ2"], target2=b, state2=st2)
+        ones.append((w, b, st, st2))
+        wm, bm, stm, st2m = fresh(t)
+        items.append(ops.TableReduce(t["occ"], t["si"], wm, t["dim"], state=stm, occ2=t["occ2"], target2=bm, state2=st2m))
+        many.append((wm, bm, stm, st2m))
+    ops.segreduce_multi(items, M, lr=lr, eps=eps, scale=scale)
+    for one, m in zip(ones, many):
+        for x, y in zip(one, m):
+            assert (x is None and y is None) or torch.equal(x, y)
+    # one table twice in a launch would have two writers per row: refused
+    with pytest.raises(RuntimeError, match="once per call"):
+        ops.segreduce_multi([items[0], items[0]], M, lr=lr, eps=eps)
+    # widths of different lane layouts do not share a launch
+    t = tabs[0]
+    odd = ops.TableReduce(torch.randn(t["n"], 6).cuda(), t["si"], torch.zeros(t["rows"], 6).cuda(), 6,
+                          state=torch.zeros(t["rows"], 6).cuda())
+    with pytest.raises(RuntimeError, match="share the row shape"):
+        ops.segreduce_multi([items[1], odd], M, lr=lr, eps=eps)
 
 
 @pytest.mark.parametrize("mode", ["dense", "sgd", "adagrad", "compact"])
