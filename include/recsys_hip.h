@@ -401,6 +401,16 @@ int rx_fg_reduce(const rx_fg_reduce_args* a, void* ws, size_t ws_bytes, int devi
 int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                      float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                      int64_t n_rows, float lr, float eps, const float* d_scale, int device, void* stream);
+/* The same update with the global-norm clip factor (recsys/utils.py:101: clip_grad_norm_ over all
+ * parameters) formed inside the launch: d_parts[0 .. n_parts) are ALL partial sums of squares of the
+ * step (the sq_part of the one reduce that fed d_compact; nothing else may contribute), every block
+ * adds them in the order rx_clip_scale_parts uses and scales by min(1, max_norm / (norm + 1e-6)).
+ * d_scale_out[0] / d_norm_out[0] (may be NULL) receive the factor and the norm.  Saves the one-block
+ * launch between reduce and update; bit-identical to rx_clip_scale_parts + rx_fg_row_update. */
+int rx_fg_row_update_clip(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
+                          float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                          int64_t n_rows, float lr, float eps, const float* d_parts, int64_t n_parts,
+                          float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream);
 
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above

@@ -107,6 +107,8 @@ PROTOTYPES = {
     "rx_fm2_fwd_bce_workspace_bytes": (sz, [i64, i32]),
     "rx_fm2_fwd_bce": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp, vp, i64, vp, vp, sz, vp, C.c_int, vp]),
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_fg_row_update_clip": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, f32, vp, vp,
+                                        C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_segreduce_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, vp, sz, C.c_int, vp]),
     "rx_row_update_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, C.c_int, vp]),

@@ -598,6 +598,8 @@ struct FgRed {
   float* partials2;    // [windows][2]
   uint32_t* tail_row;  // [windows] row of the run that starts in the window and leaves it, or FG_NO_LEFT
   uint32_t* meta;      // [windows] leading positions held by the run entering from the left (| FG_META_GOES_ON)
+  // rx_fg_row_update_clip: the clip factor is formed by every block from the partial sums of squares
+  const float* clip_parts; int64_t clip_n; float clip_max; float* clip_scale_out; float* clip_norm_out;
 };
 
 // Everything that happens once the sum of a run is known: G = sum_b g_b T_b (+ tower slices),
@@ -905,15 +907,50 @@ fg_combine_kernel(FgRed a, int64_t n_windows) {
 // Second phase of a clipped step: rows move by their compact gradients (stored at the last
 // position of each run) times the clip factor.  A lane group looks at FG_UPD consecutive positions.
 #define FG_UPD 8   // the row loads of the update kernel are written for 8
-template <int GROUP, int MODE>
+// The global-norm clip factor from per-block partial sums of squares, formed by EVERY block of the
+// consuming launch instead of by a one-block launch in front of it (4.6 us on the step's critical
+// path for a few thousand floats that sit in L2).  Same arithmetic and order as
+// clip_scale_parts_kernel: thread t adds parts[t], parts[t + 256], ... in fp64, a fixed tree joins
+// the threads; all blocks therefore hold the same bits.
+__device__ __forceinline__ float fg_clip_scale(const FgRed& a, double* wsum) {
+  double s = 0.0;
+  for (int64_t i0 = 0; i0 < a.clip_n; i0 += 8 * RX_BLOCK) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // loads first (entries past the end read as 0 and leave the sum's bits alone)
+      const int64_t i = i0 + u * RX_BLOCK + threadIdx.x;
+      v[u] = a.clip_parts[i < a.clip_n ? i : 0];
+      if (i >= a.clip_n) v[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  s = rx_wave_sum_f64(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const double total = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  const float tn = (float)sqrt(total);
+  const float coef = a.clip_max / (tn + 1e-6f);
+  const float scale = coef < 1.f ? coef : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.clip_scale_out[0] = scale;
+    if (a.clip_norm_out) a.clip_norm_out[0] = tn;
+  }
+  return scale;
+}
+
+template <int GROUP, int MODE, bool CLIP = false>
 __global__ void __launch_bounds__(RX_BLOCK)
 fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __restrict__ compact2) {
   constexpr int DIM = GROUP * 4;
+  __shared__ double clip_wsum[RX_BLOCK / 64];
+  float scale = 1.f;
+  if constexpr (CLIP) scale = fg_clip_scale(a, clip_wsum);   // before any thread leaves: it holds a block barrier
+  else scale = a.scale ? a.scale[0] : 1.f;
   const int64_t gid = ((int64_t)blockIdx.x * RX_BLOCK + threadIdx.x) / GROUP;
   const int lg = threadIdx.x % GROUP;
   const int64_t p0 = gid * FG_UPD;
   if (p0 >= a.n) return;
-  const float scale = a.scale ? a.scale[0] : 1.f;
   const bool has2 = a.target2 != nullptr;
   uint32_t row[FG_UPD + 1];
   if (p0 + FG_UPD < a.n) {
@@ -1069,14 +1106,41 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
 #define FG_UPDATE_GROUP(GROUPV)                                                                                                        \
   do {                                                                                                                                 \
     const unsigned grid = (unsigned)rx_cdiv(rx_cdiv(n, FG_UPD) * GROUPV, RX_BLOCK);                                                    \
-    if (mode == RX_SEG_SGD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+    if (a.clip_parts) {                                                                                                               \
+      if (mode == RX_SEG_SGD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+      else if (mode == RX_SEG_ADAGRAD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ADAGRAD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+      else hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ROWWISE_ADAGRAD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+    } else if (mode == RX_SEG_SGD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
     else if (mode == RX_SEG_ADAGRAD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ADAGRAD>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
     else hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ROWWISE_ADAGRAD>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
   } while (0)
 
+static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
+                             float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                             int64_t n_rows, float lr, float eps, const float* d_scale, const float* d_parts,
+                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream);
+
 extern "C" int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                                 float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                                 int64_t n_rows, float lr, float eps, const float* d_scale, int device, void* stream) {
+  return fg_row_update_run(d_compact, dim, d_srow, n, mode, d_w, d_state, d_compact2, d_w2, d_state2, n_rows, lr, eps, d_scale,
+                           nullptr, 0, 0.f, nullptr, nullptr, device, stream);
+}
+
+extern "C" int rx_fg_row_update_clip(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
+                                     float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                                     int64_t n_rows, float lr, float eps, const float* d_parts, int64_t n_parts,
+                                     float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream) {
+  RX_REQUIRE(d_parts && n_parts >= 1 && d_scale_out && max_norm > 0.f, "rx_fg_row_update_clip: partial sums, their count, a positive norm bound and the scale output are required");
+  RX_REQUIRE(n >= 1, "rx_fg_row_update_clip: an empty list leaves the clip factor unwritten; use rx_clip_scale_parts");
+  return fg_row_update_run(d_compact, dim, d_srow, n, mode, d_w, d_state, d_compact2, d_w2, d_state2, n_rows, lr, eps, nullptr,
+                           d_parts, n_parts, max_norm, d_scale_out, d_norm_out, device, stream);
+}
+
+static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
+                             float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
+                             int64_t n_rows, float lr, float eps, const float* d_scale, const float* d_parts,
+                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && fg_group_of(dim), "rx_fg_row_update: bad shape (dim 16, 32, 64 or 128)");
   RX_REQUIRE(mode >= RX_SEG_SGD && mode <= RX_SEG_ROWWISE_ADAGRAD, "rx_fg_row_update: unknown mode %d", mode);
@@ -1088,6 +1152,7 @@ extern "C" int rx_fg_row_update(const float* d_compact, int32_t dim, const uint3
   FgRed a{};
   a.srow = d_srow; a.n = n; a.dim = dim; a.target = d_w; a.state = d_state; a.target2 = d_w2; a.state2 = d_state2;
   a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
+  a.clip_parts = d_parts; a.clip_n = n_parts; a.clip_max = max_norm; a.clip_scale_out = d_scale_out; a.clip_norm_out = d_norm_out;
   hipStream_t st = (hipStream_t)stream;
   switch (fg_group_of(dim)) {
     case 4: FG_UPDATE_GROUP(4); break;

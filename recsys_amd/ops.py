@@ -693,7 +693,20 @@ def fm2_fwd_bce(feat, bias, ex_idx, ex_base, item_idx, item_base: int, labels: T
 
 
 def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
-                  scale=None, compact2=None, table2=None, state2=None) -> None:
+                  scale=None, compact2=None, table2=None, state2=None, clip_parts=None, max_norm=None):
+    """``clip_parts`` / ``max_norm``: instead of a ready ``scale``, ALL of the step's partial sums of
+    squares; the launch forms the clip factor itself (rx_fg_row_update_clip) and (scale, norm) are
+    returned as one-element tensors."""
+    if clip_parts is not None:
+        _req(clip_parts, torch.float32, "clip_parts")
+        if scale is not None or not clip_parts.is_contiguous():
+            raise ValueError("fg_row_update: give either a scale or contiguous partial sums")
+        out = torch.empty(2, dtype=torch.float32, device=table.device)
+        check(lib.rx_fg_row_update_clip(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
+                                        _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(clip_parts),
+                                        clip_parts.numel(), float(max_norm), _p(out[0:1]), _p(out[1:2]), _dev(table),
+                                        _stream(table)), "rx_fg_row_update_clip")
+        return out[0:1], out[1:2]
     check(lib.rx_fg_row_update(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
                                _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(scale), _dev(table),
                                _stream(table)), "rx_fg_row_update")

@@ -22,6 +22,7 @@ import torch
 
 from . import _lib, ops
 
+_SEPARATE_CLIP_LAUNCH = os.environ.get("RX_SEPARATE_CLIP") == "1"   # A/B timing of the clip factor formed inside the row update
 _ONE_LAUNCH_PER_TABLE = os.environ.get("RX_NO_MULTI_TABLE") == "1"   # A/B timing of the multi-table launches
 
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
@@ -297,7 +298,20 @@ class FusedOptimizer:
                     ops.sumsq_accumulate(g, acc)
                 for sq in parts[:-1]:
                     ops.sum_accumulate(sq, acc)
-            if parts or parts64 is not None:
+            e0 = self._pending[0] if len(self._pending) == 1 else None
+            if (e0 is not None and isinstance(e0[3], ops.FieldGroups) and e0[3].n > 0 and acc is None and parts64 is None
+                    and len(parts) == 1 and parts[0].is_contiguous() and not _SEPARATE_CLIP_LAUNCH):
+                # one field-grouped table and nothing else (the FM): every block of the row update adds the
+                # partial sums itself, which takes the one-block clip launch off the step's critical path
+                rule, param, compact, si, _, comp = e0
+                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+                scale, self.last_total_norm = ops.fg_row_update(
+                    compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr, eps=rule.eps,
+                    compact2=compact2, table2=param2.data if param2 is not None else None,
+                    state2=rule2._state_for(param2) if rule2 is not None else None,
+                    clip_parts=parts[0], max_norm=float(self.clip_norm))
+                self._pending.clear()
+            elif parts or parts64 is not None:
                 scale, self.last_total_norm = ops.clip_scale_parts(parts[-1] if parts else None, acc,
                                                                    float(self.clip_norm), parts64)
             else:

@@ -252,3 +252,33 @@ def test_reduce_agrees_with_the_sorted_path_on_hot_rows():
     ops.segreduce_fm(T, g, F, si, _lib.RX_SEG_DENSE, old, table=table, target2=old2)
     assert_close(grad, old, rtol=1e-5, what="grad vs sorted path")
     assert_close(grad2, old2, rtol=1e-5, what="bias grad vs sorted path")
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "rowwise_adagrad"])
+def test_clip_factor_formed_inside_the_row_update_equals_the_separate_launch_bitwise(kind, monkeypatch):
+    """One field-grouped table and nothing else (the FM): FusedOptimizer.step lets every block of the
+    row update add the partial sums of squares itself (rx_fg_row_update_clip).  Weights, optimizer
+    state, clip factor and norm must equal the path with the one-block clip launch bit for bit."""
+    from recsys_amd import optim, synthetic
+    from recsys_amd.models import fields
+    dims = [7, 1000, 13, 5000, 3, 211, 40000]
+    batches = [synthetic.criteo_batch(dims, 3000, seed=s, device="cuda") for s in (1, 2, 3)]
+    out = []
+    for separate in (True, False):
+        monkeypatch.setattr(optim, "_SEPARATE_CLIP_LAUNCH", separate)
+        torch.manual_seed(0)
+        m = fields.FieldFM(dims, 16).cuda()
+        opt = optim.FusedOptimizer(m, kind=kind, lr=0.1, clip_norm=0.02)
+        norms = []
+        for b in batches:
+            opt.zero_grad()
+            m.loss(b).backward()
+            opt.step()
+            norms.append(opt.last_total_norm.clone())
+        state = [r.state.clone() for r in opt.rules if r.state is not None]
+        out.append(([p.detach().clone() for p in m.parameters()], state, norms))
+    (wa, sa, na), (wb, sb_, nb) = out
+    assert all(torch.equal(x, y) for x, y in zip(wa, wb))
+    assert len(sa) == len(sb_) and all(torch.equal(x, y) for x, y in zip(sa, sb_))
+    assert all(torch.equal(x, y) for x, y in zip(na, nb))
+    assert float(na[0]) > 0.02          # the clip was active
