@@ -525,7 +525,17 @@ slab_reduce_kernel(const float* __restrict__ slabs, int64_t n, int n_slabs, floa
   const int64_t i = blk * 64 + e;
   float s = 0.f;
   if (i < n) {
+    // a thread adds slabs q, q + 4, q + 8, ... in that order; eight loads are in flight ahead of the
+    // additions (a tower layer of a few thousand weights has hundreds of slabs, and with four in
+    // flight the launch was a chain of dependent round trips)
     int z = q;
+    for (; z + 28 < n_slabs; z += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(int64_t)(z + 4 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
     for (; z + 12 < n_slabs; z += 16) {
       const float a = slabs[(int64_t)z * n + i], b = slabs[(int64_t)(z + 4) * n + i];
       const float c = slabs[(int64_t)(z + 8) * n + i], d = slabs[(int64_t)(z + 12) * n + i];
