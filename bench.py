@@ -387,8 +387,9 @@ def run_train_loop(name, device, clip):
     n = data.implicit_matrix.nnz
     return {"workload": name, "samples_per_s": n / el, "ms_per_step": 1e3 * el / len(dl), "steps": len(dl), "dtype": "f32",
             "epoch_mean_loss": float(running.item()) / len(dl),
-            "what": "one epoch of train_epoch over ImplicitData's device loader (sampling, shuffle, slicing, copy into the graph's "
-                    "static batch, replay), timed end to end"}
+            "what": "one epoch of train_epoch over ImplicitData's device loader, timed end to end: negative sampling and shuffle on "
+                    "the device, then one graph launch per step (the recorded step ends with rx_epoch_advance: running loss, "
+                    "copy of the next batch's slices into the static batch, cursor); the short last batch runs eagerly"}
 
 
 def kernel_source_sha():

@@ -665,6 +665,28 @@ int rx_sample_negatives(const int64_t* d_users, const int64_t* d_items, const in
                         int64_t* d_out_items, double* d_out_labels, int32_t* err_flag, int device,
                         void* stream);
 
+/* The loop of recsys/utils.py:93-106 (`for inputs in train_dl:` ... `train_loss += loss.item()`) for a
+ * step that is replayed as a HIP graph: recorded at the end of the step, one launch
+ *   - adds the step's loss (d_loss: one double, or one float when loss_f64 == 0; may be NULL together
+ *     with d_running) to d_running[0],
+ *   - copies batch *d_cursor + 1 of every epoch tensor (rows [(c + 1) * rows_per_batch, (c + 2) *
+ *     rows_per_batch) of src[t], row_bytes[t] bytes per row, a multiple of 8) into dst[t], the
+ *     static batch the recorded step reads, unless that batch index is n_batches or beyond,
+ *   - and advances *d_cursor.
+ * d_ticket: one zero-initialised uint32 owned by this call sequence (the launch leaves it at zero).
+ * Launches that share a cursor must not overlap. */
+#define RX_BATCH_MAX_TENSORS 8
+typedef struct rx_batch_plan {
+  const void* src[RX_BATCH_MAX_TENSORS];
+  void* dst[RX_BATCH_MAX_TENSORS];
+  int64_t row_bytes[RX_BATCH_MAX_TENSORS];
+  int32_t count;
+  int64_t rows_per_batch;
+  int64_t n_batches;
+} rx_batch_plan;
+int rx_epoch_advance(const rx_batch_plan* plan, int64_t* d_cursor, uint32_t* d_ticket, const void* d_loss,
+                     int loss_f64, double* d_running, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

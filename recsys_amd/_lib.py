@@ -62,6 +62,12 @@ class TensorList(C.Structure):
 
 
 RX_SEG_MULTI_MAX = 8
+RX_BATCH_MAX_TENSORS = 8
+
+
+class BatchPlan(C.Structure):
+    _fields_ = [("src", vp * RX_BATCH_MAX_TENSORS), ("dst", vp * RX_BATCH_MAX_TENSORS),
+                ("row_bytes", i64 * RX_BATCH_MAX_TENSORS), ("count", i32), ("rows_per_batch", i64), ("n_batches", i64)]
 
 
 class SegTable(C.Structure):
@@ -110,6 +116,7 @@ PROTOTYPES = {
     "rx_fg_row_update_clip": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, f32, vp, vp,
                                         C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_epoch_advance": (C.c_int, [C.POINTER(BatchPlan), vp, vp, vp, C.c_int, vp, C.c_int, vp]),
     "rx_segreduce_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, vp, sz, C.c_int, vp]),
     "rx_row_update_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, C.c_int, vp]),
     "rx_dense_adam": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, C.c_int, vp]),

@@ -58,3 +58,58 @@ extern "C" int rx_sample_negatives(const int64_t* d_users, const int64_t* d_item
   RX_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- next batch of a resident epoch
+// The train step of a MovieLens-sized batch takes tens of microseconds on the GPU; slicing the
+// epoch tensors and copying the slices into the recorded step's static batch from the host costs
+// more than that per step.  This kernel is recorded at the END of the step's graph: it adds the
+// step's loss to the epoch's running sum and copies batch cursor + 1 of every epoch tensor into the
+// static batch, so the host's share of a step is one graph launch.
+// All blocks read the cursor on entry; the block that arrives last at the ticket (an integer
+// atomic: no block can still be about to read) advances it and takes the loss.
+__global__ void __launch_bounds__(RX_BLOCK)
+epoch_advance_kernel(rx_batch_plan p, int64_t* __restrict__ cursor, uint32_t* __restrict__ ticket,
+                     const void* __restrict__ loss, int loss_f64, double* __restrict__ running) {
+  const int64_t next = cursor[0] + 1;
+  if (next >= 0 && next < p.n_batches) {
+    for (int t = 0; t < p.count; ++t) {
+      const int64_t words = p.rows_per_batch * (p.row_bytes[t] / 8);
+      const uint64_t* src = reinterpret_cast<const uint64_t*>(p.src[t]) + next * words;
+      uint64_t* dst = reinterpret_cast<uint64_t*>(p.dst[t]);
+      for (int64_t i = (int64_t)blockIdx.x * RX_BLOCK + threadIdx.x; i < words; i += (int64_t)gridDim.x * RX_BLOCK) dst[i] = src[i];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const uint32_t arrived = atomicAdd(ticket, 1u);
+    if (arrived == gridDim.x - 1) {
+      ticket[0] = 0;
+      cursor[0] = next;
+      if (loss && running) running[0] += loss_f64 ? reinterpret_cast<const double*>(loss)[0] : (double)reinterpret_cast<const float*>(loss)[0];
+    }
+  }
+}
+
+extern "C" int rx_epoch_advance(const rx_batch_plan* plan, int64_t* d_cursor, uint32_t* d_ticket, const void* d_loss,
+                                int loss_f64, double* d_running, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(plan && d_cursor && d_ticket, "rx_epoch_advance: null argument");
+  RX_REQUIRE(plan->count >= 1 && plan->count <= RX_BATCH_MAX_TENSORS && plan->rows_per_batch >= 1 && plan->n_batches >= 0,
+             "rx_epoch_advance: 1..%d tensors, a positive batch size and a non-negative batch count", RX_BATCH_MAX_TENSORS);
+  RX_REQUIRE((d_loss == nullptr) == (d_running == nullptr), "rx_epoch_advance: loss and running sum come as a pair");
+  int64_t most = 0;
+  for (int t = 0; t < plan->count; ++t) {
+    RX_REQUIRE(plan->src[t] && plan->dst[t] && plan->row_bytes[t] >= 8 && plan->row_bytes[t] % 8 == 0 &&
+               ((uintptr_t)plan->src[t] & 7) == 0 && ((uintptr_t)plan->dst[t] & 7) == 0,
+               "rx_epoch_advance: tensor %d needs 8-byte aligned buffers and rows of whole 8-byte words", t);
+    const int64_t w = plan->rows_per_batch * (plan->row_bytes[t] / 8);
+    most = w > most ? w : most;
+  }
+  int64_t g = rx_cdiv(most, RX_BLOCK * 4);
+  const unsigned grid = (unsigned)(g < 1 ? 1 : (g > 128 ? 128 : g));
+  hipLaunchKernelGGL(epoch_advance_kernel, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, *plan, d_cursor, d_ticket,
+                     d_loss, loss_f64, d_running);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

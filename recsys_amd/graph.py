@@ -145,10 +145,11 @@ class GraphedTrainStep:
         entry[0].replay()
         return entry[2]
 
-    def add_batch(self, batch: Dict[str, torch.Tensor]) -> int:
+    def add_batch(self, batch: Dict[str, torch.Tensor], epilogue=None) -> int:
         """Record one graph bound to ``batch``'s tensors.  Before the first recording the step is
         run eagerly ``warmup`` times on a side stream (these are real train steps on ``batch``);
-        recording itself executes nothing."""
+        recording itself executes nothing.  ``epilogue(loss)``: further launches recorded behind the
+        step (utils.LoopGraph records the hand-over to the next batch there)."""
         if ops._INDEX_CHECK != "deferred":
             raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
         dev = next(self.model.parameters()).device
@@ -165,6 +166,8 @@ class GraphedTrainStep:
         clear_sort_cache()   # the recording must hold its own sort kernels (see autograd.sorted_index)
         with torch.cuda.graph(g, pool=self._pool):
             loss = self._eager(batch)
+            if epilogue is not None:
+                epilogue(loss)
         clear_sort_cache()   # memo entries made while recording point into the graph's pool
         if self._pool is None:
             self._pool = g.pool()

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -1126,6 +1126,40 @@ def sample_negatives(users: Tensor, items: Tensor, pool: Tensor, n_neg: int, see
                                   _stream(users)), "rx_sample_negatives")
     _after_index_op(dev)
     return out, labels
+
+
+def epoch_advance(epoch: Dict[str, Tensor], batch: Dict[str, Tensor], n_batches: int, cursor: Tensor, ticket: Tensor,
+                  loss: Optional[Tensor] = None, running: Optional[Tensor] = None) -> None:
+    """rx_epoch_advance: ``running += loss``, then batch ``cursor + 1`` of every tensor of ``epoch``
+    (slices of ``batch[k].shape[0]`` rows along dim 0) goes into ``batch[k]``, and the cursor moves on.
+    Meant to be recorded at the end of a graphed train step (utils.LoopGraph)."""
+    from ._lib import BatchPlan, RX_BATCH_MAX_TENSORS
+    keys = list(batch)
+    if not 1 <= len(keys) <= RX_BATCH_MAX_TENSORS:
+        raise ValueError(f"1..{RX_BATCH_MAX_TENSORS} tensors per batch")
+    _req(cursor, torch.int64, "cursor"); _req(ticket, torch.int32, "ticket")
+    plan = BatchPlan()
+    plan.count = len(keys)
+    rows = batch[keys[0]].shape[0]
+    plan.rows_per_batch, plan.n_batches = rows, int(n_batches)
+    for t, k in enumerate(keys):
+        src, dst = epoch[k], batch[k]
+        if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype
+                and src.shape[1:] == dst.shape[1:] and dst.shape[0] == rows and src.shape[0] >= n_batches * rows):
+            raise ValueError(f"epoch_advance: tensor {k!r} does not match its epoch tensor")
+        plan.src[t], plan.dst[t] = src.data_ptr(), dst.data_ptr()
+        plan.row_bytes[t] = dst[0].numel() * dst.element_size() if dst.dim() > 1 else dst.element_size()
+    if (loss is None) != (running is None):
+        raise ValueError("epoch_advance: loss and running come as a pair")
+    if loss is not None:
+        _req(running, torch.float64, "running")
+        if loss.dtype not in (torch.float64, torch.float32) or loss.numel() != 1:
+            raise ValueError("epoch_advance: the loss is one float or double")
+    dev = cursor.device
+    check(lib.rx_epoch_advance(C.byref(plan), _p(cursor), _p(ticket), _p(loss),
+                               int(loss is not None and loss.dtype == torch.float64), _p(running),
+                               dev.index if dev.index is not None else torch.cuda.current_device(),
+                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "rx_epoch_advance")
 
 
 def sample_negatives_host(users, items, pool, n_neg: int, seed: int):

@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from .autograd import backward_from_loss
+from .dataset import EpochLoader
 from .metrics import compute_metrics
 from .optim import FusedOptimizer
 
@@ -79,8 +80,14 @@ class LoopGraph:
     """Replays the train step as one HIP graph inside ``train_epoch``: the first ``eager_steps``
     batches of the first epoch run eagerly (they are ordinary train steps and leave every lazily
     sized buffer at its final size), the step is then recorded once on a static copy of a batch, and
-    every later full-size batch is copied into that copy (``GraphedTrainStep.copy_batch``) and
-    replayed.  A short last batch runs eagerly."""
+    every later full-size batch is replayed.  A short last batch runs eagerly.
+
+    Two ways to feed the recorded step.  Called per batch (any iterable of batches), each batch is
+    copied into the static copy from the host (``GraphedTrainStep.copy_batch``).  Given a whole
+    ``dataset.EpochLoader`` (``run_epoch``; ``train_epoch`` does that), the epoch's shuffled tensors
+    stay on the device and the recorded step itself ends with the hand-over to the next batch
+    (rx_epoch_advance: running loss, copy of the next slices, cursor), so that the host's share of a
+    step is one graph launch.  Both ways train on the same batches in the same order."""
 
     def __init__(self, model, optimizer, eager_steps: int = 2):
         from .graph import GraphedTrainStep
@@ -88,6 +95,52 @@ class LoopGraph:
             raise TypeError("graph replay of the train step needs a FusedOptimizer")
         self.step = GraphedTrainStep(model, optimizer, warmup=0)
         self.eager_left, self.slot, self.rows = eager_steps, None, None
+        # run_epoch: static epoch tensors, its own recording, device-side cursor / running loss
+        self.epoch, self.epoch_slot, self.epoch_shape = None, None, None
+        self.cursor = self.ticket = self.running = None
+
+    def run_epoch(self, model, optimizer, loader, clip_norm):
+        """One pass over ``loader`` (a dataset.EpochLoader on the GPU); returns the sum of the batch
+        losses as a device tensor, added in batch order like ``train_epoch`` does."""
+        tensors, n, B = loader.tensors, loader.length, loader.batch_size
+        dev = next(iter(tensors.values())).device
+        shape = (n, B, tuple((k, tuple(v.shape[1:]), v.dtype) for k, v in tensors.items()))
+        if self.epoch_shape != shape:       # first epoch, or a loader of another shape: new static tensors and recording
+            self.epoch = {k: torch.empty_like(v.contiguous()) for k, v in tensors.items()}
+            self.epoch_shape, self.epoch_slot = shape, None
+            self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.running = torch.zeros(1, dtype=torch.float64, device=dev)
+        if loader.shuffle:
+            perm = torch.randperm(n, device=dev, generator=loader.generator)
+            for k, v in tensors.items():
+                torch.index_select(v, 0, perm, out=self.epoch[k])
+        else:
+            for k, v in tensors.items():
+                self.epoch[k].copy_(v)
+        n_full, i = n // B, 0
+        cut = lambda j: {k: v[j * B:(j + 1) * B] for k, v in self.epoch.items()}
+        running = torch.zeros((), dtype=torch.float64, device=dev)
+        while i < n_full and self.eager_left > 0:
+            running += train_step(model, optimizer, cut(i), clip_norm)
+            self.eager_left -= 1
+            i += 1
+        if i < n_full:
+            if self.epoch_slot is None:
+                optimizer.clip_norm = clip_norm
+                batch = {k: v.clone() for k, v in cut(i).items()}
+                hand_over = lambda loss: ops.epoch_advance(self.epoch, batch, n_full, self.cursor, self.ticket,
+                                                           loss.detach(), self.running)
+                self.epoch_slot = self.step.add_batch(batch, epilogue=hand_over)   # records, executes nothing
+            self.step.copy_batch(self.epoch_slot, cut(i))
+            self.cursor.fill_(i)
+            self.running.copy_(running.reshape(1))
+            for _ in range(n_full - i):
+                self.step(self.epoch_slot)
+            running = self.running[0].clone()
+        if n % B:
+            running += train_step(model, optimizer, {k: v[n_full * B:] for k, v in self.epoch.items()}, clip_norm)
+        return running
 
     def __call__(self, model, optimizer, inputs, clip_norm):
         rows = next(iter(inputs.values())).shape[0]
@@ -106,6 +159,9 @@ def train_epoch(model, optimizer, train_dl, clip_norm, step_fn=None):
     """One pass over ``train_dl`` (recsys/utils.py:93-106 without its two host reads per step);
     returns the sum of the batch losses as a device tensor."""
     step_fn = step_fn or train_step
+    if isinstance(step_fn, LoopGraph) and isinstance(train_dl, EpochLoader) and train_dl.length > 0 \
+            and all(v.is_cuda and v.element_size() == 8 for v in train_dl.tensors.values()):
+        return step_fn.run_epoch(model, optimizer, train_dl, clip_norm)
     running = None
     for inputs in train_dl:
         loss = step_fn(model, optimizer, inputs, clip_norm)

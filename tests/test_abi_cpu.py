@@ -34,11 +34,11 @@ def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "recsys_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rx_gather_seg), sizeof(rx_mf_args), sizeof(rx_fm_args),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rx_gather_seg), sizeof(rx_mf_args), sizeof(rx_fm_args),'
         ' offsetof(rx_gather_seg, dim), offsetof(rx_mf_args, B), offsetof(rx_fm_args, flags),'
         ' sizeof(rx_tensor_list), offsetof(rx_tensor_list, count), offsetof(rx_gather_seg, bag),'
         ' sizeof(rx_fg_args), offsetof(rx_fg_args, field_base), sizeof(rx_fg_reduce_args), offsetof(rx_fg_reduce_args, srow),'
-        ' offsetof(rx_fg_reduce_args, sq_part), sizeof(rx_seg_table), offsetof(rx_seg_table, sorted_pos), offsetof(rx_seg_table, sq_part));return 0;}\n')
+        ' offsetof(rx_fg_reduce_args, sq_part), sizeof(rx_seg_table), offsetof(rx_seg_table, sorted_pos), offsetof(rx_seg_table, sq_part), sizeof(rx_batch_plan), offsetof(rx_batch_plan, count), offsetof(rx_batch_plan, n_batches));return 0;}\n')
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -46,7 +46,8 @@ def test_struct_layouts_match_header(tmp_path):
            _lib.MFArgs.B.offset, _lib.FMArgs.flags.offset, C.sizeof(_lib.TensorList), _lib.TensorList.count.offset,
            _lib.GatherSeg.bag.offset, C.sizeof(_lib.FGArgs), _lib.FGArgs.field_base.offset, C.sizeof(_lib.FGReduceArgs),
            _lib.FGReduceArgs.srow.offset, _lib.FGReduceArgs.sq_part.offset, C.sizeof(_lib.SegTable),
-           _lib.SegTable.sorted_pos.offset, _lib.SegTable.sq_part.offset]
+           _lib.SegTable.sorted_pos.offset, _lib.SegTable.sq_part.offset, C.sizeof(_lib.BatchPlan),
+           _lib.BatchPlan.count.offset, _lib.BatchPlan.n_batches.offset]
     assert got == exp
 
 

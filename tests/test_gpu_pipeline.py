@@ -636,10 +636,14 @@ def test_device_loader_epochs_are_reproducible_from_the_seed():
     assert not torch.equal(e2["item_code"], ea["item_code"])               # next epoch, next stream
 
 
+@pytest.mark.parametrize("feed", ["loader", "batches"])
 @pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF"])
-def test_train_epoch_graph_replay_matches_eager_bitwise(name):
-    """utils.LoopGraph: two epochs with the step replayed as a graph on copied-in batches give the
-    same weights and epoch losses, bit for bit, as the eager loop on the same seeded loader."""
+def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
+    """utils.LoopGraph: two epochs with the step replayed as a graph give the same weights and epoch
+    losses, bit for bit, as the eager loop on the same seeded loader -- both when the recorded step
+    itself hands over to the next batch of the resident epoch (feed "loader": rx_epoch_advance; the
+    epoch ends in a short batch, which runs eagerly) and when every batch is copied in from the host
+    (feed "batches": any iterable of batches)."""
     from recsys_amd import ops
     from recsys_amd.dataset import ImplicitData, synthetic_ml1m_data
     from recsys_amd.models import matrix_factorization as mf
@@ -658,13 +662,18 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name):
         step = LoopGraph(model, opt) if graphed else None
         ops.set_index_check("deferred")
         try:
-            sums = [float(train_epoch(model, opt, data.create_negative_sampled_train_dataloader(), 1.0, step).item())
-                    for _ in range(2)]
+            sums = []
+            for _ in range(2):
+                dl = data.create_negative_sampled_train_dataloader()
+                sums.append(float(train_epoch(model, opt, dl if feed == "loader" else list(dl), 1.0, step).item()))
             ops.raise_if_index_error()
         finally:
             ops.set_index_check("sync")
         if graphed:
-            assert step.slot is not None and len(step.step.graphs) == 1
+            assert (step.epoch_slot if feed == "loader" else step.slot) is not None and len(step.step.graphs) == 1
+            if feed == "loader":
+                assert int(step.cursor.item()) == len(dl) - (1 if dl.length % dl.batch_size else 0)
+                assert int(step.ticket.item()) == 0
         results.append((sums, {k: v.detach().clone() for k, v in model.state_dict().items()}))
     assert results[0][0] == results[1][0]
     for k, v in results[0][1].items():
