@@ -76,15 +76,33 @@ def sorted_index(idx: Tensor, n_rows: int):
     if hit is not None:
         return hit[1]
     cache = _CAPTURE_CACHE if capturing else _SORT_CACHE
-    for k, _, si in cache:
+    for k, _, si, made in cache:
         if k == key:
+            _follow(made, si)
             return si
     si = ops.sort_dedup(flat.contiguous() if not flat.is_contiguous() else flat, n_rows)
     if flat.is_contiguous():
-        cache.append((key, flat, si))
+        made = None
+        if flat.is_cuda:      # a model whose branches run on two streams may ask from the other one
+            made = (torch.cuda.current_stream(flat.device), torch.cuda.Event())
+            made[1].record(made[0])
+        cache.append((key, flat, si, made))
         if len(cache) > (64 if capturing else 8):
             cache.pop(0)
     return si
+
+
+def _follow(made, si) -> None:
+    """A memoised sort is about to be read on the current stream: if another stream produced it, wait
+    for that launch and tell the allocator about the second reader."""
+    if made is None:
+        return
+    cur = torch.cuda.current_stream(si.seg_off.device)
+    if cur != made[0]:
+        cur.wait_event(made[1])
+        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse):
+            if t is not None:
+                t.record_stream(cur)
 
 
 def table_backward(param: Optional[Tensor], si: SortedIndex, occ: Tensor, dim: Optional[int] = None,
@@ -154,6 +172,76 @@ _side_streams = {}
 
 def _side_stream(device) -> "torch.cuda.Stream":
     key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+_BRANCHES_OFF = os.environ.get("RX_NO_BRANCH_STREAMS") == "1"      # A/B timing: every branch on the caller's stream
+_open_branches: list = []
+_branch_warning_off = [False]
+
+
+class Branch:
+    """``with Branch(device) as br:`` runs the launches of an independent branch of a model (NeuMF's
+    GMF half beside its MLP tower) on a second stream, forked from the current stream on entry;
+    ``join`` brings the two together again.  Autograd runs a node's backward on the stream its
+    forward ran on, so the branch's backward overlaps the other branch's as well.  What the branch's
+    backward leaves for later (the per-occurrence gradients a clipped FusedOptimizer.step() reduces)
+    is joined by ``join_branches``."""
+
+    def __init__(self, device):
+        self.on = torch.device(device).type == "cuda" and not _BRANCHES_OFF
+        self.device = device
+
+    def __enter__(self):
+        if self.on:
+            if not _branch_warning_off[0]:
+                # a parameter used inside the branch gets its gradient on the branch's stream; the engine
+                # syncs that correctly and warns about the mismatch with the stream of the accumulation
+                # node, which is the intended state here
+                off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if off is not None:
+                    off(False)
+                _branch_warning_off[0] = True
+            self.main = torch.cuda.current_stream(self.device)
+            self.side = _side_stream_for("branch", self.device)
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+            if self.side not in _open_branches:
+                _open_branches.append(self.side)
+        return False
+
+    def join(self, *tensors: Tensor) -> None:
+        """Call where the caller's stream first needs the branch's results (after it has been given
+        its own work): it waits for the branch there, and ``tensors`` made inside the branch are
+        marked as read by the caller's stream."""
+        if self.on:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                t.record_stream(self.main)
+
+
+def join_branches(device) -> None:
+    """The current stream waits for everything the branch streams have been given (their share of
+    the backward pass included).  FusedOptimizer.step() and backward_from_loss call it."""
+    if not _open_branches:
+        return
+    cur = torch.cuda.current_stream(device)
+    for s in _open_branches:
+        if s.device == cur.device and s != cur:
+            cur.wait_stream(s)
+    _open_branches[:] = [s for s in _open_branches if s.device != cur.device]
+
+
+def _side_stream_for(what: str, device) -> "torch.cuda.Stream":
+    key = (what, torch.device(device).index)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
@@ -732,12 +820,14 @@ def backward_from_loss(loss: Tensor) -> None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward")):
         loss.backward(gradient=one)
-        return
-    _UNIT_LOSS_GRAD = True
-    try:
-        loss.backward(gradient=one)
-    finally:
-        _UNIT_LOSS_GRAD = False
+    else:
+        _UNIT_LOSS_GRAD = True
+        try:
+            loss.backward(gradient=one)
+        finally:
+            _UNIT_LOSS_GRAD = False
+    if loss.is_cuda:
+        join_branches(loss.device)
 
 
 class BCEWithLogits(Function):

@@ -152,10 +152,14 @@ class NeuMF(HotPathModule):
         items = as_index(items, "item_code")
         if pointwise and items.dim() != 1:
             raise ValueError("pointwise=True takes item_code of shape [B]")
-        prod = rxa.GMFMul.apply(users, items, self.user_embedding_gmf.weight, self.item_embedding_gmf.weight)
-        out_gmf = rxa.linear(prod, self.linear_gmf.weight, self.linear_gmf.bias)
+        # the GMF half shares nothing with the MLP tower until the concatenation: it runs on a second
+        # stream, forward and (autograd keeps a node on its forward stream) backward
+        with rxa.Branch(users.device) as br:
+            prod = rxa.GMFMul.apply(users, items, self.user_embedding_gmf.weight, self.item_embedding_gmf.weight)
+            out_gmf = rxa.linear(prod, self.linear_gmf.weight, self.linear_gmf.bias)
         x, B, N = _tower_input(users, items, self.user_embedding_mlp.weight, self.item_embedding_mlp.weight)
         out_mlp = run_tower(self.linear_mlp, x)
+        br.join(out_gmf)
         both = torch.cat([out_mlp, out_gmf] if pointwise else [out_gmf, out_mlp], dim=1)
         out = rxa.linear(both, self.linear_final.weight, self.linear_final.bias)
         return out if pointwise else out.view(B, -1)

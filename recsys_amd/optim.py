@@ -162,6 +162,10 @@ class FusedOptimizer:
             items, made = [], []
             for (rule, param, occ, si, d, occ_ld, rule2, param2, occ2) in batch:
                 dev = param.device
+                if occ.is_cuda:      # possibly made on a branch stream: this stream reads it now
+                    occ.record_stream(torch.cuda.current_stream(dev))
+                    if occ2 is not None:
+                        occ2.record_stream(torch.cuda.current_stream(dev))
                 compact = torch.empty(max(si.n, 1), d, dtype=torch.float32, device=dev)
                 compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=dev) if param2 is not None else None
                 sq = self._sq_slice(si.n, d, dev)
@@ -268,6 +272,14 @@ class FusedOptimizer:
 
     def step(self):
         self._step += 1
+        some = self.sparse[0] if self.sparse else (self.dense[0] if self.dense else None)
+        if some is not None and some.is_cuda:
+            from .autograd import join_branches
+            join_branches(some.device)     # a model's second-stream branch may still be writing gradients
+            cur = torch.cuda.current_stream(some.device)
+            for p in self.dense:           # dense gradients may have been made on a branch stream: read here
+                if p.grad is not None:
+                    p.grad.record_stream(cur)
         if self.dense_kind == "adam" and self.dense:
             # the step count also lives on the device, advanced on the stream: a recorded graph of this
             # step then reads the count of the replay, not the one of the recording

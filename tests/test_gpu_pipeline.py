@@ -695,3 +695,42 @@ def test_sharded_step_replayed_as_a_graph_through_rccl_matches_eager_bitwise(mod
                          capture_output=True, text=True, timeout=150)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "bitwise equal True" in out.stdout and "group destroyed" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_neumf_second_stream_branch_matches_one_stream_bitwise(graphed, monkeypatch):
+    """NeuMF runs its GMF half on a second stream (autograd.Branch), forward and backward; the
+    per-occurrence gradients it leaves for the clipped optimizer step and the dense gradients of
+    linear_gmf are joined before they are read.  Weights after three steps must equal the
+    one-stream run bit for bit, eagerly and replayed as a graph."""
+    from recsys_amd import autograd as rxa, ops, synthetic
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+    batches = [synthetic.ml1m_batch(512, seed=s, device="cuda") for s in (1, 2, 3)]
+    out = []
+    for off in (True, False):
+        monkeypatch.setattr(rxa, "_BRANCHES_OFF", off)
+        torch.manual_seed(0)
+        m = NeuMF(synthetic.ML1M["n_users"], synthetic.ML1M["n_items"], 32, dropout=0.0).cuda().train()
+        opt = FusedOptimizer(m, kind="adagrad", lr=0.05, clip_norm=0.5)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=1)
+                for b in batches:
+                    gs.add_batch(b)
+                for i in range(len(batches)):
+                    gs(i)
+            else:
+                for b in batches:
+                    opt.zero_grad()
+                    rxa.backward_from_loss(m.loss(b))
+                    opt.step()
+            torch.cuda.synchronize()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        out.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    for k, v in out[0].items():
+        assert torch.equal(v, out[1][k]), k
