@@ -111,7 +111,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         return graph_sharded(w, device, world) if use_graph else w
     if name in ("fm_criteo", "fm_wide_d128", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
-        B, D = 65536, 16
+        B, D = 65536, int(os.environ.get("RX_BENCH_DIM", 16))      # RX_BENCH_DIM: width sweeps of the experiments in DESIGN.md
         if name == "fm_wide_d128":
             # one GPU's share of the 1 B-row x 128 configuration, unsharded: 125 M rows of 512 bytes (64 GB)
             dims, D = synthetic.criteo_field_dims(total_rows=125_000_000), 128
@@ -590,7 +590,8 @@ def main():
         del w
 
     fg_on = os.environ.get("RX_NO_FIELD_GROUPS") != "1"   # the unsharded field models take the field-grouped backward
-    dominant = {"fm_criteo": "fg_reduce" if fg_on else "segreduce_fm", "fm_wide_d128": "fg_reduce" if fg_on else "segreduce_fm",
+    fg_on = fg_on and int(os.environ.get("RX_BENCH_DIM", 16)) <= int(os.environ.get("RX_FG_MAX_DIM", 32))   # wide rows take the general path
+    dominant = {"fm_criteo": "fg_reduce" if fg_on else "segreduce_fm", "fm_wide_d128": "segreduce_fm",
                 "fm_criteo_sharded": "segreduce_fm",
                 "deepfm_criteo_sharded": "linear_bwd_w", "deepfm_wide_d128_sharded": "linear_bwd_w", "deepfm_criteo": "linear_bwd_w",
                 "deepfm_criteo_bf16": "linear_bwd_w",

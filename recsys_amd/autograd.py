@@ -247,10 +247,19 @@ def _side_stream_for(what: str, device) -> "torch.cuda.Stream":
     return _side_streams[key]
 
 
+_FG_MAX_DIM = int(os.environ.get("RX_FG_MAX_DIM", 32))
+
+
 def use_field_groups(feat, ex_idx, item_idx, field_base) -> bool:
     """The field-grouped backward (rx_fg_*) serves one-item-per-sample batches over disjoint field
     ranges; ``RX_NO_FIELD_GROUPS=1`` keeps everything on the general sort (for A/B timing)."""
     if field_base is None or os.environ.get("RX_NO_FIELD_GROUPS") == "1":
+        return False
+    # Rows of up to 32 floats only.  Measured on the 33 M-row Criteo-shaped FM at B = 65536 (ms per step,
+    # field groups / general sort): D = 16 0.153 / 0.197, D = 32 0.207 / 0.213, D = 64 0.398 / 0.332,
+    # D = 128 0.943 / 0.570 -- the position-parallel reduce re-reads a D-wide record per occurrence and
+    # loses to the run-walking one once rows are wide.
+    if feat.shape[1] > _FG_MAX_DIM:
         return False
     return ops.fg_supported(ex_idx, item_idx, field_base, feat.shape[1])
 

@@ -22,6 +22,9 @@
 //               with 64-lane matches, no block barrier.  Larger bins (a hot row beyond the first 256)
 //               go to a 1024-thread launch with up to 16384 words per block; anything larger than
 //               that is sorted through global memory.
+// The packed word needs bits(B - 1) + bits((largest field - 1) >> 8) bits: 32-bit words serve tables
+// of up to 16.7 M rows per field at B = 65536; wider fields (the 125 M-row tables) take the same
+// kernels instantiated on 64-bit words (WIDE), with half as many words per LDS-resident big bin.
 // No float or order-dependent atomic is involved: counts are integers, ranks come from prefix sums.
 //
 // rx_fg_reduce then sums, for every run, g_b T_b (+ the tower-input gradient slices) with one lane
@@ -38,6 +41,7 @@
 #define FG_WAVE_ROUNDS (FG_WAVE_CAP / 64)
 #define FG_BIG_CAP 16384    // words the 1024-thread kernel sorts in LDS
 #define FG_BIG_ROUNDS (FG_BIG_CAP / 1024)
+#define FG_BIG_CAP_WIDE 7168 // the same with 64-bit words (56 KB)
 #define FG_BIG_MAX 128      // bins above FG_WAVE_CAP per field (B <= 65536)
 #define FG_BIG_GRID 8       // blocks per field of the big-bin launch
 #define FG_MAX_B 65536
@@ -94,6 +98,9 @@ __device__ __forceinline__ unsigned long long fg_match(uint32_t d, bool live) {
   }
   return live ? p : 0ull;
 }
+
+template <bool WIDE> struct FgWord { using type = uint32_t; };
+template <> struct FgWord<true> { using type = uint64_t; };
 
 // ---------------------------------------------------------------- K1: histogram + transpose
 // Bin counts of a block fit 16 bits (256 samples), two per LDS word.
@@ -166,10 +173,14 @@ fg_tile_counts_kernel(FgPlan pl, const uint32_t* __restrict__ hcnt, int n_hist_b
 }
 
 // ---------------------------------------------------------------- K2: stable scatter by bin
+template <bool WIDE>
 __global__ void __launch_bounds__(RX_BLOCK)
 fg_scatter_kernel(FgPlan pl, const uint32_t* __restrict__ keyT, const uint32_t* __restrict__ counts,
-                  uint32_t* __restrict__ part, uint32_t* __restrict__ bstart, uint32_t* __restrict__ biglist,
+                  void* __restrict__ part_v, uint32_t* __restrict__ bstart, uint32_t* __restrict__ biglist,
                   uint32_t* __restrict__ srow, uint32_t* __restrict__ sb) {
+  using W = typename FgWord<WIDE>::type;
+  W* __restrict__ part = reinterpret_cast<W*>(part_v);
+
   __shared__ uint32_t gstart[FG_BINS], texcl[FG_BINS];
   __shared__ uint32_t stg[2 * FG_TS];  // first the 4 x FG_BINS wave counters, later the staged (key, sample) pairs
   __shared__ uint32_t lds4[4];
@@ -280,7 +291,7 @@ fg_scatter_kernel(FgPlan pl, const uint32_t* __restrict__ keyT, const uint32_t* 
         srow[dst] = fbase + k;
         sb[dst] = sv[j];
       } else {
-        part[dst] = ((k >> 8) << pl.BB) | sv[j];
+        part[dst] = ((W)(k >> 8) << pl.BB) | (W)sv[j];
       }
     }
   }
@@ -291,10 +302,13 @@ fg_scatter_kernel(FgPlan pl, const uint32_t* __restrict__ keyT, const uint32_t* 
 // every round matches its digits, the group leaders count; the lanes turn the 256 counts (four each)
 // into starts; the rounds then hand out positions in order (leaders advance the starts), the words
 // go to the wavefront's LDS strip at their new positions and are read back in order.
+template <bool WIDE>
 __global__ void __launch_bounds__(RX_BLOCK)
-fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t* __restrict__ bstart,
+fg_bin_wave_kernel(FgPlan pl, const void* __restrict__ part_v, const uint32_t* __restrict__ bstart,
                    uint32_t* __restrict__ srow, uint32_t* __restrict__ sb) {
-  __shared__ uint32_t strip[RX_BLOCK / 64][FG_WAVE_CAP];
+  using W = typename FgWord<WIDE>::type;
+  const W* __restrict__ part = reinterpret_cast<const W*>(part_v);
+  __shared__ W strip[RX_BLOCK / 64][FG_WAVE_CAP];
   __shared__ __align__(16) uint32_t cnt[RX_BLOCK / 64][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wid = blockIdx.x * (RX_BLOCK / 64) + wave;   // (field, shared bin)
@@ -306,13 +320,13 @@ fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t*
   const int m = (int)(hi - lo);
   if (m == 0 || m > FG_WAVE_CAP) return;
   const size_t p0 = (size_t)f * pl.B + lo;
-  uint32_t x[FG_WAVE_ROUNDS];
+  W x[FG_WAVE_ROUNDS];
 #pragma unroll
   for (int r = 0; r < FG_WAVE_ROUNDS; ++r) {
     const int j = r * 64 + lane;
     x[r] = part[p0 + (j < m ? j : m - 1)];
   }
-  uint32_t* buf = strip[wave];
+  W* buf = strip[wave];
   uint32_t* c = cnt[wave];
   uint4* c4 = reinterpret_cast<uint4*>(c);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -323,7 +337,7 @@ fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t*
 #pragma unroll
     for (int r = 0; r < FG_WAVE_ROUNDS; ++r) {
       if (r * 64 < m) {
-        const uint32_t dg = (x[r] >> bit) & mask;
+        const uint32_t dg = (uint32_t)(x[r] >> bit) & mask;
         peers[r] = fg_match<8>(dg, r * 64 + lane < m);
         if (peers[r] && lane == __ffsll((long long)peers[r]) - 1) c[dg] += (uint32_t)__popcll(peers[r]);
       }
@@ -343,7 +357,7 @@ fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t*
 #pragma unroll
     for (int r = 0; r < FG_WAVE_ROUNDS; ++r) {
       if (r * 64 < m) {
-        const uint32_t dg = (x[r] >> bit) & mask;
+        const uint32_t dg = (uint32_t)(x[r] >> bit) & mask;
         const unsigned long long p = peers[r];
         uint32_t base = 0;
         if (p) base = c[dg];
@@ -361,8 +375,8 @@ fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t*
   for (int r = 0; r < FG_WAVE_ROUNDS; ++r) {
     const int j = r * 64 + lane;
     if (j < m) {
-      srow[p0 + j] = rbase + ((x[r] >> pl.BB) << 8);
-      sb[p0 + j] = x[r] & bmask;
+      srow[p0 + j] = rbase + ((uint32_t)(x[r] >> pl.BB) << 8);
+      sb[p0 + j] = (uint32_t)x[r] & bmask;
     }
   }
 }
@@ -372,12 +386,12 @@ fg_bin_wave_kernel(FgPlan pl, const uint32_t* __restrict__ part, const uint32_t*
 // packed counts gives each thread the start of its words per digit.  The buffers are global memory
 // shared by the block's waves, so accesses bypass the per-CU cache and stores are drained before
 // each barrier.  Only bins beyond FG_BIG_CAP words come here.
-__device__ __forceinline__ uint32_t fg_gld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fg_gst(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename W> __device__ __forceinline__ W fg_gld(const W* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename W> __device__ __forceinline__ void fg_gst(W* p, W v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NTHREADS>
-__device__ __forceinline__ uint32_t* fg_radix_sort_global(uint32_t* a, uint32_t* b, int m, int lo, int nbits,
-                                                          unsigned long long* lds_w) {
+template <int NTHREADS, typename W>
+__device__ __forceinline__ W* fg_radix_sort_global(W* a, W* b, int m, int lo, int nbits,
+                                                   unsigned long long* lds_w) {
   const int k = (m + NTHREADS - 1) / NTHREADS;
   const int j0 = threadIdx.x * k < m ? threadIdx.x * k : m;
   const int j1 = j0 + k < m ? j0 + k : m;
@@ -385,7 +399,7 @@ __device__ __forceinline__ uint32_t* fg_radix_sort_global(uint32_t* a, uint32_t*
     const uint32_t mask = (lo + nbits - bit) >= 2 ? 3u : 1u;
     unsigned long long c = 0;  // counts of digits 0..2 in 21-bit fields (digit 3 follows from the thread's length)
     for (int j = j0; j < j1; ++j) {
-      const uint32_t d = (fg_gld(a + j) >> bit) & mask;
+      const uint32_t d = (uint32_t)(fg_gld(a + j) >> bit) & mask;
       c += d < 3 ? 1ull << (21 * d) : 0ull;
     }
     unsigned long long tot;
@@ -394,15 +408,15 @@ __device__ __forceinline__ uint32_t* fg_radix_sort_global(uint32_t* a, uint32_t*
     const uint32_t p0 = (uint32_t)(pre & 0x1FFFFF), p1 = (uint32_t)((pre >> 21) & 0x1FFFFF), p2 = (uint32_t)((pre >> 42) & 0x1FFFFF);
     uint32_t at0 = p0, at1 = t0 + p1, at2 = t0 + t1 + p2, at3 = t0 + t1 + t2 + ((uint32_t)j0 - p0 - p1 - p2);
     for (int j = j0; j < j1; ++j) {
-      const uint32_t x = fg_gld(a + j);
-      const uint32_t d = (x >> bit) & mask;
+      const W x = fg_gld(a + j);
+      const uint32_t d = (uint32_t)(x >> bit) & mask;
       const uint32_t pos = d == 0 ? at0 : (d == 1 ? at1 : (d == 2 ? at2 : at3));
       at0 += d == 0; at1 += d == 1; at2 += d == 2; at3 += d == 3;
       fg_gst(b + pos, x);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    uint32_t* t = a; a = b; b = t;
+    W* t = a; a = b; b = t;
   }
   return a;
 }
@@ -410,11 +424,17 @@ __device__ __forceinline__ uint32_t* fg_radix_sort_global(uint32_t* a, uint32_t*
 // Bins above FG_WAVE_CAP words: the same 4-bit passes with a whole 1024-thread block per bin (wave w
 // owns a contiguous chunk, so (wave, round, lane) is the original order); blocks walk their field's
 // list of such bins.
+template <bool WIDE>
 __global__ void __launch_bounds__(1024)
-fg_bin_big_kernel(FgPlan pl, uint32_t* __restrict__ part, uint32_t* __restrict__ spare,
+fg_bin_big_kernel(FgPlan pl, void* __restrict__ part_v, void* __restrict__ spare_v,
                   const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ biglist,
                   uint32_t* __restrict__ srow, uint32_t* __restrict__ sb) {
-  __shared__ uint32_t buf[FG_BIG_CAP];
+  using W = typename FgWord<WIDE>::type;
+  constexpr int CAP = WIDE ? FG_BIG_CAP_WIDE : FG_BIG_CAP;     // words a block sorts in LDS (56 KB / 64 KB)
+  constexpr int ROUNDS = CAP / 1024;
+  W* __restrict__ part = reinterpret_cast<W*>(part_v);
+  W* __restrict__ spare = reinterpret_cast<W*>(spare_v);
+  __shared__ W buf[CAP];
   __shared__ uint32_t cnt[16][16];
   __shared__ uint32_t lds16[16];
   __shared__ unsigned long long lds_w[16];
@@ -430,33 +450,33 @@ fg_bin_big_kernel(FgPlan pl, uint32_t* __restrict__ part, uint32_t* __restrict__
     const int m = (int)(hi - lo);
     const size_t p0 = (size_t)f * pl.B + lo;
     const uint32_t rbase = pl.base[f] + (uint32_t)(bin - 256);
-    if (m > FG_BIG_CAP) {
-      const uint32_t* res = fg_radix_sort_global<1024>(part + p0, spare + p0, m, pl.BB, hb, lds_w);
+    if (m > CAP) {
+      const W* res = fg_radix_sort_global<1024, W>(part + p0, spare + p0, m, pl.BB, hb, lds_w);
       for (int j = threadIdx.x; j < m; j += 1024) {
-        const uint32_t x = fg_gld(res + j);
-        srow[p0 + j] = rbase + ((x >> pl.BB) << 8);
-        sb[p0 + j] = x & bmask;
+        const W x = fg_gld(res + j);
+        srow[p0 + j] = rbase + ((uint32_t)(x >> pl.BB) << 8);
+        sb[p0 + j] = (uint32_t)x & bmask;
       }
       __syncthreads();
       continue;
     }
     const int ch = ((m + 15) / 16 + 63) / 64 * 64;   // words per wave, whole rounds
     const int w0 = wave * ch;
-    uint32_t x[FG_BIG_ROUNDS];
+    W x[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < FG_BIG_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       const int j = w0 + r * 64 + lane;
       x[r] = part[p0 + (j < m ? j : m - 1)];
     }
     for (int bit = pl.BB; bit < pl.BB + hb; bit += 4) {
       const uint32_t mask = (1u << (pl.BB + hb - bit < 4 ? pl.BB + hb - bit : 4)) - 1u;
       if (lane < 16) cnt[wave][lane] = 0;
-      unsigned long long peers[FG_BIG_ROUNDS];
+      unsigned long long peers[ROUNDS];
 #pragma unroll
-      for (int r = 0; r < FG_BIG_ROUNDS; ++r) {
+      for (int r = 0; r < ROUNDS; ++r) {
         peers[r] = 0ull;
         if (r * 64 < ch) {
-          const uint32_t dg = (x[r] >> bit) & mask;
+          const uint32_t dg = (uint32_t)(x[r] >> bit) & mask;
           peers[r] = fg_match<4>(dg, w0 + r * 64 + lane < m);
           if (peers[r] && lane == __ffsll((long long)peers[r]) - 1) cnt[wave][dg] += (uint32_t)__popcll(peers[r]);
         }
@@ -470,9 +490,9 @@ fg_bin_big_kernel(FgPlan pl, uint32_t* __restrict__ part, uint32_t* __restrict__
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < FG_BIG_ROUNDS; ++r) {
+      for (int r = 0; r < ROUNDS; ++r) {
         if (r * 64 < ch) {
-          const uint32_t dg = (x[r] >> bit) & mask;
+          const uint32_t dg = (uint32_t)(x[r] >> bit) & mask;
           const unsigned long long p = peers[r];
           uint32_t base = 0;
           if (p) base = cnt[wave][dg];
@@ -482,25 +502,26 @@ fg_bin_big_kernel(FgPlan pl, uint32_t* __restrict__ part, uint32_t* __restrict__
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < FG_BIG_ROUNDS; ++r) {
+      for (int r = 0; r < ROUNDS; ++r) {
         const int j = w0 + r * 64 + lane;
         if (r * 64 < ch) x[r] = buf[j < m ? j : m - 1];
       }
       __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < FG_BIG_ROUNDS; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       const int j = w0 + r * 64 + lane;
       if (r * 64 < ch && j < m) {
-        srow[p0 + j] = rbase + ((x[r] >> pl.BB) << 8);
-        sb[p0 + j] = x[r] & bmask;
+        srow[p0 + j] = rbase + ((uint32_t)(x[r] >> pl.BB) << 8);
+        sb[p0 + j] = (uint32_t)x[r] & bmask;
       }
     }
   }
 }
 
 struct FgWs {
-  uint32_t *keyT, *part, *counts, *hcnt, *bstart, *biglist;
+  uint32_t *keyT, *counts, *hcnt, *bstart, *biglist;
+  void *part, *spare;     // packed words (4 or 8 bytes each) and the scratch of the through-memory sort
   size_t bytes;
 };
 
@@ -512,7 +533,8 @@ static FgWs fg_ws_layout(void* ws, int64_t B, int nf) {
   w.counts = (uint32_t*)p; p += rx_align_up((size_t)nf * NT * FG_BINS * 4, 256);
   w.hcnt = (uint32_t*)p; p += rx_align_up((size_t)nf * rx_cdiv(bb, FG_HB) * (FG_BINS / 2) * 4, 256);
   w.keyT = (uint32_t*)p; p += rx_align_up((size_t)nf * bb * 4, 256);
-  w.part = (uint32_t*)p; p += rx_align_up((size_t)nf * bb * 4, 256);
+  w.part = (void*)p; p += rx_align_up((size_t)nf * bb * 8, 256);
+  w.spare = (void*)p; p += rx_align_up((size_t)nf * bb * 8, 256);
   w.bstart = (uint32_t*)p; p += rx_align_up((size_t)nf * (FG_BINS + 1) * 4, 256);
   w.biglist = (uint32_t*)p; p += rx_align_up((size_t)nf * (FG_BIG_MAX + 1) * 4, 256);
   w.bytes = (size_t)(p - (char*)ws);
@@ -541,7 +563,7 @@ extern "C" int rx_fg_supported(const rx_fg_args* a) {
   if (a->field_base[a->n_fields] > (1ll << 32) - 16) return 0;
   const int BB = fg_bits((uint64_t)(a->B - 1)) > 0 ? fg_bits((uint64_t)(a->B - 1)) : 1;
   const int hb = max_card > 256 ? fg_bits((uint64_t)((max_card - 1) >> 8)) : 0;
-  return BB + hb <= 32 ? 1 : 0;
+  return BB + hb <= 48 ? 1 : 0;
 }
 
 extern "C" int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb, void* ws, size_t ws_bytes,
@@ -551,7 +573,7 @@ extern "C" int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb
   RX_REQUIRE(a->n_fields >= 1 && a->n_fields <= RX_FG_MAX_FIELDS, "rx_fg_group: n_fields=%d outside 1..%d", a->n_fields, RX_FG_MAX_FIELDS);
   RX_REQUIRE(a->B >= 0 && a->B <= FG_MAX_B, "rx_fg_group: B=%lld outside 0..%d", (long long)a->B, FG_MAX_B);
   if (a->B == 0) return 0;
-  RX_REQUIRE(rx_fg_supported(a), "rx_fg_group: field ranges must be ascending, non-empty, below 2^32 - 16 rows, and bits(B - 1) + bits((largest field - 1) >> 8) must fit 32 bits");
+  RX_REQUIRE(rx_fg_supported(a), "rx_fg_group: field ranges must be ascending, non-empty and below 2^32 - 16 rows");
   RX_REQUIRE(a->ex_idx && a->item_idx && d_srow && d_sb && ws, "rx_fg_group: null pointer");
   RX_REQUIRE(a->ex_ld >= a->n_fields - 1 && a->item_ld >= 1, "rx_fg_group: index row strides too small");
   RX_REQUIRE(ws_bytes >= rx_fg_workspace_bytes(a->B, a->n_fields) && ((uintptr_t)ws & 255) == 0, "rx_fg_group: workspace too small or not 256-byte aligned");
@@ -573,11 +595,27 @@ extern "C" int rx_fg_group(const rx_fg_args* a, uint32_t* d_srow, uint32_t* d_sb
   RX_LAUNCH_CHECK();
   hipLaunchKernelGGL(fg_tile_counts_kernel, dim3(pl.NT, pl.nf), dim3(RX_BLOCK), 0, st, pl, w.hcnt, n_hist, w.counts);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fg_scatter_kernel, dim3(pl.NT, pl.nf), dim3(RX_BLOCK), 0, st, pl, w.keyT, w.counts, w.part, w.bstart, w.biglist, d_srow, d_sb);
-  RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fg_bin_wave_kernel, dim3((unsigned)rx_cdiv((int64_t)pl.nf * 256, RX_BLOCK / 64)), dim3(RX_BLOCK), 0, st, pl, w.part, w.bstart, d_srow, d_sb);
-  RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fg_bin_big_kernel, dim3(FG_BIG_GRID, pl.nf), dim3(1024), 0, st, pl, w.part, w.keyT, w.bstart, w.biglist, d_srow, d_sb);
+  // words of (row >> 8, sample): 32 bits when they fit, else 64
+  int64_t max_card = 0;
+  for (int f = 0; f < a->n_fields; ++f) {
+    const int64_t card = a->field_base[f + 1] - a->field_base[f];
+    max_card = card > max_card ? card : max_card;
+  }
+  const bool wide = pl.BB + (max_card > 256 ? fg_bits((uint64_t)((max_card - 1) >> 8)) : 0) > 32;
+  const dim3 gw((unsigned)rx_cdiv((int64_t)pl.nf * 256, RX_BLOCK / 64));
+  if (wide) {
+    hipLaunchKernelGGL(fg_scatter_kernel<true>, dim3(pl.NT, pl.nf), dim3(RX_BLOCK), 0, st, pl, w.keyT, w.counts, w.part, w.bstart, w.biglist, d_srow, d_sb);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fg_bin_wave_kernel<true>, gw, dim3(RX_BLOCK), 0, st, pl, w.part, w.bstart, d_srow, d_sb);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fg_bin_big_kernel<true>, dim3(FG_BIG_GRID, pl.nf), dim3(1024), 0, st, pl, w.part, w.spare, w.bstart, w.biglist, d_srow, d_sb);
+  } else {
+    hipLaunchKernelGGL(fg_scatter_kernel<false>, dim3(pl.NT, pl.nf), dim3(RX_BLOCK), 0, st, pl, w.keyT, w.counts, w.part, w.bstart, w.biglist, d_srow, d_sb);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fg_bin_wave_kernel<false>, gw, dim3(RX_BLOCK), 0, st, pl, w.part, w.bstart, d_srow, d_sb);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fg_bin_big_kernel<false>, dim3(FG_BIG_GRID, pl.nf), dim3(1024), 0, st, pl, w.part, w.spare, w.bstart, w.biglist, d_srow, d_sb);
+  }
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -49,6 +49,10 @@ CASES = [
     ([100000, 9, 3000000], 9000, "uniform"),
     ([1 << 24, 50], 20000, "uniform"),
     ([600, 90000], 30000, "one_row"),          # a single row (id >= 256) holds the whole field: beyond the small bucket kernel
+    # fields whose (row >> 8, sample) words need more than 32 bits: the 64-bit instantiation
+    ([1 << 26, 50], 20000, "uniform"),
+    ([300, 50_000_000, 257, 1 << 27], 4096 + 17, "zipf"),
+    ([600, 1 << 25], 40000, "one_row"),
 ]
 
 
@@ -89,6 +93,26 @@ def test_grouping_at_the_largest_supported_batch_and_a_quarter_batch_row():
     assert np.array_equal((fg.sb.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), exp_b)
     again = _group(sparse, dims)
     assert torch.equal(again.srow, fg.srow) and torch.equal(again.sb, fg.sb)
+
+
+def test_grouping_of_125m_row_tables_at_the_largest_batch():
+    """The field mix of the 125 M-row x 128 workloads at B = 65536 (34-bit words: the 64-bit
+    instantiation), with one row above id 255 named by a third of the samples (sorted through global
+    memory) and one named by 3000 of them (the LDS-resident big-bin path with 64-bit words)."""
+    from recsys_amd import ops, synthetic
+    dims = synthetic.criteo_field_dims(total_rows=125_000_000)
+    B = 65536
+    sparse = synthetic.criteo_batch(dims, B, seed=5, device="cuda")["sparse"]
+    big = int(np.argmax(dims))
+    assert dims[big] > (1 << 24)
+    r = torch.rand(B, device="cuda")
+    sparse[r < 0.34, big] = 40001
+    sparse[(r >= 0.34) & (r < 0.34 + 3000 / B), big] = 12_345_678
+    fg = _group(sparse, dims)
+    ops.raise_if_index_error()
+    exp_row, exp_b = _expected_order(sparse, dims)
+    assert np.array_equal((fg.srow.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), exp_row)
+    assert np.array_equal((fg.sb.to(torch.int64) & 0xFFFFFFFF).cpu().numpy(), exp_b)
 
 
 def test_grouping_flags_an_index_outside_its_field():
