@@ -353,7 +353,8 @@ int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g, const floa
  * [0, field_base[f + 1] - field_base[f]) sets RX_ERR_INDEX and is clamped into its field (stricter
  * than nn.Embedding, which only checks the whole table: here the fields must not alias).
  * field_base holds HOST values.  Limits: B <= 65536, n_fields <= RX_FG_MAX_FIELDS, table rows
- * <= 2^32 - 16, bits(B - 1) + bits((largest field - 1) >> 8) <= 32 (rx_fg_supported tells).
+ * <= 2^32 - 16 (rx_fg_supported tells); fields of any size: the packed (row >> 8, sample) words are
+ * 32 bits wide where bits(B - 1) + bits((largest field - 1) >> 8) <= 32 and 64 bits wide otherwise.
  * ex_idx [B, n_fields - 1] / item_idx [B, 1] with their row strides, as in rx_fm_args. */
 #define RX_FG_MAX_FIELDS 64
 typedef struct {
