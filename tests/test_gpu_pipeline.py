@@ -637,7 +637,7 @@ def test_device_loader_epochs_are_reproducible_from_the_seed():
 
 
 @pytest.mark.parametrize("feed", ["loader", "batches"])
-@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF"])
+@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF", "NeuMF"])
 def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
     """utils.LoopGraph: two epochs with the step replayed as a graph give the same weights and epoch
     losses, bit for bit, as the eager loop on the same seeded loader -- both when the recorded step
@@ -657,7 +657,11 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
         kw = dict(n_users=data.n_users, n_items=data.n_items, embedding_dim=16)
         if name == "TemporalMF":
             kw.update(n_occupations=data.n_occupations, max_timestamp_rank=data.max_timestamp_rank)
-        model = getattr(mf, name)(**kw).cuda().train()
+        if name == "NeuMF":      # two-stream model (GMF half on a branch); no dropout: its masks differ between graph and eager
+            from recsys_amd.models.neuralcf import NeuMF
+            model = NeuMF(data.n_users, data.n_items, 16, dropout=0.0).cuda().train()
+        else:
+            model = getattr(mf, name)(**kw).cuda().train()
         opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
         step = LoopGraph(model, opt) if graphed else None
         ops.set_index_check("deferred")
