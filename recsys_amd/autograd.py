@@ -483,9 +483,12 @@ class LinearAct(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dy = dy.contiguous()
         if ctx.act:
-            dy = ops.relu_bwd(dy, y)
+            dy = ops.relu_bwd(dy.contiguous(), y)
+        elif not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0):
+            # (a column block of a wider gradient -- the backward of torch.cat -- is read in place:
+            # the products take a row stride)
+            dy = dy.contiguous()
         dx = ops.linear_bwd_x(dy, w, ctx.bf16) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
