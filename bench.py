@@ -117,11 +117,19 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
             dims, D = synthetic.criteo_field_dims(total_rows=125_000_000), 128
         cls = {"fm_criteo": fields.FieldFM, "fm_wide_d128": fields.FieldFM, "deepfm_criteo": fields.FieldDeepFM,
                "deepfm_criteo_bf16": fields.FieldDeepFM, "dcnv2_criteo": fields.DCNv2}[name]
+        # fm_criteo: rows of 16 floats sit in 128-byte lines of their own with the bias entry behind them
+        # (fields._FieldTable: same parameters and results, other strides); RX_BENCH_NO_LINE_ROWS=1 for A/B
+        line_rows = name == "fm_criteo" and D == 16 and os.environ.get("RX_BENCH_NO_LINE_ROWS") != "1"
         with torch.device(device):
-            model = cls(dims, D, bf16=True) if name == "deepfm_criteo_bf16" else cls(dims, D)
+            if name == "deepfm_criteo_bf16":
+                model = cls(dims, D, bf16=True)
+            else:
+                model = cls(dims, D, line_rows=True) if line_rows else cls(dims, D)
         batches = [synthetic.criteo_batch(dims, B, seed=1000 * rank + i, device=device) for i in range(n_batches)]
         desc = {"workload": name, "fields": len(dims), "rows": int(sum(dims)), "dim": D, "batch_per_gpu": B,
                 "items_per_row": 1, "optimizer": "fused sparse SGD", "clip_norm": clip}
+        if line_rows:
+            desc["table_layout"] = "one 128-byte line per row: 16 floats, the bias entry, zeros"
         lr = 0.05
     elif name in ("mf_ml1m", "neumf_ml1m"):
         B = 1024 if name == "mf_ml1m" else 8192

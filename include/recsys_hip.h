@@ -179,6 +179,11 @@ typedef struct {
   int64_t B; int32_t F; int32_t N; int32_t dim;
   int32_t flags;            /* RX_FM_NO_SECOND_ORDER: bias sums only (the wide part of
                                recsys/models/neuralcf/widendeep.py:69-77); rows still feed deep_out */
+  int64_t feat_ld;          /* row stride of feat in floats; 0 = dim (rows back to back) */
+  int64_t bias_ld;          /* stride of bias in floats; 0 = 1.  A table whose rows are padded to whole
+                               128-byte lines can hold a row's bias entry in the row's own line
+                               (bias = feat + dim, bias_ld = feat_ld): the bias read then costs no
+                               memory access of its own */
 } rx_fm_args;
 #define RX_FM_NO_SECOND_ORDER 1
 
@@ -393,15 +398,23 @@ typedef struct {
   float lr, eps;
   const float* scale;                      /* NULL: 1 */
   float* sq_part;                          /* NULL: no sums of squares */
+  int64_t ld_w, ld_w2;                     /* row strides (floats) of the TABLE and of the companion table:
+                                              `table` in the gradient modes, `target` / `target2` in the update
+                                              modes; 0 = dim / 1.  Gradient and state arrays are never strided.
+                                              target2 == target + dim with ld_w2 == ld_w == 2 * dim (row and
+                                              companion entry in one line, the rest of the line padding) makes
+                                              the SGD update write whole lines: the padding is rewritten as 0 */
 } rx_fg_reduce_args;
 int64_t rx_fg_reduce_grid(int64_t n, int32_t dim);
 size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim);
 int rx_fg_reduce(const rx_fg_reduce_args* a, void* ws, size_t ws_bytes, int device, void* stream);
 /* Second phase of a clipped step: every run's row moves by its compact gradient (at the run's last
- * position) times *d_scale; mode SGD / ADAGRAD / ROWWISE_ADAGRAD; companion table in the same launch. */
+ * position) times *d_scale; mode SGD / ADAGRAD / ROWWISE_ADAGRAD; companion table in the same launch.
+ * ld_w / ld_w2: row strides of d_w / d_w2 in floats (0 = dim / 1), as in rx_fg_reduce_args. */
 int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                      float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
-                     int64_t n_rows, float lr, float eps, const float* d_scale, int device, void* stream);
+                     int64_t n_rows, float lr, float eps, const float* d_scale, int64_t ld_w, int64_t ld_w2,
+                     int device, void* stream);
 /* The same update with the global-norm clip factor (recsys/utils.py:101: clip_grad_norm_ over all
  * parameters) formed inside the launch: d_parts[0 .. n_parts) are ALL partial sums of squares of the
  * step (the sq_part of the one reduce that fed d_compact; nothing else may contribute), every block
@@ -411,7 +424,8 @@ int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow
 int rx_fg_row_update_clip(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                           float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                           int64_t n_rows, float lr, float eps, const float* d_parts, int64_t n_parts,
-                          float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream);
+                          float max_norm, float* d_scale_out, float* d_norm_out, int64_t ld_w, int64_t ld_w2,
+                          int device, void* stream);
 
 /* Row update from a compact gradient [*n_uniq, dim] produced by RX_SEG_COMPACT (two-phase
  * step when a global clip factor must be known before any row moves). mode as above

@@ -58,6 +58,15 @@ timed("fm2_fwd", lambda i: ops.fm2_fwd(table, bias, batches[i % 4][:, :nf - 1], 
 labels = (torch.rand(B, 1, device=dev) < 0.25).double()
 timed("fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(table, bias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
 timed("bce", lambda i: ops.bce_with_logits(T[:, :1].contiguous(), labels))
+if D == 16:
+    # the same three ops on rows that sit in 128-byte lines of their own, bias entry behind the row
+    buf = torch.zeros(base[-1], 32, device=dev)
+    buf[:, :16].copy_(table)
+    buf[:, 16].copy_(bias)
+    ltab, lbias = buf[:, :16], buf[:, 16]
+    timed("line/fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(ltab, lbias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
+    timed("line/fg_reduce", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=ltab, target2=comp2, want_sq=True, sq_out=sq))
+    timed("line/fg_row_update", lambda i: ops.fg_row_update(comp, fgs[i % 4], _lib.RX_SEG_SGD, ltab, lr=0.05, scale=scale, compact2=comp2, table2=lbias))
 if os.environ.get("SORTED") == "1":
     # the same ops on occurrence lists ordered by ascending row inside every field (any order that keeps a
     # row's occurrences together is valid input): what the bin order costs in memory locality

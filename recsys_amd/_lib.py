@@ -34,7 +34,7 @@ class FMArgs(C.Structure):
     _fields_ = [("feat", vp), ("bias", vp), ("n_feat", i64), ("ex_idx", vp), ("ex_base", vp),
                 ("item_idx", vp), ("item_base", i64), ("ex_ld", i64), ("item_ld", i64),
                 ("deep_ld", i64), ("B", i64), ("F", i32), ("N", i32),
-                ("dim", i32), ("flags", i32)]
+                ("dim", i32), ("flags", i32), ("feat_ld", i64), ("bias_ld", i64)]
 
 
 RX_FG_MAX_FIELDS = 64
@@ -49,7 +49,7 @@ class FGReduceArgs(C.Structure):
     _fields_ = [("T", vp), ("ld_T", i64), ("g", vp), ("ld_g", i64), ("deep", vp), ("deep_ld", i64), ("B", i64),
                 ("n_fields", i32), ("dim", i32), ("mode", i32), ("premultiplied", i32), ("srow", vp), ("sb", vp),
                 ("target", vp), ("state", vp), ("table", vp), ("target2", vp), ("state2", vp), ("n_rows", i64),
-                ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp)]
+                ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp), ("ld_w", i64), ("ld_w2", i64)]
 
 
 RX_FM_NO_SECOND_ORDER = 1
@@ -112,9 +112,9 @@ PROTOTYPES = {
     "rx_fg_reduce": (C.c_int, [C.POINTER(FGReduceArgs), vp, sz, C.c_int, vp]),
     "rx_fm2_fwd_bce_workspace_bytes": (sz, [i64, i32]),
     "rx_fm2_fwd_bce": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp, vp, i64, vp, vp, sz, vp, C.c_int, vp]),
-    "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
+    "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, i64, C.c_int, vp]),
     "rx_fg_row_update_clip": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, f32, vp, vp,
-                                        C.c_int, vp]),
+                                        i64, i64, C.c_int, vp]),
     "rx_row_update": (C.c_int, [vp, i32, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, C.c_int, vp]),
     "rx_epoch_advance": (C.c_int, [C.POINTER(BatchPlan), vp, vp, vp, C.c_int, vp, C.c_int, vp]),
     "rx_segreduce_multi": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, vp, vp, sz, C.c_int, vp]),

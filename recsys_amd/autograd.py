@@ -318,8 +318,9 @@ def table_backward_fm(feat, bias_table, si, tsum, g, n_fields_ex: int, deep=None
     if rule is not None:
         rule.apply_fm(feat, bias_table, si, tsum, g, n_fields_ex, deep, premultiplied)
         return None, None
-    grad = torch.zeros_like(feat)
-    grad2 = torch.zeros_like(bias_table) if bias_table is not None else None
+    # dense gradients are back-to-back rows whatever the strides of the tables
+    grad = torch.zeros(feat.shape, dtype=feat.dtype, device=feat.device)
+    grad2 = torch.zeros(bias_table.shape, dtype=bias_table.dtype, device=bias_table.device) if bias_table is not None else None
     if isinstance(si, FieldGroups):
         ops.fg_reduce(tsum, g, si, _lib.RX_SEG_DENSE, grad, table=feat.detach(), target2=grad2, deep=deep,
                       premultiplied=premultiplied)

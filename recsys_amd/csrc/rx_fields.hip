@@ -638,7 +638,15 @@ struct FgRed {
   uint32_t* meta;      // [windows] leading positions held by the run entering from the left (| FG_META_GOES_ON)
   // rx_fg_row_update_clip: the clip factor is formed by every block from the partial sums of squares
   const float* clip_parts; int64_t clip_n; float clip_max; float* clip_scale_out; float* clip_norm_out;
+  int64_t ldw, ldw2;   // row strides of the table (a.table, or a.target in the update modes) and of the companion table
+  int line;            // the companion entry sits right behind its row in a line of 2 * dim floats: SGD writes whole lines
 };
+
+// Second half of a row's line in the whole-line layout: the companion entry, then zeros.
+template <int GROUP>
+__device__ __forceinline__ void fg_store_line_tail(float* w_row, float v2, int lg) {
+  *reinterpret_cast<float4*>(w_row + GROUP * 4 + lg * 4) = make_float4(lg == 0 ? v2 : 0.f, 0.f, 0.f, 0.f);
+}
 
 // Everything that happens once the sum of a run is known: G = sum_b g_b T_b (+ tower slices),
 // g2 = sum_b g_b; e: the row's current value, whose FM term g2 * e is subtracted here.  p: the run's
@@ -662,10 +670,12 @@ __device__ __forceinline__ float fg_finish(const FgRed& a, float4 G, float g2, f
   }
   G.x *= scale; G.y *= scale; G.z *= scale; G.w *= scale;
   float4 x = e;
-  float* w = a.target + (int64_t)row * dim + lg * 4;
+  float* w = a.target + (int64_t)row * a.ldw + lg * 4;
   if constexpr (MODE == RX_SEG_SGD) {
     x.x = x.x - a.lr * G.x; x.y = x.y - a.lr * G.y; x.z = x.z - a.lr * G.z; x.w = x.w - a.lr * G.w;
-    if (has2 && lg == 0) a.target2[row] = old2 - a.lr * (g2 * scale);
+    const float new2 = old2 - a.lr * (g2 * scale);
+    if (a.line) fg_store_line_tail<GROUP>(a.target + (int64_t)row * a.ldw, new2, lg);   // lane 0 of the group holds the entry
+    else if (has2 && lg == 0) a.target2[(int64_t)row * a.ldw2] = new2;
   } else if constexpr (MODE == RX_SEG_ADAGRAD) {
     float* sp = a.state + (int64_t)row * dim + lg * 4;
     float4 s = *reinterpret_cast<const float4*>(sp);
@@ -686,7 +696,7 @@ __device__ __forceinline__ float fg_finish(const FgRed& a, float4 G, float g2, f
       const float gs = g2 * scale;
       const float s2 = a.state2[row] + gs * gs;
       a.state2[row] = s2;
-      a.target2[row] = a.target2[row] - a.lr * (gs / (sqrtf(s2) + a.eps));
+      a.target2[(int64_t)row * a.ldw2] = a.target2[(int64_t)row * a.ldw2] - a.lr * (gs / (sqrtf(s2) + a.eps));
     }
   }
   *reinterpret_cast<float4*>(w) = x;
@@ -755,8 +765,8 @@ fg_reduce_kernel(FgRed a) {
       e[s] = make_float4(0.f, 0.f, 0.f, 0.f);
       old2[s] = 0.f;
       if (endf[s]) {
-        e[s] = *reinterpret_cast<const float4*>(tab + (int64_t)rw[s + 1] * DIM + lg * 4);
-        if (MODE == RX_SEG_SGD && has2 && lg == 0) old2[s] = a.target2[rw[s + 1]];
+        e[s] = *reinterpret_cast<const float4*>(tab + (int64_t)rw[s + 1] * a.ldw + lg * 4);
+        if (MODE == RX_SEG_SGD && has2 && lg == 0) old2[s] = a.target2[(int64_t)rw[s + 1] * a.ldw2];
       }
     }
 #pragma unroll
@@ -890,8 +900,8 @@ fg_combine_kernel(FgRed a, int64_t n_windows) {
   const bool has_tail = tail != FG_NO_LEFT;
   const bool shortrun = has_tail && !(meta1 & FG_META_GOES_ON);
   if (shortrun) {
-    const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)tail * DIM + lg * 4);
-    const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[tail] : 0.f;
+    const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)tail * a.ldw + lg * 4);
+    const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[(int64_t)tail * a.ldw2] : 0.f;
     G.x += H.x; G.y += H.y; G.z += H.z; G.w += H.w;
     const int64_t p_end = (win + 1) * W + (int64_t)(meta1 & 0xFFFFu) - 1;
     sq += fg_finish<GROUP, MODE>(a, G, g2a + g2b, e, old2, tail, p_end, lg, scale);
@@ -934,8 +944,8 @@ fg_combine_kernel(FgRed a, int64_t n_windows) {
       a2 += __shfl_xor(a2, m, 64);
     }
     if (slot == 0) {
-      const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)row * DIM + lg * 4);
-      const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[row] : 0.f;
+      const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)row * a.ldw + lg * 4);
+      const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[(int64_t)row * a.ldw2] : 0.f;
       sq += fg_finish<GROUP, MODE>(a, A, a2, e, old2, row, p_end, lg, scale);
     }
   }
@@ -1008,10 +1018,10 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
     g2[j] = 0.f; old2[j] = 0.f;
     if (endf[j]) {
       G[j] = *reinterpret_cast<const float4*>(compact + (p0 + j) * DIM + lg * 4);
-      x[j] = *reinterpret_cast<const float4*>(a.target + (int64_t)row[j] * DIM + lg * 4);
+      x[j] = *reinterpret_cast<const float4*>(a.target + (int64_t)row[j] * a.ldw + lg * 4);
       if (has2 && lg == 0) {
         g2[j] = compact2[p0 + j];
-        if (MODE == RX_SEG_SGD) old2[j] = a.target2[row[j]];
+        if (MODE == RX_SEG_SGD) old2[j] = a.target2[(int64_t)row[j] * a.ldw2];
       }
     }
   }
@@ -1023,7 +1033,9 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
     g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
     if constexpr (MODE == RX_SEG_SGD) {
       w.x = w.x - a.lr * g.x; w.y = w.y - a.lr * g.y; w.z = w.z - a.lr * g.z; w.w = w.w - a.lr * g.w;
-      if (has2 && lg == 0) a.target2[r] = old2[j] - a.lr * (g2[j] * scale);
+      const float new2 = old2[j] - a.lr * (g2[j] * scale);
+      if (a.line) fg_store_line_tail<GROUP>(a.target + (int64_t)r * a.ldw, new2, lg);   // lane 0 of the group holds the entry
+      else if (has2 && lg == 0) a.target2[(int64_t)r * a.ldw2] = new2;
     } else if constexpr (MODE == RX_SEG_ADAGRAD) {
       float* sp = a.state + (int64_t)r * DIM + lg * 4;
       float4 s = *reinterpret_cast<const float4*>(sp);
@@ -1044,10 +1056,10 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
         const float gs = g2[j] * scale;
         const float s2 = a.state2[r] + gs * gs;
         a.state2[r] = s2;
-        a.target2[r] = a.target2[r] - a.lr * (gs / (sqrtf(s2) + a.eps));
+        a.target2[(int64_t)r * a.ldw2] = a.target2[(int64_t)r * a.ldw2] - a.lr * (gs / (sqrtf(s2) + a.eps));
       }
     }
-    *reinterpret_cast<float4*>(a.target + (int64_t)r * DIM + lg * 4) = w;
+    *reinterpret_cast<float4*>(a.target + (int64_t)r * a.ldw + lg * 4) = w;
   }
 }
 
@@ -1121,6 +1133,9 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
   a.srow = r->srow; a.sb = r->sb;
   a.n = n; a.B = (int)B; a.nf = n_fields; a.dim = dim; a.target = r->target; a.state = r->state; a.table = r->table;
   a.target2 = r->target2; a.state2 = r->state2; a.n_rows = r->n_rows; a.lr = r->lr; a.eps = r->eps; a.scale = r->scale; a.sq_part = r->sq_part;
+  a.ldw = r->ld_w ? r->ld_w : dim; a.ldw2 = r->ld_w2 ? r->ld_w2 : 1;
+  RX_REQUIRE(a.ldw >= dim && a.ldw % 4 == 0 && a.ldw2 >= 1, "rx_fg_reduce: table row stride must be a multiple of 4 floats and >= dim");
+  a.line = !grad_mode && mode == RX_SEG_SGD && r->target2 && r->target2 == r->target + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
   const size_t nw = (size_t)fg_windows(n, dim);
   char* w = (char*)ws;
   a.partials = (float*)w; w += rx_align_up(nw * 2 * dim * sizeof(float), 256);
@@ -1156,29 +1171,33 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
 static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                              float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                              int64_t n_rows, float lr, float eps, const float* d_scale, const float* d_parts,
-                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream);
+                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int64_t ld_w, int64_t ld_w2,
+                             int device, void* stream);
 
 extern "C" int rx_fg_row_update(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                                 float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
-                                int64_t n_rows, float lr, float eps, const float* d_scale, int device, void* stream) {
+                                int64_t n_rows, float lr, float eps, const float* d_scale, int64_t ld_w, int64_t ld_w2,
+                                int device, void* stream) {
   return fg_row_update_run(d_compact, dim, d_srow, n, mode, d_w, d_state, d_compact2, d_w2, d_state2, n_rows, lr, eps, d_scale,
-                           nullptr, 0, 0.f, nullptr, nullptr, device, stream);
+                           nullptr, 0, 0.f, nullptr, nullptr, ld_w, ld_w2, device, stream);
 }
 
 extern "C" int rx_fg_row_update_clip(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                                      float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                                      int64_t n_rows, float lr, float eps, const float* d_parts, int64_t n_parts,
-                                     float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream) {
+                                     float max_norm, float* d_scale_out, float* d_norm_out, int64_t ld_w, int64_t ld_w2,
+                                     int device, void* stream) {
   RX_REQUIRE(d_parts && n_parts >= 1 && d_scale_out && max_norm > 0.f, "rx_fg_row_update_clip: partial sums, their count, a positive norm bound and the scale output are required");
   RX_REQUIRE(n >= 1, "rx_fg_row_update_clip: an empty list leaves the clip factor unwritten; use rx_clip_scale_parts");
   return fg_row_update_run(d_compact, dim, d_srow, n, mode, d_w, d_state, d_compact2, d_w2, d_state2, n_rows, lr, eps, nullptr,
-                           d_parts, n_parts, max_norm, d_scale_out, d_norm_out, device, stream);
+                           d_parts, n_parts, max_norm, d_scale_out, d_norm_out, ld_w, ld_w2, device, stream);
 }
 
 static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t* d_srow, int64_t n, int mode,
                              float* d_w, float* d_state, const float* d_compact2, float* d_w2, float* d_state2,
                              int64_t n_rows, float lr, float eps, const float* d_scale, const float* d_parts,
-                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int device, void* stream) {
+                             int64_t n_parts, float max_norm, float* d_scale_out, float* d_norm_out, int64_t ld_w, int64_t ld_w2,
+                             int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && fg_group_of(dim), "rx_fg_row_update: bad shape (dim 16, 32, 64 or 128)");
   RX_REQUIRE(mode >= RX_SEG_SGD && mode <= RX_SEG_ROWWISE_ADAGRAD, "rx_fg_row_update: unknown mode %d", mode);
@@ -1190,6 +1209,9 @@ static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t
   FgRed a{};
   a.srow = d_srow; a.n = n; a.dim = dim; a.target = d_w; a.state = d_state; a.target2 = d_w2; a.state2 = d_state2;
   a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
+  a.ldw = ld_w ? ld_w : dim; a.ldw2 = ld_w2 ? ld_w2 : 1;
+  RX_REQUIRE(a.ldw >= dim && a.ldw % 4 == 0 && a.ldw2 >= 1, "rx_fg_row_update: table row stride must be a multiple of 4 floats and >= dim");
+  a.line = mode == RX_SEG_SGD && d_w2 && d_w2 == d_w + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
   a.clip_parts = d_parts; a.clip_n = n_parts; a.clip_max = max_norm; a.clip_scale_out = d_scale_out; a.clip_norm_out = d_norm_out;
   hipStream_t st = (hipStream_t)stream;
   switch (fg_group_of(dim)) {

@@ -373,6 +373,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
   const int spb = blockDim.x / group;
   const int64_t b0 = (int64_t)blockIdx.x * spb;
   const int F = a.F, N = a.N, dim = a.dim;
+  const int64_t fld = a.feat_ld ? a.feat_ld : dim, bld = a.bias_ld ? a.bias_ld : 1;   // table row strides
   {
     const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
     const int n_here = (int)rows_here * F;
@@ -395,8 +396,8 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
   for (int f = 0; f < F; ++f) {
     const int64_t row = lds_idx[my * F + f];
     const bool ok = rx_row_ok(row, a.n_feat, ef);
-    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
-    if (a.bias && ok) bsum += a.bias[row];
+    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
+    if (a.bias && ok) bsum += a.bias[row * bld];
     ROW_FOREACH(k, i) {
       S.p[k].v[i] += e.p[k].v[i];
       Q.p[k].v[i] += e.p[k].v[i] * e.p[k].v[i];
@@ -408,7 +409,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
   for (int n = 0; n < N; ++n) {
     const int64_t row = a.item_idx[b * a.item_ld + n] + a.item_base;
     const bool ok = rx_row_ok(row, a.n_feat, ef);
-    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
     float acc = 0.f;
     ROW_FOREACH(k, i) {
       const float s = S.p[k].v[i] + v.p[k].v[i];
@@ -424,7 +425,7 @@ fm2_fwd_kernel(rx_fm_args a, float* __restrict__ logits, float* __restrict__ dee
     }
     if (lg == 0 && logits) {
       float bt = bsum;
-      if (a.bias && ok) bt += a.bias[row];
+      if (a.bias && ok) bt += a.bias[row * bld];
       logits[b * N + n] = (a.flags & RX_FM_NO_SECOND_ORDER) ? bt : bt + 0.5f * acc;
     }
   }
@@ -438,6 +439,7 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
   const int spb = blockDim.x / group;
   const int64_t b0 = (int64_t)blockIdx.x * spb;
   const int F = a.F, N = a.N, dim = a.dim;
+  const int64_t fld = a.feat_ld ? a.feat_ld : dim;   // table row stride
   {
     const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
     const int n_here = (int)rows_here * F;
@@ -462,7 +464,7 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
   for (int f = 0; f < F; ++f) {
     const int64_t row = lds_idx[my * F + f];
     const bool ok = row >= 0 && row < a.n_feat;
-    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
     ROW_FOREACH(k, i) S.p[k].v[i] += e.p[k].v[i];
   }
   // pass B: items.  d v_n = g_n S (+ deep); gv = sum_n g_n v_n; G = sum_n g_n
@@ -473,7 +475,7 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
     G += gn;
     const int64_t row = a.item_idx[b * a.item_ld + n] + a.item_base;
     const bool ok = row >= 0 && row < a.n_feat;
-    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
     RowRegs<VEC, CH> dv;
     ROW_FOREACH(k, i) {
       gv.p[k].v[i] += (so * gn) * v.p[k].v[i];
@@ -490,7 +492,7 @@ fm2_bwd_kernel(rx_fm_args a, const float* __restrict__ g, const float* __restric
   for (int f = 0; f < F; ++f) {
     const int64_t row = lds_idx[my * F + f];
     const bool ok = row >= 0 && row < a.n_feat;
-    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
     ROW_FOREACH(k, i) e.p[k].v[i] = (so * G) * (S.p[k].v[i] - e.p[k].v[i]) + gv.p[k].v[i];
     if (d_deep) {
       for (int n = 0; n < N; ++n) {
@@ -522,6 +524,8 @@ static int fm_check(const rx_fm_args* a, const char* who) {
   RX_REQUIRE(a->n_feat > 0, "%s: empty table", who);
   RX_REQUIRE(a->ex_ld >= a->F && a->item_ld >= a->N, "%s: index row strides smaller than F / N", who);
   RX_REQUIRE(a->deep_ld >= (int64_t)(1 + a->F) * a->dim, "%s: deep_ld smaller than (1+F)*dim", who);
+  RX_REQUIRE(a->feat_ld == 0 || (a->feat_ld >= a->dim && (a->dim % 4 != 0 || a->feat_ld % 4 == 0)), "%s: feat_ld must be >= dim (and a multiple of 4 floats for 16-byte rows)", who);
+  RX_REQUIRE(a->bias_ld >= 0, "%s: negative bias_ld", who);
   return 0;
 }
 
@@ -568,6 +572,7 @@ fm2_fwd_bce_kernel(rx_fm_args a, const void* __restrict__ labels, float* __restr
   const int spb = blockDim.x / group;
   const int64_t b0 = (int64_t)blockIdx.x * spb;
   const int F = a.F, dim = a.dim;
+  const int64_t fld = a.feat_ld ? a.feat_ld : dim, bld = a.bias_ld ? a.bias_ld : 1;   // table row strides
   {
     const int64_t rows_here = (a.B - b0 < spb) ? a.B - b0 : spb;
     const int n_here = (int)rows_here * F;
@@ -590,8 +595,8 @@ fm2_fwd_bce_kernel(rx_fm_args a, const void* __restrict__ labels, float* __restr
     for (int f = 0; f < F; ++f) {
       const int64_t row = lds_idx[my * F + f];
       const bool ok = rx_row_ok(row, a.n_feat, ef);
-      RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
-      if (a.bias && ok) bsum += a.bias[row];
+      RowRegs<VEC, CH> e = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
+      if (a.bias && ok) bsum += a.bias[row * bld];
       ROW_FOREACH(k, i) {
         S.p[k].v[i] += e.p[k].v[i];
         Q.p[k].v[i] += e.p[k].v[i] * e.p[k].v[i];
@@ -599,7 +604,7 @@ fm2_fwd_bce_kernel(rx_fm_args a, const void* __restrict__ labels, float* __restr
     }
     const int64_t row = a.item_idx[b * a.item_ld] + a.item_base;
     const bool ok = rx_row_ok(row, a.n_feat, ef);
-    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * dim, ok, lg, group, dim);
+    RowRegs<VEC, CH> v = row_load<VEC, CH>(a.feat + row * fld, ok, lg, group, dim);
     float acc = 0.f;
     RowRegs<VEC, CH> t;
     ROW_FOREACH(k, i) {
@@ -610,7 +615,7 @@ fm2_fwd_bce_kernel(rx_fm_args a, const void* __restrict__ labels, float* __restr
     }
     acc = rx_group_sum(acc, group);
     float bt = bsum;
-    if (a.bias && ok) bt += a.bias[row];
+    if (a.bias && ok) bt += a.bias[row * bld];
     const float xf = (a.flags & RX_FM_NO_SECOND_ORDER) ? bt : bt + 0.5f * acc;
     float g = 0.f;
     if (lg == 0) {

@@ -34,6 +34,42 @@ class _FieldTable(HotPathModule):
         self._offsets = offs
         self._field_base = tuple(offs) + (self.n_features,)   # host row offsets of every field + table height
 
+    # ---- whole-line rows -------------------------------------------------------------------------
+    # MI355X moves memory in 128-byte lines.  A D = 16 row is 64 bytes, its bias entry 4 bytes in another
+    # array: two lines per occurrence in the forward pass and, in the update, a second read-modify-write
+    # whose 4-byte store is the expensive kind.  With ``line_rows`` the two parameters are views into one
+    # [rows, 2 * D] buffer -- row in columns 0..D-1, bias entry in column D, zeros behind it -- so a row
+    # and its bias share a line: the bias read rides on the row's, and the SGD update writes the line
+    # whole.  Names, shapes, values and arithmetic of ``feature_embedding.weight`` [rows, D] and
+    # ``bias_embedding.weight`` [rows, 1] do not change (state_dicts stay interchangeable; results are
+    # bit-identical to the back-to-back layout); only their strides do, and the table takes twice the
+    # memory.  Such a model trains through the field-grouped backward only (one item per sample,
+    # batches of up to 65536): the general sort path takes back-to-back rows and refuses these.
+    def _pack_lines(self):
+        feat, bias = self.feature_embedding.weight, self.bias_embedding.weight
+        D = self.embedding_dim
+        if D % 4 or feat.dtype != torch.float32:
+            raise ValueError("line_rows: fp32 rows of a multiple of 4 floats only")
+        with torch.no_grad():
+            buf = torch.zeros(self.n_features, 2 * D, dtype=torch.float32, device=feat.device)
+            buf[:, :D].copy_(feat)
+            buf[:, D].copy_(bias.reshape(-1))
+        self.feature_embedding.weight = nn.Parameter(buf[:, :D], requires_grad=feat.requires_grad)
+        self.bias_embedding.weight = nn.Parameter(buf[:, D:D + 1], requires_grad=bias.requires_grad)
+
+    def lines_packed(self) -> bool:
+        feat, bias = self.feature_embedding.weight, getattr(self, "bias_embedding", None)
+        D = self.embedding_dim
+        return (bias is not None and feat.stride(0) == 2 * D and bias.weight.stride(0) == 2 * D
+                and bias.weight.data_ptr() == feat.data_ptr() + 4 * D)
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() rebuild every parameter on its own, back to back: pack again
+        out = super()._apply(fn, *args, **kwargs)
+        if getattr(self, "line_rows", False) and not self.lines_packed():
+            self._pack_lines()
+        return out
+
     def _split(self, inputs):
         sparse = as_index(inputs["sparse"], "sparse")
         if sparse.dim() != 2 or sparse.shape[1] != self.n_fields:
@@ -62,11 +98,14 @@ class FieldFM(_FieldTable):
     """logit = sum_f bias[f] + 0.5 * sum_d[(sum_f e_f)^2 - sum_f e_f^2]."""
     _sparse_names = ["feature_embedding.weight", "bias_embedding.weight"]
 
-    def __init__(self, field_dims, embedding_dim):
+    def __init__(self, field_dims, embedding_dim, line_rows: bool = False):
         super().__init__()
         self._init_fields(field_dims, embedding_dim)
         self.feature_embedding = nn.Embedding(self.n_features, embedding_dim)
         self.bias_embedding = nn.Embedding(self.n_features, 1)
+        self.line_rows = bool(line_rows)
+        if self.line_rows:
+            self._pack_lines()
 
     def forward(self, inputs):
         ex, base, item, item_base = self._split(inputs)

@@ -96,6 +96,21 @@ def _table(t: Tensor, name: str) -> Tensor:
     return _req(t, torch.float32, name, 2)
 
 
+def _row_strided(t: Tensor, name: str, cols: Optional[int] = None):
+    """fp32 table [rows, cols] on the GPU whose rows may be spaced out (unit inner stride, row stride a
+    multiple of 4 floats, 16-byte aligned): (tensor, row stride).  The layout of a table that keeps
+    every row in a cache line of its own; ops that take only back-to-back rows go through ``_table``."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+        raise TypeError(f"{name}: expected an fp32 [rows, cols] tensor on the GPU")
+    if cols is not None and t.shape[1] != cols:
+        raise ValueError(f"{name}: expected {cols} columns, got {t.shape[1]}")
+    if t.is_contiguous():
+        return t, t.shape[1]
+    if (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(0) < t.shape[1]:
+        raise ValueError(f"{name}: rows must have unit inner stride and must not overlap")
+    return t, t.stride(0)
+
+
 def _idx(t: Tensor, name: str) -> Tensor:
     return _req(t, torch.int64, name)
 
@@ -298,7 +313,9 @@ def _idx_matrix(t: Tensor, name: str):
 
 def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order: bool = True,
              deep_ld: Optional[int] = None):
-    _table(feat, "feature table")
+    feat, feat_ld = _row_strided(feat, "feature table")
+    if feat_ld != feat.shape[1] and (feat_ld % 4 or feat.data_ptr() % 16):
+        raise ValueError("feature table: spaced-out rows need a row stride that is a multiple of 4 floats and 16-byte alignment")
     _idx(ex_base, "ex_base")
     ex_idx, F, ex_ld = _idx_matrix(ex_idx, "ex_idx")
     item_idx, N, item_ld = _idx_matrix(item_idx, "item_idx")
@@ -309,17 +326,24 @@ def _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base: int, second_order
         raise ValueError("ex_base: one offset per field expected")
     if item_idx.shape[0] != B:
         raise ValueError("ex_idx and item_idx disagree on the batch size")
+    bias_ld = 1
     if bias is not None:
-        _req(bias, torch.float32, "bias table")
+        if bias.dim() == 2 and bias.shape[1] == 1:
+            bias = bias[:, 0]
+        if not (bias.is_cuda and bias.dtype == torch.float32 and bias.dim() == 1):
+            raise TypeError("bias table: expected an fp32 vector (or [rows, 1]) on the GPU")
         if bias.numel() != feat.shape[0]:
             raise ValueError("bias table: one entry per feature row expected")
+        bias_ld = bias.stride(0) if bias.numel() > 1 else 1
+        if bias_ld < 1:
+            raise ValueError("bias table: bad stride")
     _same_device(feat, bias, ex_idx, ex_base, item_idx)
     dim = feat.shape[1]
     if deep_ld is None:
         deep_ld = (1 + F) * dim
     a = FMArgs(feat.data_ptr(), 0 if bias is None else bias.data_ptr(), feat.shape[0], ex_idx.data_ptr(),
                ex_base.data_ptr(), item_idx.data_ptr(), item_base, ex_ld, item_ld, deep_ld, B, F, N, dim,
-               0 if second_order else _lib.RX_FM_NO_SECOND_ORDER)
+               0 if second_order else _lib.RX_FM_NO_SECOND_ORDER, feat_ld, bias_ld)
     return a, B, F, N
 
 
@@ -529,6 +553,9 @@ def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mod
     ``deep`` [B, >= (1+F)*D]: gradient of the tower input laid out by fm2_fwd; its per-field slices
     are added to the rows' gradients in the same walk."""
     _req(tsum, torch.float32, "T", 2); _req(g, torch.float32, "g"); _req(target, torch.float32, "target")
+    for t, name in ((table, "table"), (target2, "companion target")):
+        if t is not None:
+            _req(t, torch.float32, name)     # rows back to back: spaced-out tables take the field-grouped path only
     B, dim = tsum.shape
     deep_ld = 0
     if deep is not None:
@@ -614,6 +641,20 @@ def fg_group(ex_idx: Tensor, item_idx: Tensor, field_base: Sequence[int], out: O
     return out if out is not None else FieldGroups(n, n_rows, B, nf, srow, sb)
 
 
+def _table_strides(table: Optional[Tensor], table2: Optional[Tensor], dim: int):
+    """(row stride of the table, stride of its [rows, 1] / [rows] companion) in floats for the rx_fg_* calls."""
+    ld_w, ld_w2 = dim, 1
+    if table is not None:
+        _, ld_w = _row_strided(table, "table", dim)
+        if ld_w % 4 or table.data_ptr() % 16:
+            raise ValueError("table: row stride must be a multiple of 4 floats, 16-byte aligned")
+    if table2 is not None:
+        if not (table2.is_cuda and table2.dtype == torch.float32) or table2.numel() != (table2.shape[0] if table2.dim() else 1):
+            raise TypeError("companion table: expected fp32 [rows] or [rows, 1] on the GPU")
+        ld_w2 = table2.stride(0) if table2.shape[0] > 1 else 1
+    return ld_w, ld_w2
+
+
 def fg_reduce_grid(n: int, dim: int) -> int:
     return max(int(lib.rx_fg_reduce_grid(n, dim)), 1)
 
@@ -629,7 +670,8 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
     for t, name in ((tsum, "T"), (g, "g")):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
             raise TypeError(f"{name}: expected an fp32 tensor on the GPU")
-    _req(target, torch.float32, "target")
+    if mode in (_lib.RX_SEG_COMPACT, _lib.RX_SEG_DENSE):
+        _req(target, torch.float32, "target")     # gradient arrays: rows back to back
     if tsum.dim() != 2 or tsum.stride(1) != 1 or g.dim() != 1:
         raise ValueError("fg_reduce: T must be [B, dim] with unit inner stride, g a vector")
     B, dim = tsum.shape
@@ -662,6 +704,8 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
                     ("scale", scale), ("sq_part", sq)):
         setattr(a, name, 0 if t is None else t.data_ptr())
     a.n_rows, a.lr, a.eps = fg.n_rows, lr, eps
+    grad_mode = mode in (_lib.RX_SEG_COMPACT, _lib.RX_SEG_DENSE)
+    a.ld_w, a.ld_w2 = _table_strides(table if grad_mode else target, None if grad_mode else target2, dim)
     ws = _ws(int(lib.rx_fg_reduce_workspace_bytes(fg.n, dim)), tsum.device)
     check(lib.rx_fg_reduce(C.byref(a), _p(ws), ws.numel(), _dev(tsum), _stream(tsum)), "rx_fg_reduce")
     return sq
@@ -697,6 +741,8 @@ def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *,
     """``clip_parts`` / ``max_norm``: instead of a ready ``scale``, ALL of the step's partial sums of
     squares; the launch forms the clip factor itself (rx_fg_row_update_clip) and (scale, norm) are
     returned as one-element tensors."""
+    _req(compact, torch.float32, "compact", 2)
+    ld_w, ld_w2 = _table_strides(table, table2, compact.shape[1])
     if clip_parts is not None:
         _req(clip_parts, torch.float32, "clip_parts")
         if scale is not None or not clip_parts.is_contiguous():
@@ -704,18 +750,21 @@ def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *,
         out = torch.empty(2, dtype=torch.float32, device=table.device)
         check(lib.rx_fg_row_update_clip(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
                                         _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(clip_parts),
-                                        clip_parts.numel(), float(max_norm), _p(out[0:1]), _p(out[1:2]), _dev(table),
-                                        _stream(table)), "rx_fg_row_update_clip")
+                                        clip_parts.numel(), float(max_norm), _p(out[0:1]), _p(out[1:2]), ld_w, ld_w2,
+                                        _dev(table), _stream(table)), "rx_fg_row_update_clip")
         return out[0:1], out[1:2]
     check(lib.rx_fg_row_update(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
-                               _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(scale), _dev(table),
-                               _stream(table)), "rx_fg_row_update")
+                               _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(scale), ld_w, ld_w2,
+                               _dev(table), _stream(table)), "rx_fg_row_update")
 
 
 def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
                scale=None, compact2=None, table2=None, state2=None) -> None:
     """``compact2`` [n] / ``table2`` / ``state2``: the companion scalar table, updated in the same launch."""
     dim = compact.shape[1] if compact.dim() == 2 else 1
+    _req(table, torch.float32, "table")
+    if table2 is not None:
+        _req(table2, torch.float32, "companion table")
     check(lib.rx_row_update(_p(compact), dim, _p(si.uniq_rows), _p(si.n_uniq), si.n, mode, _p(table), _p(state),
                             _p(compact2), _p(table2), _p(state2), si.n_rows, lr, eps, _p(scale), _dev(table),
                             _stream(table)), "rx_row_update")

@@ -306,3 +306,107 @@ def test_clip_factor_formed_inside_the_row_update_equals_the_separate_launch_bit
     assert len(sa) == len(sb_) and all(torch.equal(x, y) for x, y in zip(sa, sb_))
     assert all(torch.equal(x, y) for x, y in zip(na, nb))
     assert float(na[0]) > 0.02          # the clip was active
+
+
+# ------------------------------------------------------------------ rows in whole cache lines
+def _line_model(dims, dim, line_rows, how):
+    from recsys_amd.models import fields
+    torch.manual_seed(0)
+    if how == "on_device":
+        with torch.device("cuda"):
+            return fields.FieldFM(dims, dim, line_rows=line_rows)
+    return fields.FieldFM(dims, dim, line_rows=line_rows).cuda()      # rebuilt by .cuda(): must pack again
+
+
+@pytest.mark.parametrize("how", ["on_device", "moved"])
+def test_line_rows_keep_names_shapes_and_values(how):
+    dims = [7, 1000, 13, 211]
+    a, b = _line_model(dims, 16, False, how), _line_model(dims, 16, True, how)   # same generator, same draws
+    assert b.lines_packed() and not a.lines_packed()
+    sa, sb_ = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb_)
+    for k in sa:
+        assert sa[k].shape == sb_[k].shape and torch.equal(sa[k].cpu(), sb_[k].cpu())
+    fw, bw = b.feature_embedding.weight, b.bias_embedding.weight
+    assert fw.stride() == (32, 1) and bw.stride(0) == 32 and bw.data_ptr() == fw.data_ptr() + 64
+    # a state_dict of the back-to-back model loads in place: the views stay views of one buffer
+    with torch.no_grad():
+        for p in a.parameters():
+            p.add_(1.0)
+    b.load_state_dict(a.state_dict())
+    assert b.lines_packed() and torch.equal(b.bias_embedding.weight.cpu(), a.bias_embedding.weight.cpu())
+
+
+@pytest.mark.parametrize("kind,clip", [("sgd", 0.02), ("sgd", None), ("adagrad", 0.02), ("adagrad", None), ("rowwise_adagrad", 0.02)])
+def test_line_rows_train_bit_identically_to_back_to_back_rows(kind, clip):
+    """Same seed, same batches: a model whose rows sit in whole 128-byte lines (bias entry behind the
+    row) must produce the same loss bits and the same weights as the back-to-back layout after three
+    fused steps, with the clip (two-phase update, clip factor inside the row update) and without
+    (update inside the reduce); the padding behind the bias entry stays zero."""
+    from recsys_amd import synthetic
+    from recsys_amd.optim import FusedOptimizer
+    dims = [7, 1000, 13, 5000, 3, 211, 40000]
+    batches = [synthetic.criteo_batch(dims, 3000, seed=s, device="cuda") for s in (1, 2, 3)]
+    out = []
+    for line_rows in (False, True):
+        m = _line_model(dims, 16, line_rows, "on_device")
+        m.train()
+        opt = FusedOptimizer(m, kind=kind, lr=0.1, clip_norm=clip)
+        losses = []
+        for b in batches:
+            opt.zero_grad()
+            loss = m.loss(b)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        m.eval()
+        logits = m(batches[0]).detach().clone()
+        out.append((m, losses, logits, [r.state.clone() for r in opt.rules if r.state is not None]))
+    (ma, la, ea, sa), (mb, lb, eb, sb_) = out
+    assert mb.lines_packed()
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    assert torch.equal(ea, eb)
+    assert torch.equal(ma.feature_embedding.weight.detach(), mb.feature_embedding.weight.detach())
+    assert torch.equal(ma.bias_embedding.weight.detach(), mb.bias_embedding.weight.detach())
+    assert len(sa) == len(sb_) and all(torch.equal(x, y) for x, y in zip(sa, sb_))
+    fw = mb.feature_embedding.weight
+    whole = torch.as_strided(fw.detach(), (fw.shape[0], 32), (32, 1))
+    assert int((whole[:, 17:] != 0).sum()) == 0
+    assert not torch.equal(ma.feature_embedding.weight.detach(), _line_model(dims, 16, False, "on_device").feature_embedding.weight.detach())
+
+
+def test_line_rows_dense_gradients_and_torch_optimizer():
+    """Drop-in mode (no fused optimizer): dense gradients, clip_grad_norm_ and torch.optim.SGD on the
+    strided parameters equal the back-to-back model's bit for bit."""
+    from recsys_amd import synthetic
+    dims = [7, 1000, 13, 5000, 3, 211]
+    batch = synthetic.criteo_batch(dims, 2000, seed=4, device="cuda")
+    res = []
+    for line_rows in (False, True):
+        m = _line_model(dims, 16, line_rows, "on_device")
+        opt = torch.optim.SGD(m.parameters(), lr=0.1)
+        for _ in range(2):
+            opt.zero_grad()
+            m.loss(batch).backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.05)
+            opt.step()
+        res.append([p.detach().clone() for p in m.parameters()] + [p.grad.detach().clone() for p in m.parameters()])
+    assert all(torch.equal(x, y) for x, y in zip(*res))
+
+
+def test_line_rows_refuse_the_general_sort_path(monkeypatch):
+    """The general sort + reduce takes back-to-back rows only: a whole-line model that is sent there
+    must fail loudly, not scribble over memory."""
+    from recsys_amd import autograd as rxa, synthetic
+    from recsys_amd.optim import FusedOptimizer
+    dims = [7, 1000, 13, 211]
+    m = _line_model(dims, 16, True, "on_device")
+    before = m.feature_embedding.weight.detach().clone()
+    opt = FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=1.0)
+    monkeypatch.setattr(rxa, "use_field_groups", lambda *a, **k: False)
+    batch = synthetic.criteo_batch(dims, 500, seed=1, device="cuda")
+    with pytest.raises((ValueError, RuntimeError)):
+        opt.zero_grad()
+        m.loss(batch).backward()
+        opt.step()
+    assert torch.equal(before, m.feature_embedding.weight.detach())
