@@ -1219,14 +1219,15 @@ struct Gemm16Args {
 // Pieces in flight between a K-step's global loads and its LDS stores.  Out-of-range pieces are
 // loaded from a clamped (valid) address and zeroed only when they are written to LDS: a select
 // right behind the load would make the wave wait for the load before the MFMAs it is meant to hide behind.
-struct HRegs { uint4 v[H_NP]; unsigned ok; };
+template <int NP = H_NP> struct HRegs { uint4 v[NP]; unsigned ok; };
 
 // K-contiguous: thread = (row tid/8 [+32p], 8 k at (tid%8)*8); K % 8 == 0, so a 16-byte piece is whole or absent
+template <int NP>
 __device__ __forceinline__ void h_load_kc(const uint16_t* __restrict__ P, int64_t ld, int64_t r0, int64_t r_lim,
-                                          int64_t k0, int64_t k_end, int tid, HRegs& t) {
+                                          int64_t k0, int64_t k_end, int tid, HRegs<NP>& t) {
   const int64_t k = k0 + (tid % H_CPR) * 8;
 #pragma unroll
-  for (int p = 0; p < H_NP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int64_t row = r0 + (tid / H_CPR) + (RX_BLOCK / H_CPR) * p;
     const bool ok = row < r_lim && k < k_end;
     t.v[p] = *reinterpret_cast<const uint4*>(P + (ok ? row : 0) * ld + (ok ? k : 0));
@@ -1235,15 +1236,16 @@ __device__ __forceinline__ void h_load_kc(const uint16_t* __restrict__ P, int64_
   }
 }
 
-__device__ __forceinline__ void h_store_kc(uint16_t* lds, int tid, const HRegs& t) {
+template <int NP>
+__device__ __forceinline__ void h_store_kc(uint16_t* lds, int tid, const HRegs<NP>& t) {
 #pragma unroll
-  for (int p = 0; p < H_NP; ++p)
+  for (int p = 0; p < NP; ++p)
     *reinterpret_cast<uint4*>(&lds[((tid / H_CPR) + (RX_BLOCK / H_CPR) * p) * H_LDK + (tid % H_CPR) * 8]) = ((t.ok >> p) & 1u) ? t.v[p] : make_uint4(0u, 0u, 0u, 0u);
 }
 
 // contiguous along the output dimension: 64 k-rows of 128 elements; thread = (k-row tid/16 [+16p], 8 at (tid%16)*8)
 __device__ __forceinline__ void h_load_mc(const uint16_t* __restrict__ P, int64_t ld, int64_t c0, int64_t c_lim,
-                                          int64_t k0, int64_t k_end, int tid, HRegs& t) {
+                                          int64_t k0, int64_t k_end, int tid, HRegs<>& t) {
   const int64_t c = c0 + (tid & 15) * 8;
 #pragma unroll
   for (int p = 0; p < H_NP; ++p) {
@@ -1255,7 +1257,7 @@ __device__ __forceinline__ void h_load_mc(const uint16_t* __restrict__ P, int64_
   }
 }
 
-__device__ __forceinline__ void h_store_mc(uint16_t* lds, int tid, const HRegs& t) {
+__device__ __forceinline__ void h_store_mc(uint16_t* lds, int tid, const HRegs<>& t) {
 #pragma unroll
   for (int p = 0; p < H_NP; ++p)
     *reinterpret_cast<uint4*>(&lds[((tid >> 4) + 16 * p) * H_LDR + (tid & 15) * 8]) = ((t.ok >> p) & 1u) ? t.v[p] : make_uint4(0u, 0u, 0u, 0u);
@@ -1280,11 +1282,36 @@ __device__ __forceinline__ bf16x8 h_frag(const uint16_t* lds, int base, int ks, 
 
 // KC: both operands K-contiguous (forward, input gradient); !KC: both contiguous along the output
 // dimensions (weight gradient, K = batch, slabs over blockIdx.z, fp32 output only)
-template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false>
-__global__ void __launch_bounds__(RX_BLOCK)
+// One k-step of a wavefront's products out of the LDS operand tiles.
+template <bool KC, int WM>
+__device__ __forceinline__ void h_multiply(const uint16_t* As, const uint16_t* Bs, int wave_m, int wave_n, int lane, f32x16 (&acc)[WM][2]) {
+#pragma unroll
+  for (int ks = 0; ks < H_BK; ks += 16) {
+    bf16x8 a[WM], b[2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = h_frag<KC>(As, (wave_m * WM + i) * 32, ks, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = h_frag<KC>(Bs, (wave_n * 2 + j) * 32, ks, lane);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T tile: see the epilogue
+  }
+}
+
+// BM: rows of the output tile, 128 or 256 (K-contiguous operands only).  With 256 rows a wavefront owns
+// 128 x 64 outputs (4 x 2 products per 16-wide k-step): six 1 KB operand reads from LDS feed eight
+// products instead of four feeding four.
+template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false, int BM = H_T>
+__global__ void __launch_bounds__(RX_BLOCK, BM == H_T ? 3 : 2)   // workgroups per CU the register budget must allow
 gemm_h16_kernel(Gemm16Args g, int swizzle) {
-  constexpr int OP_SZ = KC ? H_T * H_LDK : H_BK * H_LDR;
-  extern __shared__ __attribute__((aligned(16))) uint16_t h_lds[];   // [2][2 * OP_SZ]
+  static_assert(BM == H_T || (KC && BM == 2 * H_T), "256-row tiles for K-contiguous operands only");
+  constexpr int WM = BM / 64;                  // 32-row products per wavefront along M
+  constexpr int NPA = H_NP * (BM / H_T);       // 16-byte pieces of A per thread and k-step
+  constexpr int A_SZ = KC ? BM * H_LDK : H_BK * H_LDR;
+  constexpr int B_SZ = KC ? H_T * H_LDK : H_BK * H_LDR;
+  constexpr int OP_SZ = A_SZ + B_SZ;
+  extern __shared__ __attribute__((aligned(16))) uint16_t h_lds[];   // [2][A_SZ + B_SZ]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1294,14 +1321,14 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
   if (swizzle) bid = (bid % 8) * (gridDim.x / 8) + bid / 8;
   const int64_t tile_m = bid / g.tiles_n;
   const int tile_n = (int)(bid % g.tiles_n);
-  const int64_t m0 = tile_m * H_T;
+  const int64_t m0 = tile_m * BM;
   const int64_t n0 = (int64_t)tile_n * H_T;
   const int64_t k_begin = (int64_t)blockIdx.z * g.k_per_slab;
   const int64_t k_end = (k_begin + g.k_per_slab < g.K) ? k_begin + g.k_per_slab : g.K;
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1317,7 +1344,11 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
     for (int e = 0; e < (OUT16 ? 8 : 4); ++e) bias_r[e] = (g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
   }
 
-  HRegs ra, rb;
+  // Operand pieces travel global -> registers -> LDS one k-step ahead of the products.  (Two steps
+  // ahead -- a second register set, the loop written out for two steps -- was measured: no gain at any
+  // of the tower shapes, and the extra registers cost the 128-row tiles a workgroup per CU.)
+  HRegs<NPA> ra;
+  HRegs<> rb;
   auto fetch = [&](int64_t k0) {
     if constexpr (KC) {
       h_load_kc(g.A, g.lda, m0, g.M, k0, k_end, tid, ra);
@@ -1328,9 +1359,9 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
     }
   };
   auto stash = [&](int buf) {
-    uint16_t* base = h_lds + buf * 2 * OP_SZ;
-    if constexpr (KC) { h_store_kc(base, tid, ra); h_store_kc(base + OP_SZ, tid, rb); }
-    else { h_store_mc(base, tid, ra); h_store_mc(base + OP_SZ, tid, rb); }
+    uint16_t* base = h_lds + buf * OP_SZ;
+    if constexpr (KC) { h_store_kc(base, tid, ra); h_store_kc(base + A_SZ, tid, rb); }
+    else { h_store_mc(base, tid, ra); h_store_mc(base + A_SZ, tid, rb); }
   };
 
   fetch(k_begin);
@@ -1340,20 +1371,7 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
   for (int64_t k0 = k_begin; k0 < k_end; k0 += H_BK) {
     const bool more = k0 + H_BK < k_end;
     if (more) fetch(k0 + H_BK);
-    const uint16_t* As = h_lds + cur * 2 * OP_SZ;
-    const uint16_t* Bs = As + OP_SZ;
-#pragma unroll
-    for (int ks = 0; ks < H_BK; ks += 16) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = h_frag<KC>(As, (wave_m * 2 + i) * 32, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = h_frag<KC>(Bs, (wave_n * 2 + j) * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T tile: see the epilogue
-    }
+    h_multiply<KC, WM>(h_lds + cur * OP_SZ, h_lds + cur * OP_SZ + A_SZ, wave_m, wave_n, lane, acc);
     if (more) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -1366,10 +1384,14 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
   // 16-byte pieces of contiguous rows
   float* ct = reinterpret_cast<float*>(h_lds);
   const int h = lane >> 5, l31 = lane & 31;
+  // 64 rows at a time (the image then fits beside nothing bigger than the operand buffers): pass
+  // (wm, hp) holds the rows of wavefront row wm's products 2 hp and 2 hp + 1
+#pragma unroll
+  for (int hp = 0; hp < WM / 2; ++hp) {
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {      // 64 rows at a time: the image then fits beside nothing bigger than the operand buffers
-    if (half) __syncthreads();
-    if (wave_m == half) {
+  for (int wm = 0; wm < 2; ++wm) {
+    if (hp || wm) __syncthreads();
+    if (wave_m == wm) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1377,10 +1399,10 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(&ct[(i * 32 + l31) * H_LDC + (wave_n * 2 + j) * 32 + 8 * q + 4 * h]) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                make_float4(acc[2 * hp + i][j][4 * q], acc[2 * hp + i][j][4 * q + 1], acc[2 * hp + i][j][4 * q + 2], acc[2 * hp + i][j][4 * q + 3]);
     }
     __syncthreads();
-    const int64_t mh = m0 + 64 * half;
+    const int64_t mh = m0 + 64 * (wm * (WM / 2) + hp);
     if constexpr (OUT16) {
       // 8 columns per thread: 16 threads per row, 16 rows per pass
       const int c8 = (tid & 15) * 8;
@@ -1450,29 +1472,51 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
       }
     }
   }
+  }
 }
 
-#define H_LDS_OPERANDS(KC_) ((size_t)2 * 2 * ((KC_) ? H_T * H_LDK : H_BK * H_LDR) * sizeof(uint16_t))
+#define H_LDS_OPERANDS(KC_, BM_) ((size_t)2 * ((KC_) ? ((BM_) + H_T) * H_LDK : 2 * H_BK * H_LDR) * sizeof(uint16_t))
 #define H_LDS_IMAGE ((size_t)64 * H_LDC * sizeof(float))
-#define H_LDS_BYTES(KC_) (H_LDS_OPERANDS(KC_) > H_LDS_IMAGE ? H_LDS_OPERANDS(KC_) : H_LDS_IMAGE)
+#define H_LDS_BYTES(KC_, BM_) (H_LDS_OPERANDS(KC_, BM_) > H_LDS_IMAGE ? H_LDS_OPERANDS(KC_, BM_) : H_LDS_IMAGE)
+
+template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false, int BM = H_T>
+static int gemm_h16_launch_bm(Gemm16Args& g, int n_slabs, hipStream_t st);
+
+// Tall tiles (256 rows) where the grid still fills the card a few times over; RX_GEMM16_TILE_ROWS=128
+// in the environment keeps every product on 128-row tiles (A/B timing).
+static bool h16_tall_tiles(const Gemm16Args& g) {
+  static const int forced = [] { const char* e = getenv("RX_GEMM16_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  if (forced == 128) return false;
+  return rx_cdiv(g.M, 2 * H_T) * rx_cdiv(g.N, H_T) >= 512;
+}
 
 template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS = false>
 static int gemm_h16_launch(Gemm16Args& g, int n_slabs, hipStream_t st) {
+  // measured at the tower shapes (M = 65536): tall tiles pay for plain forward products (fp32 out 10-15 %,
+  // bf16 out 1-5 %); the gated and accumulating input-gradient products, bound by their extra operand, lose
+  if constexpr (KC && !GATE && !ACCUM) {
+    if (h16_tall_tiles(g)) return gemm_h16_launch_bm<KC, OUT16, GATE, ACCUM, CROSS, 2 * H_T>(g, n_slabs, st);
+  }
+  return gemm_h16_launch_bm<KC, OUT16, GATE, ACCUM, CROSS, H_T>(g, n_slabs, st);
+}
+
+template <bool KC, bool OUT16, bool GATE, bool ACCUM, bool CROSS, int BM>
+static int gemm_h16_launch_bm(Gemm16Args& g, int n_slabs, hipStream_t st) {
   g.tiles_n = (int)rx_cdiv(g.N, H_T);
-  const int64_t blocks = rx_cdiv(g.M, H_T) * g.tiles_n;
+  const int64_t blocks = rx_cdiv(g.M, BM) * g.tiles_n;
   RX_REQUIRE(blocks < (1ll << 31), "gemm16: grid too large");
-  const size_t lds = H_LDS_BYTES(KC);
+  const size_t lds = H_LDS_BYTES(KC, BM);
   // 72 KB / 80 KB of dynamic LDS need the attribute once per instantiation and device
   static bool raised[64] = {};
   int device = 0;
   RX_HIP(hipGetDevice(&device));
   if (device < 0 || device >= 64 || !raised[device]) {
-    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>),
+    RX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS, BM>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (device >= 0 && device < 64) raised[device] = true;
   }
   const int swz = (blocks % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);
+  hipLaunchKernelGGL((gemm_h16_kernel<KC, OUT16, GATE, ACCUM, CROSS, BM>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), lds, st, g, swz);
   RX_LAUNCH_CHECK();
   return 0;
 }
