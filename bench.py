@@ -666,6 +666,12 @@ def main():
                                 "distinct_rows_per_round": round_rows,
                                 "table_bytes_touched_per_round": None if round_rows is None else round_rows * (4 * w["desc"]["dim"] + 4),
                                 "infinity_cache_bytes": 256 * 1024 * 1024}
+    if world > 1:
+        # what a weak-scaling efficiency of this line is to be computed against: the SAME sharded workload at
+        # one rank, which the --gpus 1 line reports under other_workloads (its main line is the unsharded
+        # D = 16 configuration, another workload)
+        out["scaling_base"] = {"workload": args.workload, "where": "other_workloads[workload == '%s'] of the --gpus 1 line" % args.workload,
+                               "note": "value / (n_gpus x that entry's samples_per_s); the --gpus 1 main line runs fm_criteo (D = 16, unsharded)"}
     cap_slots = getattr(w["model"], "capacity", None)
     if world > 1 and cap_slots:
         # third bound of the sharded step: bytes a rank puts on its xGMI links per step (slot ids out,

@@ -684,10 +684,12 @@ int rx_sample_negatives(const int64_t* d_users, const int64_t* d_items, const in
  * step that is replayed as a HIP graph: recorded at the end of the step, one launch
  *   - adds the step's loss (d_loss: one double, or one float when loss_f64 == 0; may be NULL together
  *     with d_running) to d_running[0],
- *   - copies batch *d_cursor + 1 of every epoch tensor (rows [(c + 1) * rows_per_batch, (c + 2) *
- *     rows_per_batch) of src[t], row_bytes[t] bytes per row, a multiple of 8) into dst[t], the
- *     static batch the recorded step reads, unless that batch index is n_batches or beyond,
- *   - and advances *d_cursor.
+ *   - copies batch *d_cursor + ahead of every epoch tensor (rows [(c + ahead) * rows_per_batch,
+ *     (c + ahead + 1) * rows_per_batch) of src[t], row_bytes[t] bytes per row, a multiple of 8) into
+ *     dst[t], the static batch a recorded step reads, unless that batch index is n_batches or beyond
+ *     (ahead = 1: one static batch, refilled for the next step; ahead = 2: two static batches used in
+ *     turn, so that the index preparation of the next batch can run beside the current step),
+ *   - and advances *d_cursor by one.
  * d_ticket: one zero-initialised uint32 owned by this call sequence (the launch leaves it at zero).
  * Launches that share a cursor must not overlap. */
 #define RX_BATCH_MAX_TENSORS 8
@@ -698,6 +700,7 @@ typedef struct rx_batch_plan {
   int32_t count;
   int64_t rows_per_batch;
   int64_t n_batches;
+  int64_t ahead;            /* 0 is read as 1 */
 } rx_batch_plan;
 int rx_epoch_advance(const rx_batch_plan* plan, int64_t* d_cursor, uint32_t* d_ticket, const void* d_loss,
                      int loss_f64, double* d_running, int device, void* stream);

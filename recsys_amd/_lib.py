@@ -67,7 +67,8 @@ RX_BATCH_MAX_TENSORS = 8
 
 class BatchPlan(C.Structure):
     _fields_ = [("src", vp * RX_BATCH_MAX_TENSORS), ("dst", vp * RX_BATCH_MAX_TENSORS),
-                ("row_bytes", i64 * RX_BATCH_MAX_TENSORS), ("count", i32), ("rows_per_batch", i64), ("n_batches", i64)]
+                ("row_bytes", i64 * RX_BATCH_MAX_TENSORS), ("count", i32), ("rows_per_batch", i64), ("n_batches", i64),
+                ("ahead", i64)]
 
 
 class SegTable(C.Structure):

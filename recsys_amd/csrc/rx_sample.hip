@@ -71,10 +71,11 @@ __global__ void __launch_bounds__(RX_BLOCK)
 epoch_advance_kernel(rx_batch_plan p, int64_t* __restrict__ cursor, uint32_t* __restrict__ ticket,
                      const void* __restrict__ loss, int loss_f64, double* __restrict__ running) {
   const int64_t next = cursor[0] + 1;
-  if (next >= 0 && next < p.n_batches) {
+  const int64_t take = cursor[0] + (p.ahead > 0 ? p.ahead : 1);   // the batch that goes into the static tensors
+  if (take >= 0 && take < p.n_batches) {
     for (int t = 0; t < p.count; ++t) {
       const int64_t words = p.rows_per_batch * (p.row_bytes[t] / 8);
-      const uint64_t* src = reinterpret_cast<const uint64_t*>(p.src[t]) + next * words;
+      const uint64_t* src = reinterpret_cast<const uint64_t*>(p.src[t]) + take * words;
       uint64_t* dst = reinterpret_cast<uint64_t*>(p.dst[t]);
       for (int64_t i = (int64_t)blockIdx.x * RX_BLOCK + threadIdx.x; i < words; i += (int64_t)gridDim.x * RX_BLOCK) dst[i] = src[i];
     }
@@ -95,7 +96,7 @@ extern "C" int rx_epoch_advance(const rx_batch_plan* plan, int64_t* d_cursor, ui
                                 int loss_f64, double* d_running, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(plan && d_cursor && d_ticket, "rx_epoch_advance: null argument");
-  RX_REQUIRE(plan->count >= 1 && plan->count <= RX_BATCH_MAX_TENSORS && plan->rows_per_batch >= 1 && plan->n_batches >= 0,
+  RX_REQUIRE(plan->count >= 1 && plan->count <= RX_BATCH_MAX_TENSORS && plan->rows_per_batch >= 1 && plan->n_batches >= 0 && plan->ahead >= 0,
              "rx_epoch_advance: 1..%d tensors, a positive batch size and a non-negative batch count", RX_BATCH_MAX_TENSORS);
   RX_REQUIRE((d_loss == nullptr) == (d_running == nullptr), "rx_epoch_advance: loss and running sum come as a pair");
   int64_t most = 0;

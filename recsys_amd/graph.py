@@ -176,6 +176,68 @@ class GraphedTrainStep:
         self.losses.append(loss)
         return len(self.graphs) - 1
 
+    def add_pair(self, batches, epilogues, unroll: int = 8):
+        """Two static batches that take turns (utils.LoopGraph over a resident epoch): the graph of
+        slot s runs the step on batch s, prepares the indices of batch 1 - s on a forked stream beside
+        it, and ends with ``epilogues[s](loss)`` (the hand-over that refills batch s).  Replays must
+        alternate s = 0, 1, 0, ...; before the first replay of slot 0 its preparation has to be current
+        (``refresh_prepared(0)``).  A third graph holds ``unroll`` (even) such steps starting at slot 0
+        (``run_pair_steps``): one host launch per ``unroll`` steps, for steps short enough that the
+        launch itself sets the pace.  The recording runs the index preparation of both batches once and
+        nothing else.  Returns the two slot numbers."""
+        if ops._INDEX_CHECK != "deferred":
+            raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
+        dev = next(self.model.parameters()).device
+        prepared = [self.model.prepare(b) for b in batches]      # static preparation buffers (filled eagerly once)
+
+        def record(order):
+            g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad()
+            clear_sort_cache()
+            with torch.cuda.graph(g, pool=self._pool):
+                main = torch.cuda.current_stream(dev)
+                for s in order:
+                    fork = torch.cuda.Stream(device=dev)
+                    fork.wait_stream(main)       # behind the hand-over that refilled batch 1 - s
+                    with torch.cuda.stream(fork):
+                        self.model.prepare(prepared[1 - s], out=prepared[1 - s])
+                    loss = self._eager(prepared[s])
+                    epilogues[s](loss)
+                    main.wait_stream(fork)
+            clear_sort_cache()
+            if self._pool is None:
+                self._pool = g.pool()
+            return g, loss
+
+        slots = []
+        for s in (0, 1):
+            g, loss = record([s])
+            self.graphs.append(g)
+            self.batches.append(batches[s])
+            self.losses.append(loss)
+            slots.append(len(self.graphs) - 1)
+        unroll -= unroll % 2
+        self._pair_multi = (record([k % 2 for k in range(unroll)])[0], unroll) if unroll >= 4 else None
+        self._pair_prepared, self._pair_slots = prepared, slots
+        return slots
+
+    def run_pair_steps(self, count: int) -> None:
+        """``count`` alternating steps of the pair starting at its slot 0: multi-step graph launches
+        while enough steps remain, single-step graphs for the rest."""
+        done = 0
+        if self._pair_multi is not None:
+            g, u = self._pair_multi
+            while count - done >= u:
+                g.replay()
+                done += u
+        while done < count:
+            self.graphs[self._pair_slots[done % 2]].replay()
+            done += 1
+
+    def refresh_prepared(self, s: int) -> None:
+        """Index preparation of the pair's static batch ``s`` from its current contents (eager)."""
+        self.model.prepare(self._pair_prepared[s], out=self._pair_prepared[s])
+
     def copy_batch(self, slot: int, new_batch: Dict[str, torch.Tensor]) -> None:
         for k, v in self.batches[slot].items():
             if k in new_batch:

@@ -1178,10 +1178,11 @@ def sample_negatives(users: Tensor, items: Tensor, pool: Tensor, n_neg: int, see
 
 
 def epoch_advance(epoch: Dict[str, Tensor], batch: Dict[str, Tensor], n_batches: int, cursor: Tensor, ticket: Tensor,
-                  loss: Optional[Tensor] = None, running: Optional[Tensor] = None) -> None:
-    """rx_epoch_advance: ``running += loss``, then batch ``cursor + 1`` of every tensor of ``epoch``
-    (slices of ``batch[k].shape[0]`` rows along dim 0) goes into ``batch[k]``, and the cursor moves on.
-    Meant to be recorded at the end of a graphed train step (utils.LoopGraph)."""
+                  loss: Optional[Tensor] = None, running: Optional[Tensor] = None, ahead: int = 1) -> None:
+    """rx_epoch_advance: ``running += loss``, then batch ``cursor + ahead`` of every tensor of ``epoch``
+    (slices of ``batch[k].shape[0]`` rows along dim 0) goes into ``batch[k]``, and the cursor moves on
+    by one.  Meant to be recorded at the end of a graphed train step (utils.LoopGraph; ``ahead`` = 2
+    when two static batches take turns)."""
     from ._lib import BatchPlan, RX_BATCH_MAX_TENSORS
     keys = list(batch)
     if not 1 <= len(keys) <= RX_BATCH_MAX_TENSORS:
@@ -1190,7 +1191,7 @@ def epoch_advance(epoch: Dict[str, Tensor], batch: Dict[str, Tensor], n_batches:
     plan = BatchPlan()
     plan.count = len(keys)
     rows = batch[keys[0]].shape[0]
-    plan.rows_per_batch, plan.n_batches = rows, int(n_batches)
+    plan.rows_per_batch, plan.n_batches, plan.ahead = rows, int(n_batches), int(ahead)
     for t, k in enumerate(keys):
         src, dst = epoch[k], batch[k]
         if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype

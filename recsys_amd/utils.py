@@ -85,9 +85,10 @@ class LoopGraph:
     Two ways to feed the recorded step.  Called per batch (any iterable of batches), each batch is
     copied into the static copy from the host (``GraphedTrainStep.copy_batch``).  Given a whole
     ``dataset.EpochLoader`` (``run_epoch``; ``train_epoch`` does that), the epoch's shuffled tensors
-    stay on the device and the recorded step itself ends with the hand-over to the next batch
-    (rx_epoch_advance: running loss, copy of the next slices, cursor), so that the host's share of a
-    step is one graph launch.  Both ways train on the same batches in the same order."""
+    stay on the device and the recorded step itself ends with the hand-over (rx_epoch_advance: running
+    loss, copy of coming slices, cursor), so that the host's share of a step is one graph launch; two
+    static batches take turns there, and the graph of one prepares the indices of the other beside its
+    own step.  Both ways train on the same batches in the same order."""
 
     def __init__(self, model, optimizer, eager_steps: int = 2):
         from .graph import GraphedTrainStep
@@ -127,16 +128,22 @@ class LoopGraph:
             i += 1
         if i < n_full:
             if self.epoch_slot is None:
+                # two static batches take turns: while the step runs on one, the index preparation (sort,
+                # dedup) of the other, which already holds the next batch, runs beside it; the step's
+                # hand-over then refills its own batch with the batch after next
                 optimizer.clip_norm = clip_norm
-                batch = {k: v.clone() for k, v in cut(i).items()}
-                hand_over = lambda loss: ops.epoch_advance(self.epoch, batch, n_full, self.cursor, self.ticket,
-                                                           loss.detach(), self.running)
-                self.epoch_slot = self.step.add_batch(batch, epilogue=hand_over)   # records, executes nothing
-            self.step.copy_batch(self.epoch_slot, cut(i))
+                pair = [{k: v.clone() for k, v in cut(i).items()} for _ in range(2)]
+                hand_over = [(lambda loss, b=b: ops.epoch_advance(self.epoch, b, n_full, self.cursor, self.ticket,
+                                                                  loss.detach(), self.running, ahead=2)) for b in pair]
+                self.epoch_slot = self.step.add_pair(pair, hand_over)   # records, executes nothing
+            s0, s1 = self.epoch_slot
+            self.step.copy_batch(s0, cut(i))
+            if i + 1 < n_full:
+                self.step.copy_batch(s1, cut(i + 1))
+            self.step.refresh_prepared(0)
             self.cursor.fill_(i)
             self.running.copy_(running.reshape(1))
-            for _ in range(n_full - i):
-                self.step(self.epoch_slot)
+            self.step.run_pair_steps(n_full - i)
             running = self.running[0].clone()
         if n % B:
             running += train_step(model, optimizer, {k: v[n_full * B:] for k, v in self.epoch.items()}, clip_norm)
