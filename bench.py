@@ -400,6 +400,36 @@ def run_train_loop(name, device, clip):
                     "copy of the next batch's slices into the static batch, cursor); the short last batch runs eagerly"}
 
 
+def run_eval_loop(name, device):
+    """The evaluation half of an epoch of the reference's loop (recsys/utils.py:67-81): list-wise forward of
+    every test user over its 100 candidate items, top-10 on the device, NDCG / HR -- ``recsys_amd.utils.eval_loop``
+    on ML-1M-sized data (6040 users), timed end to end including the metrics' host read."""
+    import contextlib
+    import io
+    from recsys_amd.dataset import ImplicitData, synthetic_ml1m_data
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.utils import eval_loop
+    data = ImplicitData(synthetic_ml1m_data(seed=0), device=device, seed=1)
+    data.create_test_dataloader()
+    torch.manual_seed(1234)
+    with torch.device(device):
+        model = (VanillaMF if name.startswith("mf_") else NeuMF)(data.n_users, data.n_items, 64)
+    times = []
+    for _ in range(6):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):     # eval_loop prints its metrics line like the reference
+            ndcg, hr = eval_loop(model, data, 10)
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    el = sorted(times[1:])[len(times[1:]) // 2]
+    users = int(data.test_codes.shape[0])
+    return {"workload": name, "users_per_s": users / el, "ms_per_eval": 1e3 * el, "users": users,
+            "candidates_per_user": int(data.test_codes.shape[1]), "k": 10, "dtype": "f32", "ndcg": float(ndcg), "hr": float(hr),
+            "what": "utils.eval_loop: N = 100 list-wise forwards over the test loader, rx_topk_codes, NDCG / HR; median of 5 after 1 warm-up"}
+
+
 def kernel_source_sha():
     """sha256 over the HIP sources and the C header: identifies the kernels a PMC measurement was taken on."""
     import glob
@@ -495,7 +525,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
-    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
+    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,neumf_ml1m_eval_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 
@@ -516,6 +546,9 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:     # RX_BENCH_FORCE_DIST without a launcher: a group of one
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         backend = os.environ.get("RX_BENCH_BACKEND", "nccl")   # "gloo" only for the shared-card rehearsal
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -688,6 +721,10 @@ def main():
     if extras and rank == 0 and world == 1:
         out["other_workloads"] = []
         for name in extras:
+            if name.endswith("_eval_loop"):
+                out["other_workloads"].append(run_eval_loop(name, device))
+                torch.cuda.empty_cache()
+                continue
             if name.endswith("_train_loop"):
                 out["other_workloads"].append(run_train_loop(name, device, clip))
                 torch.cuda.empty_cache()
