@@ -600,7 +600,7 @@ __device__ __forceinline__ void g3_store_mc(float* lds, int tid, const G3Regs& t
 }
 
 template <bool A_KC, bool B_KC, bool ACCUM>
-__global__ void __launch_bounds__(RX_BLOCK)
+__global__ void __launch_bounds__(RX_BLOCK, 4)   // 128 registers: four workgroups per CU (34 KB of LDS each)
 gemm_f32_pipe_kernel(GemmArgs g, int swizzle) {
   constexpr int T_SZ = G3_BK * G3_LD;
   __shared__ __attribute__((aligned(16))) float lds[2][2 * T_SZ];
