@@ -513,6 +513,54 @@ def cpu_baseline(name, desc, clip, budget_s=25.0, optimizer="sgd"):
                       f"clip_grad_norm_ + torch.optim.{'SGD' if optimizer == 'sgd' else 'Adam(lr=1e-3)'}, {el:.1f} s"}
 
 
+def extra_entry(name, device, clip, run):
+    """One entry of ``other_workloads``: a further single-GPU workload timed briefly."""
+    if name.endswith("_eval_loop"):
+        return run_eval_loop(name, device)
+    if name.endswith("_train_loop"):
+        return run_train_loop(name, device, clip)
+    # the 64 GB-table workloads need a longer warm-up (allocator growth, first touches)
+    n2, wu2 = (96, 24) if name in ("fm_wide_d128", "fm_criteo_sharded") else (30, 5)
+    if name == "deepfm_wide_d128_sharded":
+        n2, wu2 = 12, 3        # 20-30 ms per step; the 24 set-up steps of run() come on top
+    if name in ("mf_ml1m", "neumf_ml1m"):
+        n2, wu2 = 200, 20      # steps of 0.1-0.4 ms: a 30-step region is a few ms and one hiccup doubles it
+    w2, el2, _, _ = run(name, n2, wu2)
+    entry = {"workload": name, "samples_per_s": w2["B"] * n2 / el2, "ms_per_step": 1e3 * el2 / n2,
+             "dtype": workload_dtype(name)}
+    if name in ("fm_wide_d128", "fm_criteo_sharded"):
+        r2 = unique_fraction(w2["batches"], w2["dims"])
+        b2 = embedding_bytes_per_sample(w2["desc"], r2)
+        entry["embedding_hbm_frac"] = b2 * entry["samples_per_s"] / 1e9 / HBM_PEAK_GBS
+        entry["distinct_row_fraction"] = r2
+    if name == "deepfm_wide_d128_sharded":
+        entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"],
+                     role="the 1 B-row x 128 DeepFM as named, one rank's share (125 M rows, tower 3344-3344-1672-836-1)")
+    if name == "fm_criteo_sharded":
+        # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
+        entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")
+    fl = dense_flops_per_sample(name)
+    if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
+        entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12
+    return entry
+
+
+def extra_in_child(name, args, limit_s=420):
+    """``extra_entry`` in a child process (this file with --child-entry); a child that fails leaves an
+    entry that says so.  The parent has released its tables before this is called."""
+    import subprocess
+    cmd = [sys.executable, "-u", os.path.abspath(__file__), "--workload", name, "--child-entry", "--extra", "none",
+           "--no-cpu-baseline"] + (["--no-clip"] if args.no_clip else [])
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"workload": name, "error": f"no result within {limit_s} s"}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"workload": name, "error": f"child process ended with code {p.returncode}", "stderr_tail": p.stderr[-300:]}
+    return json.loads(lines[-1])
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -525,6 +573,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
+    ap.add_argument("--extras-in-process", action="store_true", help="time the --extra workloads in this process instead of one child process each")
+    ap.add_argument("--child-entry", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,neumf_ml1m_eval_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
@@ -622,6 +672,9 @@ def main():
                 ops_ms["_gemm_op"] = ran
         return w, el, ops_ms, float(loss.item())
 
+    if args.child_entry:       # one entry of other_workloads, printed for the parent process
+        print(json.dumps(extra_entry(args.workload, device, clip, run)))
+        return
     if args.op_profile and rank == 0:
         w = build_workload(args.workload, device, rank, world, clip, use_graph=False)
         for i in range(5):
@@ -719,42 +772,9 @@ def main():
 
     extras = [x for x in args.extra.split(",") if x and x != "none" and x != args.workload]
     if extras and rank == 0 and world == 1:
-        out["other_workloads"] = []
-        for name in extras:
-            if name.endswith("_eval_loop"):
-                out["other_workloads"].append(run_eval_loop(name, device))
-                torch.cuda.empty_cache()
-                continue
-            if name.endswith("_train_loop"):
-                out["other_workloads"].append(run_train_loop(name, device, clip))
-                torch.cuda.empty_cache()
-                continue
-            # the 64 GB-table workloads need a longer warm-up (allocator growth, first touches)
-            n2, wu2 = (96, 24) if name in ("fm_wide_d128", "fm_criteo_sharded") else (30, 5)
-            if name == "deepfm_wide_d128_sharded":
-                n2, wu2 = 12, 3        # 20-30 ms per step; the 24 set-up steps of run() come on top
-            if name in ("mf_ml1m", "neumf_ml1m"):
-                n2, wu2 = 200, 20      # steps of 0.1-0.4 ms: a 30-step region is a few ms and one hiccup doubles it
-            w2, el2, _, _ = run(name, n2, wu2)
-            entry = {"workload": name, "samples_per_s": w2["B"] * n2 / el2, "ms_per_step": 1e3 * el2 / n2,
-                     "dtype": workload_dtype(name)}
-            if name in ("fm_wide_d128", "fm_criteo_sharded"):
-                r2 = unique_fraction(w2["batches"], w2["dims"])
-                b2 = embedding_bytes_per_sample(w2["desc"], r2)
-                entry["embedding_hbm_frac"] = b2 * entry["samples_per_s"] / 1e9 / HBM_PEAK_GBS
-                entry["distinct_row_fraction"] = r2
-            if name == "deepfm_wide_d128_sharded":
-                entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"],
-                             role="the 1 B-row x 128 DeepFM as named, one rank's share (125 M rows, tower 3344-3344-1672-836-1)")
-            if name == "fm_criteo_sharded":
-                # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
-                entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")
-            fl = dense_flops_per_sample(name)
-            if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
-                entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12
-            out["other_workloads"].append(entry)
-            del w2
-            torch.cuda.empty_cache()
+        # every further workload in a process of its own: a crash or a hang there costs that entry, not the line
+        out["other_workloads"] = [extra_entry(name, device, clip, run) if args.extras_in_process else extra_in_child(name, args)
+                                  for name in extras]
 
     if rank == 0 and world == 1 and args.workload == "fm_criteo" and os.environ.get("RX_BENCH_BATCHES") is None:
         # the same workload cycling over 10 resident batches (the round-1 protocol): the rows a round

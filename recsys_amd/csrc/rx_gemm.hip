@@ -56,15 +56,19 @@ __device__ __forceinline__ void load4(const float* p, int64_t stride_unused, int
   }
 }
 
-template <bool A_KC, bool B_KC, int BM, int BN, int WAVES_M, int WAVES_N>
+// BK: k extent staged per iteration.  The loop is single-buffered (load, barrier, multiply, barrier), so
+// every iteration costs a full trip to memory; skinny products (K <= 128: the ML-1M towers, and every
+// 128-row weight-gradient slab) take BK = 64, i.e. one or two trips instead of four or eight, with all
+// of a trip's loads in flight together.  Products are accumulated in ascending k whatever BK is: same bits.
+template <bool A_KC, bool B_KC, int BM, int BN, int WAVES_M, int WAVES_N, int BK = GEMM_BK>
 __global__ void __launch_bounds__(RX_BLOCK)
 gemm_f32_kernel(GemmArgs g) {
   constexpr int TM = BM / (32 * WAVES_M);
   constexpr int TN = BN / (32 * WAVES_N);
   constexpr int LDA = BM + GEMM_PAD;
   constexpr int LDB = BN + GEMM_PAD;
-  __shared__ __attribute__((aligned(16))) float As[GEMM_BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,10 +90,10 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += GEMM_BK) {
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
     // ---- stage A tile [BM x BK] -> As[k][i]
     if (A_KC) {
-      constexpr int TPR = GEMM_BK / 4;          // threads per row
+      constexpr int TPR = BK / 4;          // threads per row
       constexpr int RPP = RX_BLOCK / TPR;       // rows per pass
       const int kq = (tid % TPR) * 4;
 #pragma unroll
@@ -105,7 +109,7 @@ gemm_f32_kernel(GemmArgs g) {
       constexpr int KPP = RX_BLOCK / TPR;       // k-rows per pass
       const int iq = (tid % TPR) * 4;
 #pragma unroll
-      for (int kk = tid / TPR; kk < GEMM_BK; kk += KPP) {
+      for (int kk = tid / TPR; kk < BK; kk += KPP) {
         const int64_t k = k0 + kk;
         float v[4];
         load4(g.A + k * g.a_cs + (m0 + iq), 0, m0 + iq, g.M, k < k_end, g.a_vec, v);
@@ -114,7 +118,7 @@ gemm_f32_kernel(GemmArgs g) {
     }
     // ---- stage B tile [BK x BN] -> Bs[k][j]
     if (B_KC) {
-      constexpr int TPR = GEMM_BK / 4;
+      constexpr int TPR = BK / 4;
       constexpr int RPP = RX_BLOCK / TPR;
       const int kq = (tid % TPR) * 4;
 #pragma unroll
@@ -130,7 +134,7 @@ gemm_f32_kernel(GemmArgs g) {
       constexpr int KPP = RX_BLOCK / TPR;
       const int jq = (tid % TPR) * 4;
 #pragma unroll
-      for (int kk = tid / TPR; kk < GEMM_BK; kk += KPP) {
+      for (int kk = tid / TPR; kk < BK; kk += KPP) {
         const int64_t k = k0 + kk;
         float v[4];
         load4(g.B + k * g.b_rs + (n0 + jq), 0, n0 + jq, g.N, k < k_end, g.b_vec, v);
@@ -141,7 +145,7 @@ gemm_f32_kernel(GemmArgs g) {
     // ---- 8 k-pairs of 32x32x2 MFMAs
     const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int kk = 0; kk < GEMM_BK; kk += 2) {
+    for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = As[(kk + h) * LDA + (wave_m * TM + i) * 32 + l31];
@@ -801,6 +805,24 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
     else                                                                                                \
       hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, BM_, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g);  \
   } while (0)
+  // skinny fp32 products: the same tiles with 64 k per trip to memory (see gemm_f32_kernel); RX_GEMM_BK16=1
+  // in the environment keeps 16 (A/B timing)
+  static const bool bk16 = [] { const char* e = getenv("RX_GEMM_BK16"); return e && e[0] == '1'; }();
+  if (skinny && !bk16 && g.k_per_slab >= 64) {
+#define RX_GEMM_DEEP(BM_, BN_, WM_, WN_)                                                               \
+  do {                                                                                                  \
+    g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
+    const int64_t blocks = rx_cdiv(g.M, BM_) * g.tiles_n;                                               \
+    RX_REQUIRE(blocks < (1ll << 31), "gemm: grid too large");                                           \
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, BM_, BN_, WM_, WN_, 64>), dim3((unsigned)blocks, 1, (unsigned)n_slabs), dim3(RX_BLOCK), 0, st, g); \
+  } while (0)
+    if (g.N <= 32) RX_GEMM_DEEP(128, 32, 4, 1);
+    else if (g.N <= 64) RX_GEMM_DEEP(64, 64, 2, 2);
+    else RX_GEMM_DEEP(64, 128, 2, 2);
+#undef RX_GEMM_DEEP
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   if (g.N <= 32) RX_GEMM_GO(128, 32, 4, 1);
   else if (g.N <= 64 && !bf16) RX_GEMM_GO(64, 64, 2, 2);   // fwd 128->64 at M = 40960: 23.0 -> 15.7 us
   else if (g.N <= 64) RX_GEMM_GO(128, 64, 2, 2);

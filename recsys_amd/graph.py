@@ -196,8 +196,8 @@ class GraphedTrainStep:
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
+                fork = torch.cuda.Stream(device=dev)     # one side stream for all steps of the recording
                 for s in order:
-                    fork = torch.cuda.Stream(device=dev)
                     fork.wait_stream(main)       # behind the hand-over that refilled batch 1 - s
                     with torch.cuda.stream(fork):
                         self.model.prepare(prepared[1 - s], out=prepared[1 - s])

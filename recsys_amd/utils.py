@@ -99,6 +99,7 @@ class LoopGraph:
         # run_epoch: static epoch tensors, its own recording, device-side cursor / running loss
         self.epoch, self.epoch_slot, self.epoch_shape = None, None, None
         self.cursor = self.ticket = self.running = None
+        self.paired = False
 
     def run_epoch(self, model, optimizer, loader, clip_norm):
         """One pass over ``loader`` (a dataset.EpochLoader on the GPU); returns the sum of the batch
@@ -128,22 +129,37 @@ class LoopGraph:
             i += 1
         if i < n_full:
             if self.epoch_slot is None:
-                # two static batches take turns: while the step runs on one, the index preparation (sort,
-                # dedup) of the other, which already holds the next batch, runs beside it; the step's
-                # hand-over then refills its own batch with the batch after next
                 optimizer.clip_norm = clip_norm
-                pair = [{k: v.clone() for k, v in cut(i).items()} for _ in range(2)]
-                hand_over = [(lambda loss, b=b: ops.epoch_advance(self.epoch, b, n_full, self.cursor, self.ticket,
-                                                                  loss.detach(), self.running, ahead=2)) for b in pair]
-                self.epoch_slot = self.step.add_pair(pair, hand_over)   # records, executes nothing
-            s0, s1 = self.epoch_slot
-            self.step.copy_batch(s0, cut(i))
-            if i + 1 < n_full:
-                self.step.copy_batch(s1, cut(i + 1))
-            self.step.refresh_prepared(0)
+                # Two static batches that take turns -- while the step runs on one, the index preparation
+                # (sort, dedup) of the other, which already holds the next batch, runs beside it on a forked
+                # stream, and the step's hand-over refills its own batch with the batch after next -- for
+                # models whose step is one chain of launches.  A model that already runs a branch of its own
+                # on a second stream (NeuMF's GMF half) keeps ONE static batch and one plain graph per step:
+                # graphs with a third concurrent branch have crashed the HIP runtime in hipGraphLaunch here
+                # (intermittently, on replay), so they are not recorded.
+                self.paired = not getattr(model, "_branch_streams", False)
+                if self.paired:
+                    pair = [{k: v.clone() for k, v in cut(i).items()} for _ in range(2)]
+                    hand_over = [(lambda loss, b=b: ops.epoch_advance(self.epoch, b, n_full, self.cursor, self.ticket,
+                                                                      loss.detach(), self.running, ahead=2)) for b in pair]
+                    self.epoch_slot = tuple(self.step.add_pair(pair, hand_over))   # records; runs only the index preparation
+                else:
+                    batch = {k: v.clone() for k, v in cut(i).items()}
+                    hand_over = lambda loss: ops.epoch_advance(self.epoch, batch, n_full, self.cursor, self.ticket,
+                                                               loss.detach(), self.running)
+                    self.epoch_slot = (self.step.add_batch(batch, epilogue=hand_over),)   # records, executes nothing
+            self.step.copy_batch(self.epoch_slot[0], cut(i))
+            if self.paired:
+                if i + 1 < n_full:
+                    self.step.copy_batch(self.epoch_slot[1], cut(i + 1))
+                self.step.refresh_prepared(0)
             self.cursor.fill_(i)
             self.running.copy_(running.reshape(1))
-            self.step.run_pair_steps(n_full - i)
+            if self.paired:
+                self.step.run_pair_steps(n_full - i)
+            else:
+                for _ in range(n_full - i):
+                    self.step(self.epoch_slot[0])
             running = self.running[0].clone()
         if n % B:
             running += train_step(model, optimizer, {k: v[n_full * B:] for k, v in self.epoch.items()}, clip_norm)

@@ -675,8 +675,9 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
             ops.set_index_check("sync")
         if graphed:
             assert (step.epoch_slot if feed == "loader" else step.slot) is not None
-            assert len(step.step.graphs) == (2 if feed == "loader" else 1)     # the loader path alternates two static batches
-            assert feed != "loader" or step.step._pair_multi[1] == 8            # ... and replays eight steps per launch
+            paired = feed == "loader" and name != "NeuMF"     # two static batches take turns; not for the two-stream model
+            assert len(step.step.graphs) == (2 if paired else 1) and step.paired == paired
+            assert not paired or step.step._pair_multi[1] == 8                  # ... and eight steps replay per launch
             if feed == "loader":
                 assert int(step.cursor.item()) == len(dl) - (1 if dl.length % dl.batch_size else 0)
                 assert int(step.ticket.item()) == 0
