@@ -91,6 +91,50 @@ gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
+    if constexpr (BK > GEMM_BK) {
+      // Deep steps (aligned operands only, checked by the launcher): every 16-byte piece of both tiles is
+      // loaded first -- from a clamped address, without a branch, so that all loads of the trip are in
+      // flight together -- and only then zeroed where it lies outside the matrix and written to LDS.
+      // (The guarded loads below sit in branches of their own and therefore wait for one another.)
+      constexpr int A_TPR = A_KC ? BK / 4 : BM / 4, A_PP = RX_BLOCK / A_TPR, A_NP = (A_KC ? BM : BK) / A_PP;
+      constexpr int B_TPR = B_KC ? BK / 4 : BN / 4, B_PP = RX_BLOCK / B_TPR, B_NP = (B_KC ? BN : BK) / B_PP;
+      static_assert(A_NP >= 1 && B_NP >= 1 && A_NP <= 16 && B_NP <= 16, "tile does not divide over the block");
+      float4 va[A_NP], vb[B_NP];
+      unsigned oka = 0u, okb = 0u;
+      const int aq = (tid % A_TPR) * 4, bq = (tid % B_TPR) * 4;
+#pragma unroll
+      for (int p = 0; p < A_NP; ++p) {
+        const int o = tid / A_TPR + A_PP * p;                 // row of the tile (A_KC) or k-row
+        const int64_t row = A_KC ? m0 + o : m0 + aq, k = A_KC ? k0 + aq : k0 + o;
+        const bool ok = (A_KC ? (row < g.M && k + 3 < k_end) : (k < k_end && row + 3 < g.M));
+        const float* src = A_KC ? g.A + (ok ? row : 0) * g.a_rs + (ok ? k : 0) : g.A + (ok ? k : 0) * g.a_cs + (ok ? row : 0);
+        va[p] = *reinterpret_cast<const float4*>(src);
+        oka |= (ok ? 1u : 0u) << p;
+      }
+#pragma unroll
+      for (int p = 0; p < B_NP; ++p) {
+        const int o = tid / B_TPR + B_PP * p;
+        const int64_t col = B_KC ? n0 + o : n0 + bq, k = B_KC ? k0 + bq : k0 + o;
+        const bool ok = (B_KC ? (col < g.N && k + 3 < k_end) : (k < k_end && col + 3 < g.N));
+        const float* src = B_KC ? g.B + (ok ? col : 0) * g.b_cs + (ok ? k : 0) : g.B + (ok ? k : 0) * g.b_rs + (ok ? col : 0);
+        vb[p] = *reinterpret_cast<const float4*>(src);
+        okb |= (ok ? 1u : 0u) << p;
+      }
+#pragma unroll
+      for (int p = 0; p < A_NP; ++p) {
+        const int o = tid / A_TPR + A_PP * p;
+        const float4 v = ((oka >> p) & 1u) ? va[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (A_KC) { As[(aq + 0) * LDA + o] = v.x; As[(aq + 1) * LDA + o] = v.y; As[(aq + 2) * LDA + o] = v.z; As[(aq + 3) * LDA + o] = v.w; }
+        else *reinterpret_cast<float4*>(&As[o * LDA + aq]) = v;
+      }
+#pragma unroll
+      for (int p = 0; p < B_NP; ++p) {
+        const int o = tid / B_TPR + B_PP * p;
+        const float4 v = ((okb >> p) & 1u) ? vb[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (B_KC) { Bs[(bq + 0) * LDB + o] = v.x; Bs[(bq + 1) * LDB + o] = v.y; Bs[(bq + 2) * LDB + o] = v.z; Bs[(bq + 3) * LDB + o] = v.w; }
+        else *reinterpret_cast<float4*>(&Bs[o * LDB + bq]) = v;
+      }
+    } else {
     // ---- stage A tile [BM x BK] -> As[k][i]
     if (A_KC) {
       constexpr int TPR = BK / 4;          // threads per row
@@ -141,8 +185,9 @@ gemm_f32_kernel(GemmArgs g) {
         *reinterpret_cast<float4*>(&Bs[kk * LDB + jq]) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
+    }
     __syncthreads();
-    // ---- 8 k-pairs of 32x32x2 MFMAs
+    // ---- BK / 2 k-pairs of 32x32x2 MFMAs
     const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -808,7 +853,12 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
   // skinny fp32 products: the same tiles with 64 k per trip to memory (see gemm_f32_kernel); RX_GEMM_BK16=1
   // in the environment keeps 16 (A/B timing)
   static const bool bk16 = [] { const char* e = getenv("RX_GEMM_BK16"); return e && e[0] == '1'; }();
-  if (skinny && !bk16 && g.k_per_slab >= 64) {
+  // (whole 16-byte pieces only: aligned operands, K and the contiguous extents multiples of 4)
+  const bool whole4 = g.a_vec && g.b_vec && g.K % 4 == 0 && g.k_per_slab % 4 == 0 && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
+  // measured on the ML-1M tower shapes (M = 40960): the weight-gradient slabs gain 10 % (34.7 -> 30.9 us at
+  // 128 -> 64), the forward and input-gradient products lose as much (their K-contiguous tiles are
+  // transposed into LDS float by float), so only products with both operands contiguous along the output take it
+  if (skinny && !bk16 && g.k_per_slab >= 64 && whole4 && !A_KC && !B_KC) {
 #define RX_GEMM_DEEP(BM_, BN_, WM_, WN_)                                                               \
   do {                                                                                                  \
     g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
