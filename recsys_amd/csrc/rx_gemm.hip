@@ -65,8 +65,11 @@ __global__ void __launch_bounds__(RX_BLOCK)
 gemm_f32_kernel(GemmArgs g) {
   constexpr int TM = BM / (32 * WAVES_M);
   constexpr int TN = BN / (32 * WAVES_N);
-  constexpr int LDA = BM + GEMM_PAD;
-  constexpr int LDB = BN + GEMM_PAD;
+  // k-major LDS tiles.  A K-contiguous operand is transposed on its way in (four scalar stores per 16-byte
+  // piece): with 16 threads along k (deep steps) a row pitch of 1 mod 16 floats spreads a wavefront's
+  // stores over all 64 banks; tiles stored as whole 16-byte pieces need a pitch that is a multiple of 4
+  constexpr int LDA = BM + ((A_KC && BK > GEMM_BK) ? 1 : GEMM_PAD);
+  constexpr int LDB = BN + ((B_KC && BK > GEMM_BK) ? 1 : GEMM_PAD);
   __shared__ __attribute__((aligned(16))) float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
 
@@ -855,10 +858,10 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
   static const bool bk16 = [] { const char* e = getenv("RX_GEMM_BK16"); return e && e[0] == '1'; }();
   // (whole 16-byte pieces only: aligned operands, K and the contiguous extents multiples of 4)
   const bool whole4 = g.a_vec && g.b_vec && g.K % 4 == 0 && g.k_per_slab % 4 == 0 && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
-  // measured on the ML-1M tower shapes (M = 40960): the weight-gradient slabs gain 10 % (34.7 -> 30.9 us at
-  // 128 -> 64), the forward and input-gradient products lose as much (their K-contiguous tiles are
-  // transposed into LDS float by float), so only products with both operands contiguous along the output take it
-  if (skinny && !bk16 && g.k_per_slab >= 64 && whole4 && !A_KC && !B_KC) {
+  // measured on the ML-1M tower shapes (M = 40960, 128 -> 64): weight-gradient slabs 34.7 -> 30.8 us, forward
+  // 15.8 -> 14.6, input gradient 19.0 -> 18.2 (the last two only with the bank-conflict-free pitch of their
+  // transposed tiles; with the common pitch they lost 2 us)
+  if (skinny && !bk16 && g.k_per_slab >= 64 && whole4) {
 #define RX_GEMM_DEEP(BM_, BN_, WM_, WN_)                                                               \
   do {                                                                                                  \
     g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
