@@ -1081,7 +1081,11 @@ static int bwd_w_slabs(int64_t M, int32_t N, int32_t K) {
   // enough slabs to put >= ~768 blocks (three per CU) on the chip, each slab a multiple of the k-step
   const int64_t tiles = rx_cdiv(N, 128) * rx_cdiv(K, (K <= 32 ? 32 : (K <= 64 ? 64 : 128)));
   int64_t want = rx_cdiv(768, tiles);
-  int64_t max_by_rows = rx_cdiv(M, 128);   // 128-row slabs: 64-row ones cost more in the slab sum than they gain
+  static const int slab_rows = [] { const char* e = getenv("RX_BWDW_SLAB_ROWS"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 192; }();
+  // rows per slab where the row count caps the slab count (one-tile products of the ML-1M towers): 64-row slabs
+  // cost more in the slab sum than they gain; with 64-k trips 192 rows (three trips) edge out 128 and 256
+  // (NeuMF step 0.271 / 0.267 / 0.270 ms at 128 / 192 / 256); RX_BWDW_SLAB_ROWS overrides
+  int64_t max_by_rows = rx_cdiv(M, slab_rows);
   if (want > max_by_rows) want = max_by_rows;
   if (want < 1) want = 1;
   if (want > 1024) want = 1024;
