@@ -33,6 +33,8 @@ struct GemmArgs {
   int64_t c_slab_stride;               // C offset per blockIdx.z
   int a_vec, b_vec;                    // 16-byte global loads are legal for this operand
   int tiles_n;
+  float* colsum;                       // deep-step kernels with an M-contiguous A only: [slab][M] sums of A over the slab's k
+                                       // range (the bias gradient of a weight-gradient product, from the dY tiles it stages)
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
@@ -93,6 +95,7 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // this thread's share of the column sums of A (deep steps, M-contiguous A)
   for (int64_t k0 = k_begin; k0 < k_end; k0 += BK) {
     if constexpr (BK > GEMM_BK) {
       // Deep steps (aligned operands only, checked by the launcher): every 16-byte piece of both tiles is
@@ -105,6 +108,7 @@ gemm_f32_kernel(GemmArgs g) {
       float4 va[A_NP], vb[B_NP];
       unsigned oka = 0u, okb = 0u;
       const int aq = (tid % A_TPR) * 4, bq = (tid % B_TPR) * 4;
+      (void)aq; (void)bq;
 #pragma unroll
       for (int p = 0; p < A_NP; ++p) {
         const int o = tid / A_TPR + A_PP * p;                 // row of the tile (A_KC) or k-row
@@ -127,6 +131,7 @@ gemm_f32_kernel(GemmArgs g) {
       for (int p = 0; p < A_NP; ++p) {
         const int o = tid / A_TPR + A_PP * p;
         const float4 v = ((oka >> p) & 1u) ? va[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!A_KC) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }   // k ascending per thread
         if constexpr (A_KC) { As[(aq + 0) * LDA + o] = v.x; As[(aq + 1) * LDA + o] = v.y; As[(aq + 2) * LDA + o] = v.z; As[(aq + 3) * LDA + o] = v.w; }
         else *reinterpret_cast<float4*>(&As[o * LDA + aq]) = v;
       }
@@ -205,6 +210,23 @@ gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+  }
+
+  if constexpr (BK > GEMM_BK && !A_KC) {
+    // column sums of A over this slab (block-uniform condition; the K loop ended with a barrier, so the A
+    // tile's LDS is free): the threads that staged one 16-byte column piece add up in thread order
+    if (g.colsum && tile_n == 0) {
+      constexpr int A_TPR = BM / 4, A_PP = RX_BLOCK / A_TPR;
+      const int aq = (tid % A_TPR) * 4;
+      *reinterpret_cast<float4*>(&As[(tid / A_TPR) * BM + aq]) = csum;
+      __syncthreads();
+      if (tid < BM && m0 + tid < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < A_PP; ++q) t += As[q * BM + tid];
+        g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = t;
+      }
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -812,6 +834,15 @@ static bool pipe_ok_f32(const GemmArgs& g) {
   return true;
 }
 
+// Whether gemm_launch sends this fp32 product to the deep-step (64 k per trip) tiles of gemm_f32_kernel.
+static bool gemm_deep_f32(const GemmArgs& g, int bf16, bool a_kc, bool b_kc) {
+  static const bool bk16 = [] { const char* e = getenv("RX_GEMM_BK16"); return e && e[0] == '1'; }();   // A/B timing: keep 16-k steps
+  const bool skinny = !bf16 && g.N <= 128 && (g.k_per_slab <= 128 || g.M <= 64);
+  // whole 16-byte pieces only: aligned operands, K and the contiguous extents multiples of 4
+  const bool whole4 = g.a_vec && g.b_vec && g.K % 4 == 0 && g.k_per_slab % 4 == 0 && (a_kc || g.M % 4 == 0) && (b_kc || g.N % 4 == 0);
+  return skinny && !bk16 && g.k_per_slab >= 64 && whole4;
+}
+
 template <bool A_KC, bool B_KC>
 static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
   const int64_t tiles_m = rx_cdiv(g.M, 128);
@@ -853,15 +884,11 @@ static int gemm_launch(GemmArgs& g, int n_slabs, int bf16, hipStream_t st) {
     else                                                                                                \
       hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, BM_, BN_, WM_, WN_>), grid, dim3(RX_BLOCK), 0, st, g);  \
   } while (0)
-  // skinny fp32 products: the same tiles with 64 k per trip to memory (see gemm_f32_kernel); RX_GEMM_BK16=1
-  // in the environment keeps 16 (A/B timing)
-  static const bool bk16 = [] { const char* e = getenv("RX_GEMM_BK16"); return e && e[0] == '1'; }();
-  // (whole 16-byte pieces only: aligned operands, K and the contiguous extents multiples of 4)
-  const bool whole4 = g.a_vec && g.b_vec && g.K % 4 == 0 && g.k_per_slab % 4 == 0 && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
+  // skinny fp32 products: the same tiles with 64 k per trip to memory (see gemm_f32_kernel);
   // measured on the ML-1M tower shapes (M = 40960, 128 -> 64): weight-gradient slabs 34.7 -> 30.8 us, forward
   // 15.8 -> 14.6, input gradient 19.0 -> 18.2 (the last two only with the bank-conflict-free pitch of their
   // transposed tiles; with the common pitch they lost 2 us)
-  if (skinny && !bk16 && g.k_per_slab >= 64 && whole4) {
+  if (gemm_deep_f32(g, bf16, A_KC, B_KC)) {
 #define RX_GEMM_DEEP(BM_, BN_, WM_, WN_)                                                               \
   do {                                                                                                  \
     g.tiles_n = (int)rx_cdiv(g.N, BN_);                                                                 \
@@ -1130,8 +1157,18 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   g.M = N; g.N = K; g.K = M; g.act = 0; g.accumulate = 0;
   g.k_per_slab = rows_per_slab; g.c_slab_stride = (int64_t)N * K;
   g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(X, ldx);
+  // the deep-step kernel sums the columns of the dY tiles it stages: the bias gradient's partials come out of
+  // the product's own launch, one per weight-gradient slab
+  const bool fused_bias = db && gemm_deep_f32(g, bf16, false, false);
+  if (fused_bias) g.colsum = bpart;
   if (gemm_launch<false, false>(g, n_slabs, bf16, st)) return 1;
   const int64_t nk = (int64_t)N * K;
+  if (fused_bias) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv(nk, 64) + rx_cdiv(N, 64))), dim3(RX_BLOCK), 0, st, slabs, nk,
+                       n_slabs, dW, (const float*)bpart, (int64_t)N, n_slabs, db);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   if (!db) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(nk, 64)), dim3(RX_BLOCK), 0, st, slabs, nk, n_slabs, dW,
                        (const float*)nullptr, (int64_t)0, 0, (float*)nullptr);
