@@ -517,6 +517,12 @@ int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int64_t ldx, f
                     float* db, int64_t M, int32_t N, int32_t K, int bf16, void* ws,
                     size_t ws_bytes, int device, void* stream);
 int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int device, void* stream);
+/* Backward of the pair ReLU + Dropout of the ReLU towers (recsys/models/neuralcf/mlp.py:27-36,
+ * neumf.py:36-45: nn.Linear, nn.ReLU, nn.Dropout) from the pair's OUTPUT alone:
+ * dZ = Y > 0 ? dY * scale : 0 with scale = 1 / (1 - p) -- Y is positive exactly where the ReLU was open
+ * and the element was kept, so neither the keep mask nor the ReLU's own output has to be stored. */
+int rx_relu_bwd_scaled(const float* dY, const float* Y, float* dZ, int64_t n, float scale, int device,
+                       void* stream);
 
 /* ---- BatchNorm1d of the reference's BN towers, fused with the ReLU and Dropout that follow it
  * (widendeep.py:6-24 and deep_factorization_machine.py:6-24: Linear, BatchNorm1d, ReLU,

@@ -155,6 +155,7 @@ PROTOTYPES = {
     "rx_linear_bwd_w_workspace_bytes": (sz, [i64, i32, i32]),
     "rx_linear_bwd_w": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, i32, i32, C.c_int, vp, sz, C.c_int, vp]),
     "rx_relu_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "rx_relu_bwd_scaled": (C.c_int, [vp, vp, vp, i64, f32, C.c_int, vp]),
     "rx_cross_combine_fwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_cross_combine_bwd": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, vp]),
     "rx_cross_combine_bwd_stack": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i64, i32, C.c_int, C.c_int,

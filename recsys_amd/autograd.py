@@ -474,18 +474,31 @@ class GMFMul(Function):
 
 # ------------------------------------------------------------------ Linear (+ReLU) on the matrix cores
 class LinearAct(Function):
+    """Linear (+ ReLU (+ Dropout)).  ``drop_p`` > 0: the Dropout behind a Linear + ReLU.  Its forward is
+    torch's own fused dropout (one vectorised pass, mask from torch's generator, safe under graph
+    capture); its backward is folded into the ReLU's: the pair's output is positive exactly where the
+    ReLU was open and the element kept, so one pass ``dz = y > 0 ? dy / (1 - p) : 0`` over the saved output
+    replaces the masked scaling and the ReLU backward, and neither the mask nor the ReLU's own output
+    is kept.  (Applying a keep mask in the product's epilogue was measured too: drawing the mask as a
+    tensor costs more than the fused dropout pass it replaces.)"""
+
     @staticmethod
-    def forward(ctx, x, w, b, act, bf16):
+    def forward(ctx, x, w, b, act, bf16, drop_p=0.0):
+        if drop_p and not act:
+            raise ValueError("the fused dropout comes with the ReLU in front of it")
         y = ops.linear_fwd(x, w, b, act, bf16)
+        if drop_p:
+            y = torch.nn.functional.dropout(y, float(drop_p), True)
         ctx.save_for_backward(x, w, y if act else None)
         ctx.act, ctx.bf16, ctx.has_b = act, bf16, b is not None
+        ctx.scale = 1.0 / (1.0 - float(drop_p)) if drop_p else 1.0
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         if ctx.act:
-            dy = ops.relu_bwd(dy.contiguous(), y)
+            dy = ops.relu_bwd(dy.contiguous(), y, ctx.scale)
         elif not (dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0):
             # (a column block of a wider gradient -- the backward of torch.cat -- is read in place:
             # the products take a row stride)
@@ -494,11 +507,11 @@ class LinearAct(Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dw, db = ops.linear_bwd_w(dy, x, ctx.has_b, ctx.bf16)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool = False, bf16: bool = False) -> Tensor:
-    return LinearAct.apply(x, w, b, 1 if relu else 0, bf16)
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool = False, bf16: bool = False, drop_p: float = 0.0) -> Tensor:
+    return LinearAct.apply(x, w, b, 1 if relu else 0, bf16, drop_p)
 
 
 # ------------------------------------------------------------------ DCN-v2 cross layer

@@ -1197,6 +1197,24 @@ relu_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float
     dZ[i] = Y[i] > 0.f ? dY[i] : 0.f;
 }
 
+__global__ void __launch_bounds__(RX_BLOCK)
+relu_bwd_scaled_kernel(const float* __restrict__ dY, const float* __restrict__ Y, float* __restrict__ dZ, int64_t n, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dZ[i] = Y[i] > 0.f ? dY[i] * scale : 0.f;
+}
+
+extern "C" int rx_relu_bwd_scaled(const float* dY, const float* Y, float* dZ, int64_t n, float scale, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n >= 0, "rx_relu_bwd_scaled: negative size");
+  if (n == 0) return 0;
+  RX_REQUIRE(dY && Y && dZ, "rx_relu_bwd_scaled: null argument");
+  int64_t grid = rx_cdiv(n, RX_BLOCK * 4);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(relu_bwd_scaled_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, dY, Y, dZ, n, scale);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int rx_relu_bwd(const float* dY, const float* Y, float* dZ, int64_t n, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0, "rx_relu_bwd: bad n");

@@ -91,8 +91,19 @@ def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = N
         m = mods[i]
         if isinstance(m, nn.Linear):
             fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-            x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16)
-            i += 2 if fuse else 1
+            drop = mods[i + 2] if fuse and i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout) else None
+            if drop is not None and x.is_cuda and x.dim() == 2 and (not drop.training or drop.p == 0.0):
+                x = rxa.linear(x, m.weight, m.bias, relu=True, bf16=bf16)        # an idle Dropout is the identity
+                i += 3
+            elif (drop is not None and x.is_cuda and x.dim() == 2 and 0.0 < drop.p < 1.0 and not drop.inplace
+                  and os.environ.get("RX_NO_FUSED_DROPOUT") != "1"):
+                # Linear + ReLU + Dropout as one node: torch's fused dropout forward, and one backward pass over
+                # the pair's output instead of a masked scaling plus a ReLU backward (autograd.LinearAct)
+                x = rxa.linear(x, m.weight, m.bias, relu=True, bf16=bf16, drop_p=float(drop.p))
+                i += 3
+            else:
+                x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16)
+                i += 2 if fuse else 1
         elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2 and m.affine:
             j = i + 1
             relu = j < len(mods) and isinstance(mods[j], nn.ReLU)

@@ -986,10 +986,17 @@ def linear_bwd_w(dy: Tensor, x: Tensor, want_bias: bool = True, bf16: bool = Fal
     return dw, db
 
 
-def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
+def relu_bwd(dy: Tensor, y: Tensor, scale: float = 1.0) -> Tensor:
+    """dz = y > 0 ? dy * scale : 0.  ``scale`` != 1: backward of ReLU + Dropout from the pair's output
+    ``y`` (positive exactly where the ReLU was open and the element kept), scale = 1 / (1 - p)."""
     _req(dy, torch.float32, "dy"); _req(y, torch.float32, "y")
+    if dy.numel() != y.numel():
+        raise ValueError("relu_bwd: dy and y differ in size")
     dz = torch.empty_like(dy)
-    check(lib.rx_relu_bwd(_p(dy), _p(y), _p(dz), dy.numel(), _dev(dy), _stream(dy)), "rx_relu_bwd")
+    if scale != 1.0:
+        check(lib.rx_relu_bwd_scaled(_p(dy), _p(y), _p(dz), dy.numel(), float(scale), _dev(dy), _stream(dy)), "rx_relu_bwd_scaled")
+    else:
+        check(lib.rx_relu_bwd(_p(dy), _p(y), _p(dz), dy.numel(), _dev(dy), _stream(dy)), "rx_relu_bwd")
     return dz
 
 

@@ -829,3 +829,67 @@ def test_cross16_layer_in_one_launch_equals_product_then_combine(ops, M, d):
     u2 = ops.linear16_fwd(x16, w, b, relu=False, out_bf16=False)
     xn2, xn216 = ops.cross16_fwd(x0, u2, xl)
     assert torch.equal(u, u2) and torch.equal(xn, xn2) and torch.equal(xn16, xn216)
+
+
+# ------------------------------------------------------------------ Linear + ReLU + Dropout in one launch
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 64, 128), (300, 24, 40), (3000, 432, 432)])
+def test_linear_relu_dropout_node_matches_torch_composite(ops, M, N, K):
+    """autograd.LinearAct with a dropout rate: torch's dropout forward on the fused Linear + ReLU, and ONE
+    backward pass over the pair's output.  Reseeding reproduces the mask: output and the gradients of
+    x, W, b against the same expression in torch ops."""
+    from recsys_amd import autograd as rxa
+    g = _gen(M + N)
+    p = 0.3
+    x = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(N, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn(M, N, generator=g).cuda()
+    torch.manual_seed(77)
+    y = rxa.linear(x, w, b, relu=True, drop_p=p)
+    y.backward(dy)
+    got = [y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    for t in (x, w, b):
+        t.grad = None
+    torch.manual_seed(77)
+    ref = torch.nn.functional.dropout(torch.relu(torch.nn.functional.linear(x, w, b)), p, True)
+    ref.backward(dy)
+    assert_close(_np(got[0]), _np(ref), rtol=1e-5, what="dropout node output")
+    assert int(((got[0] == 0) != (ref.detach() == 0)).sum()) <= (M * N) // 1000     # a pre-activation within rounding of zero may flip
+    assert 0.55 < float((got[0] == 0).float().mean()) < 0.75                          # half closed by the ReLU, 30 % of the rest dropped
+    assert_close(_np(got[1]), _np(x.grad), rtol=1e-4, what="dropout node grad x")
+    assert_close(_np(got[2]), _np(w.grad), rtol=1e-4, what="dropout node grad w")
+    assert_close(_np(got[3]), _np(b.grad), rtol=1e-4, what="dropout node grad b")
+
+
+def test_mlp_tower_under_dropout_matches_composite(ops):
+    """The MLP model in training mode (Linear-ReLU-Dropout twice, p = 0.5): the masks come from torch's device
+    generator in layer order, so reseeding reproduces them; logits and the tower's weight gradients equal
+    the composite of torch ops.  In eval mode the Dropouts are idle."""
+    from recsys_amd.models.neuralcf import MLP
+    torch.manual_seed(0)
+    m = MLP(50, 40, 16, dropout=0.5).cuda().train()
+    users = torch.randint(0, 50, (64,)).cuda()
+    items = torch.randint(0, 40, (64, 5)).cuda()
+    batch = {"user_code": users, "item_code": items}
+    torch.manual_seed(123)
+    out = m(batch)
+    out.sum().backward()
+    torch.manual_seed(123)
+    lin = [l for l in m.mlp if isinstance(l, torch.nn.Linear)]
+    W = [l.weight.detach().clone().requires_grad_(True) for l in lin]
+    Bv = [l.bias.detach() for l in lin]
+    x = torch.cat([m.user_embedding.weight.detach()[users].repeat_interleave(5, 0), m.item_embedding.weight.detach()[items.reshape(-1)]], 1)
+    h = torch.nn.functional.dropout(torch.relu(x @ W[0].t() + Bv[0]), 0.5, True)
+    h = torch.nn.functional.dropout(torch.relu(h @ W[1].t() + Bv[1]), 0.5, True)
+    ref = (h @ W[2].t() + Bv[2]).view(64, 5)
+    ref.sum().backward()
+    assert_close(_np(out.detach()), _np(ref.detach().float()), rtol=1e-5, what="MLP logits under dropout")
+    for l, wr in zip(lin, W):
+        assert_close(_np(l.weight.grad), _np(wr.grad.float()), rtol=1e-4, what="MLP weight grad under dropout")
+    m.eval()
+    a, b2 = m(batch), m(batch)
+    assert torch.equal(a, b2)
