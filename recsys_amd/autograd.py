@@ -483,10 +483,17 @@ class LinearAct(Function):
     tensor costs more than the fused dropout pass it replaces.)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, bf16, drop_p=0.0):
+    def forward(ctx, x, w, b, act, bf16, drop_p=0.0, into=None):
+        # ``into``: a one-element list holding the [M, N] destination (e.g. a column block of the buffer a
+        # later layer reads: see JoinColumns), handed over outside autograd's view so that writing it is
+        # not recorded as an in-place change of that buffer
         if drop_p and not act:
             raise ValueError("the fused dropout comes with the ReLU in front of it")
-        y = ops.linear_fwd(x, w, b, act, bf16)
+        if into is not None and (act or drop_p):
+            raise ValueError("a destination block is for layers whose output the backward does not read")
+        y = ops.linear_fwd(x, w, b, act, bf16, out=into[0] if into is not None else None)
+        if into is not None:
+            y = y.detach()
         if drop_p:
             y = torch.nn.functional.dropout(y, float(drop_p), True)
         ctx.save_for_backward(x, w, y if act else None)
@@ -507,11 +514,40 @@ class LinearAct(Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
             dw, db = ops.linear_bwd_w(dy, x, ctx.has_b, ctx.bf16)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool = False, bf16: bool = False, drop_p: float = 0.0) -> Tensor:
-    return LinearAct.apply(x, w, b, 1 if relu else 0, bf16, drop_p)
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], relu: bool = False, bf16: bool = False, drop_p: float = 0.0,
+           into: Optional[Tensor] = None) -> Tensor:
+    return LinearAct.apply(x, w, b, 1 if relu else 0, bf16, drop_p, [into] if into is not None else None)
+
+
+class JoinColumns(Function):
+    """``torch.cat(parts, dim=1)`` without the copy: the parts were WRITTEN as column blocks of one buffer
+    by the layers that made them (``linear(..., into=block)``), so the forward only hands that buffer
+    on, and the backward hands every part its column block of the gradient, in place.  ``holder``: a
+    one-element list with the buffer; ``parts`` must tile its columns from left to right."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        col = 0
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + 4 * col or p.shape[0] != buf.shape[0] or p.stride(0) != buf.stride(0):
+                raise ValueError("JoinColumns: a part is not the next column block of the buffer")
+            col += p.shape[1]
+        if col != buf.shape[1]:
+            raise ValueError("JoinColumns: the parts do not cover the buffer")
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, d):
+        out, col = [], 0
+        for wdt in ctx.widths:
+            out.append(d[:, col:col + wdt])
+            col += wdt
+        return (None,) + tuple(out)
 
 
 # ------------------------------------------------------------------ DCN-v2 cross layer

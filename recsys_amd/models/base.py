@@ -68,14 +68,17 @@ def _relu_chain(mods):
     return mods[0::2]
 
 
-def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = None) -> Tensor:
+def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = None, into: Tensor = None) -> Tensor:
     """Evaluate a Linear/(BatchNorm1d)/ReLU/Dropout stack.  Linear (+ a directly following ReLU)
     goes through the MFMA GEMM with the ReLU fused into its epilogue; BatchNorm1d with the ReLU and
     Dropout behind it is one fused normalisation (rx_bn_*); anything else runs as the torch module.
     With ``bf16`` a pure Linear/ReLU stack of suitable widths runs as one node that keeps its
     activations in bf16 in HBM (autograd.MLPStack16; ``x16``: a bf16 copy of ``x`` if the producer
-    made one); RX_NO_BF16_STORAGE=1 keeps fp32 storage."""
+    made one); RX_NO_BF16_STORAGE=1 keeps fp32 storage.  ``into``: where a stack that ends in a plain
+    Linear writes its output (a column block of the buffer the next layer reads, autograd.JoinColumns)."""
     mods = list(seq)
+    if into is not None and (bf16 or not isinstance(mods[-1], nn.Linear)):
+        raise ValueError("run_tower: `into` is for fp32 stacks that end in a Linear")
     chain = _relu_chain(mods) if bf16 and os.environ.get("RX_NO_BF16_STORAGE") != "1" else None
     if chain is not None and rxa.h16_shapes_ok(x, [m.weight for m in chain]):
         wb = []
@@ -102,7 +105,8 @@ def run_tower(seq: nn.Sequential, x: Tensor, bf16: bool = False, x16: Tensor = N
                 x = rxa.linear(x, m.weight, m.bias, relu=True, bf16=bf16, drop_p=float(drop.p))
                 i += 3
             else:
-                x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16)
+                last = into is not None and i == len(mods) - 1
+                x = rxa.linear(x, m.weight, m.bias, relu=fuse, bf16=bf16, into=into if last else None)
                 i += 2 if fuse else 1
         elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2 and m.affine:
             j = i + 1

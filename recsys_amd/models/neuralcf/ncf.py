@@ -7,6 +7,8 @@ neumf.py:104 and neumf.py:122 do.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -155,12 +157,25 @@ class NeuMF(HotPathModule):
             raise ValueError("pointwise=True takes item_code of shape [B]")
         # the GMF half shares nothing with the MLP tower until the concatenation: it runs on a second
         # stream, forward and (autograd keeps a node on its forward stream) backward
+        x, B, N = _tower_input(users, items, self.user_embedding_mlp.weight, self.item_embedding_mlp.weight)
+        wg, wm = self.linear_gmf.weight.shape[0], self.linear_mlp[-1].weight.shape[0]
+        direct = (users.is_cuda and isinstance(self.linear_mlp[-1], nn.Linear) and wg % 4 == 0 and wm % 4 == 0
+                  and os.environ.get("RX_NEUMF_CAT") != "1")
+        if direct:
+            # the two halves write their outputs straight into the column blocks of linear_final's input:
+            # [gmf, mlp] list-wise, [mlp, gmf] point-wise (neumf.py:104, :122); no concatenation copy
+            both = torch.empty(x.shape[0], wg + wm, dtype=torch.float32, device=users.device)
+            blk_gmf, blk_mlp = (both[:, wm:], both[:, :wm]) if pointwise else (both[:, :wg], both[:, wg:])
         with rxa.Branch(users.device) as br:
             prod = rxa.GMFMul.apply(users, items, self.user_embedding_gmf.weight, self.item_embedding_gmf.weight)
-            out_gmf = rxa.linear(prod, self.linear_gmf.weight, self.linear_gmf.bias)
-        x, B, N = _tower_input(users, items, self.user_embedding_mlp.weight, self.item_embedding_mlp.weight)
-        out_mlp = run_tower(self.linear_mlp, x)
+            out_gmf = rxa.linear(prod, self.linear_gmf.weight, self.linear_gmf.bias, into=blk_gmf if direct else None)
+            if direct and br.on:
+                both.record_stream(br.side)
+        out_mlp = run_tower(self.linear_mlp, x, into=blk_mlp if direct else None)
         br.join(out_gmf)
-        both = torch.cat([out_mlp, out_gmf] if pointwise else [out_gmf, out_mlp], dim=1)
+        if direct:
+            both = rxa.JoinColumns.apply([both], *([out_mlp, out_gmf] if pointwise else [out_gmf, out_mlp]))
+        else:
+            both = torch.cat([out_mlp, out_gmf] if pointwise else [out_gmf, out_mlp], dim=1)
         out = rxa.linear(both, self.linear_final.weight, self.linear_final.bias)
         return out if pointwise else out.view(B, -1)
