@@ -45,6 +45,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// Row of flat piece index i at d pieces per row.  Streaming kernels split an index per piece; the 64-bit
+// division costs more than the piece itself, so totals below 2^31 (`small`, uniform) divide in 32 bits.
+__device__ __forceinline__ int64_t rx_row_of(int64_t i, int d, bool small) {
+  return small ? (int64_t)((uint32_t)i / (uint32_t)d) : i / d;
+}
+
 // Load 4 consecutive elements (along the contiguous axis) with bounds guards.
 __device__ __forceinline__ void load4(const float* p, int64_t stride_unused, int64_t first, int64_t limit,
                                       bool row_ok, bool vec, float out[4]) {
@@ -959,8 +965,9 @@ gemv_bwd_x_kernel(const float* __restrict__ dY, int64_t ldd, const float* __rest
                   int64_t ldx, int64_t M, int K, int accumulate) {
   const int kq = K / 4;
   const int64_t total = M * kq;
+  const bool small = total < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / kq;
+    const int64_t m = rx_row_of(i, kq, small);
     const int k0 = (int)(i - m * kq) * 4;
     const float g = dY[m * ldd];
     const float4 wv = *reinterpret_cast<const float4*>(w + k0);
@@ -1663,8 +1670,9 @@ __global__ void __launch_bounds__(RX_BLOCK)
 to_bf16_kernel(const float* __restrict__ src, int64_t lds_, uint16_t* __restrict__ dst, int64_t ldd, int64_t rows, int cols) {
   const int cq = (cols + 3) / 4;
   const int64_t total = rows * cq;
+  const bool small = total < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cq;
+    const int64_t r = rx_row_of(i, cq, small);
     const int c = (int)(i - r * cq) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -1751,8 +1759,9 @@ gemv16_bwd_x_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const float* _
   uint16_t* dZ = reinterpret_cast<uint16_t*>(dZ_);
   const int kq = (K + 7) / 8;
   const int64_t total = M * kq;
+  const bool small = total < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = i / kq;
+    const int64_t m = rx_row_of(i, kq, small);
     const int k0 = (int)(i - m * kq) * 8;
     const float gy = bf16_bits_to_f32(dY[m * ldd]);
     float wr[8];
@@ -2016,8 +2025,9 @@ cross16_fwd_kernel(const float* __restrict__ x0, int64_t ld0, const float* __res
                    const float* __restrict__ xl, int64_t ldl, float* __restrict__ xn, int64_t ldn,
                    uint16_t* __restrict__ xn16, int64_t ldn16, int64_t rows, int cq) {
   const int64_t n = rows * cq;
+  const bool small = n < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cq;
+    const int64_t r = rx_row_of(i, cq, small);
     const int c = (int)(i - r * cq) * 4;
     const float4 a = *reinterpret_cast<const float4*>(x0 + r * ld0 + c);
     const float4 b = *reinterpret_cast<const float4*>(u + r * ldu + c);
@@ -2035,8 +2045,9 @@ cross16_bwd_kernel(const float* __restrict__ dxn, int64_t ldd, const float* __re
                    float* __restrict__ dx0_acc, int64_t ldx0, float* __restrict__ dxl, int64_t ldxl,
                    int64_t rows, int cq, int accumulate, int identity) {
   const int64_t n = rows * cq;
+  const bool small = n < (1ll << 31);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cq;
+    const int64_t r = rx_row_of(i, cq, small);
     const int c = (int)(i - r * cq) * 4;
     const float4 d = *reinterpret_cast<const float4*>(dxn + r * ldd + c);
     const float4 a = *reinterpret_cast<const float4*>(x0 + r * ld0 + c);

@@ -1098,8 +1098,25 @@ multi_sumsq_kernel(rx_tensor_list t, double* __restrict__ partial) {
   const float* __restrict__ x = t.g[k];
   const int64_t n = t.n[k];
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = (double)x[i];
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  // 16-byte pieces, four of them in flight per thread (a 0.5 M-element weight matrix is 16 trips to memory
+  // per thread instead of 64 dependent ones); the elements past the last whole piece one by one
+  const int64_t n4 = (((uintptr_t)x & 15) == 0) ? n / 4 : 0;
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  int64_t i = tid;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    acc += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+    acc += ((double)b.x * b.x + (double)b.y * b.y) + ((double)b.z * b.z + (double)b.w * b.w);
+    acc += ((double)c.x * c.x + (double)c.y * c.y) + ((double)c.z * c.z + (double)c.w * c.w);
+    acc += ((double)d.x * d.x + (double)d.y * d.y) + ((double)d.z * d.z + (double)d.w * d.w);
+  }
+  for (; i < n4; i += stride) {
+    const float4 a = x4[i];
+    acc += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+  }
+  for (int64_t j = n4 * 4 + tid; j < n; j += stride) {
+    const double v = (double)x[j];
     acc += v * v;
   }
   acc = rx_wave_sum_f64(acc);
@@ -1117,15 +1134,37 @@ multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __
   float* __restrict__ s = t.state[k];
   const int64_t n = t.n[k];
   const float sc = scale ? scale[0] : 1.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i] * sc;
-    if (MODE == RX_SEG_SGD) {
-      w[i] = w[i] - lr * gi;
-    } else {
-      const float si = s[i] + gi * gi;
-      s[i] = si;
-      w[i] = w[i] - lr * (gi / (sqrtf(si) + eps));
-    }
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  auto one = [&](float wi, float gi_, float& si) {   // the rule on one element (same arithmetic whatever the access width)
+    const float gi = gi_ * sc;
+    if (MODE == RX_SEG_SGD) return wi - lr * gi;
+    si = si + gi * gi;
+    return wi - lr * (gi / (sqrtf(si) + eps));
+  };
+  // 16-byte pieces, two in flight per thread, where all of the tensor's arrays allow it
+  const bool vec = (((uintptr_t)w | (uintptr_t)g | (MODE == RX_SEG_SGD ? 0 : (uintptr_t)s)) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  float4* __restrict__ w4 = reinterpret_cast<float4*>(w);
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  float4* __restrict__ s4 = reinterpret_cast<float4*>(s);
+  auto piece = [&](int64_t i, float4 wv, float4 gv, float4 sv) {
+    wv.x = one(wv.x, gv.x, sv.x); wv.y = one(wv.y, gv.y, sv.y); wv.z = one(wv.z, gv.z, sv.z); wv.w = one(wv.w, gv.w, sv.w);
+    w4[i] = wv;
+    if (MODE != RX_SEG_SGD) s4[i] = sv;
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t i = tid;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 wa = w4[i], ga = g4[i], wb = w4[i + stride], gb = g4[i + stride];
+    const float4 sa = MODE == RX_SEG_SGD ? z4 : s4[i], sb = MODE == RX_SEG_SGD ? z4 : s4[i + stride];
+    piece(i, wa, ga, sa);
+    piece(i + stride, wb, gb, sb);
+  }
+  for (; i < n4; i += stride) piece(i, w4[i], g4[i], MODE == RX_SEG_SGD ? z4 : s4[i]);
+  for (int64_t j = n4 * 4 + tid; j < n; j += stride) {
+    float sj = MODE == RX_SEG_SGD ? 0.f : s[j];
+    w[j] = one(w[j], g[j], sj);
+    if (MODE != RX_SEG_SGD) s[j] = sj;
   }
 }
 
