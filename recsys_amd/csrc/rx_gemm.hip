@@ -45,6 +45,9 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ float round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_rne(v)); }
+
 // Row of flat piece index i at d pieces per row.  Streaming kernels split an index per piece; the 64-bit
 // division costs more than the piece itself, so totals below 2^31 (`small`, uniform) divide in 32 bits.
 __device__ __forceinline__ int64_t rx_row_of(int64_t i, int d, bool small) {
@@ -1355,6 +1358,9 @@ struct Gemm16Args {
   const float* xl; int64_t ldl;
   float* xn; int64_t ldn;
   uint16_t* xn16; int64_t ldn16;
+  // weight-gradient products (operands contiguous along the outputs): [slab][M] column sums of A over the
+  // slab's k range, formed from the A tiles the kernel stages (the layer's bias gradient), or null
+  float* colsum;
 };
 
 // Pieces in flight between a K-step's global loads and its LDS stores.  Out-of-range pieces are
@@ -1499,10 +1505,23 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
       h_load_mc(g.B, g.ldb, n0, g.N, k0, k_end, tid, rb);
     }
   };
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // !KC: this thread's 8 columns of A, summed over its k-rows
+  const bool want_colsum = !KC && g.colsum != nullptr && tile_n == 0;   // block-uniform
   auto stash = [&](int buf) {
     uint16_t* base = h_lds + buf * OP_SZ;
     if constexpr (KC) { h_store_kc(base, tid, ra); h_store_kc(base + A_SZ, tid, rb); }
-    else { h_store_mc(base, tid, ra); h_store_mc(base + A_SZ, tid, rb); }
+    else {
+      h_store_mc(base, tid, ra); h_store_mc(base + A_SZ, tid, rb);
+      if (want_colsum) {
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+          if (!((ra.ok >> p) & 1u)) continue;
+          const uint32_t xs[4] = {ra.v[p].x, ra.v[p].y, ra.v[p].z, ra.v[p].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { csum[2 * e] += bf16_bits_to_f32(xs[e] & 0xffffu); csum[2 * e + 1] += bf16_bits_to_f32(xs[e] >> 16); }
+        }
+      }
+    }
   };
 
   fetch(k_begin);
@@ -1516,6 +1535,24 @@ gemm_h16_kernel(Gemm16Args g, int swizzle) {
     if (more) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if constexpr (!KC) {
+    if (want_colsum) {
+      // the K loop ended with a barrier: the operand buffers are free.  16 k-row groups hold sums of the same
+      // 128 columns; they are added in group order
+      float* red = reinterpret_cast<float*>(h_lds);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(tid >> 4) * H_T + (tid & 15) * 8 + e] = csum[e];
+      __syncthreads();
+      if (tid < H_T && m0 + tid < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < RX_BLOCK / 16; ++q) t += red[q * H_T + tid];
+        g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = t;
+      }
+      __syncthreads();
+    }
   }
 
   // epilogue: the products were issued with the operands swapped, so an accumulator tile is C^T in the
@@ -1719,8 +1756,6 @@ extern "C" int rx_to_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64
 }
 
 // ---- one output column (the tower's last layer) with bf16 activations: K / 8 lanes of 16 bytes per row
-__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ float round_bf16(float v) { return bf16_bits_to_f32(f32_to_bf16_rne(v)); }
 
 template <int LPR>
 __global__ void __launch_bounds__(RX_BLOCK)
@@ -2004,9 +2039,14 @@ extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16
   Gemm16Args g{};
   g.A = dY16; g.lda = ldd; g.B = X16; g.ldb = ldx; g.C = slabs; g.ldc = K; g.bias = nullptr;
   g.M = N; g.N = K; g.K = M; g.act = 0; g.k_per_slab = rows_per_slab; g.c_slab_stride = nk;
+  // the bias gradient's partials come out of the product's own launch: the kernel sums the columns of the dY
+  // tiles it stages, one partial row per weight-gradient slab (RX_SEPARATE_COLSUM=1: the separate pass, A/B)
+  static const bool separate = [] { const char* e = getenv("RX_SEPARATE_COLSUM"); return e && e[0] == '1'; }();
+  const bool fused_bias = db && !separate;
+  if (fused_bias) g.colsum = bpart;
   if (gemm_h16_launch<false, false, false, false>(g, n_slabs, st)) return 1;
-  int cs = 0;
-  if (db) {
+  int cs = fused_bias ? n_slabs : 0;
+  if (db && !fused_bias) {
     int64_t cs_rows = rx_cdiv(M, COLSUM16_SLABS);
     cs_rows = rx_cdiv(cs_rows, 16) * 16;
     cs = (int)rx_cdiv(M, cs_rows);
