@@ -716,9 +716,18 @@ gemm_f32_pipe_kernel(GemmArgs g, int swizzle) {
     if constexpr (B_KC) g3_load_kc(g.B, g.b_cs, n0, g.N, k0, k_end, tid, rb);
     else g3_load_mc(g.B, g.b_rs, n0, g.N, k0, k_end, tid, rb);
   };
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);   // M-contiguous A: this thread's 4 columns of A, summed over its k-rows
+  const bool want_colsum = !A_KC && g.colsum != nullptr && tile_n == 0;   // block-uniform
   auto stash = [&](int buf) {
     if constexpr (A_KC) g3_store_kc(lds[buf], tid, ra);
-    else g3_store_mc(lds[buf], tid, ra);
+    else {
+      g3_store_mc(lds[buf], tid, ra);
+      if (want_colsum) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          if ((ra.ok >> p) & 1u) { csum.x += ra.v[p].x; csum.y += ra.v[p].y; csum.z += ra.v[p].z; csum.w += ra.v[p].w; }
+      }
+    }
     if constexpr (B_KC) g3_store_kc(lds[buf] + T_SZ, tid, rb);
     else g3_store_mc(lds[buf] + T_SZ, tid, rb);
   };
@@ -748,6 +757,21 @@ gemm_f32_pipe_kernel(GemmArgs g, int swizzle) {
     if (more) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if constexpr (!A_KC) {
+    if (want_colsum) {
+      // the K loop ended with a barrier: the tiles are free.  8 k-row groups hold sums of the same 128 columns
+      float* red = &lds[0][0];
+      *reinterpret_cast<float4*>(&red[(tid >> 5) * G2_T + (tid & 31) * 4]) = csum;
+      __syncthreads();
+      if (tid < G2_T && m0 + tid < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < RX_BLOCK / 32; ++q) t += red[q * G2_T + tid];
+        g.colsum[(int64_t)blockIdx.z * g.M + m0 + tid] = t;
+      }
+    }
   }
 
   float* Cb = g.C + (int64_t)blockIdx.z * g.c_slab_stride;
@@ -841,6 +865,13 @@ static bool pipe_ok_f32(const GemmArgs& g) {
   if (!B_KC && (g.N % 4 != 0)) return false;
   if (g.k_per_slab % G3_BK != 0 && g.k_per_slab < g.K) return false;
   return true;
+}
+
+// Whether gemm_launch sends this fp32 weight-gradient product (both operands contiguous along the outputs)
+// to the pipelined 128 x 128 kernel.
+static bool gemm_pipe_f32_mc(const GemmArgs& g, int bf16) {
+  const bool skinny = !bf16 && g.N <= 128 && (g.k_per_slab <= 128 || g.M <= 64);
+  return !bf16 && g.N > 64 && !skinny && pipe_ok_f32<false, false>(g);
 }
 
 // Whether gemm_launch sends this fp32 product to the deep-step (64 k per trip) tiles of gemm_f32_kernel.
@@ -1169,7 +1200,7 @@ extern "C" int rx_linear_bwd_w(const float* dY, int64_t ldd, const float* X, int
   g.a_vec = vec_ok(dY, ldd); g.b_vec = vec_ok(X, ldx);
   // the deep-step kernel sums the columns of the dY tiles it stages: the bias gradient's partials come out of
   // the product's own launch, one per weight-gradient slab
-  const bool fused_bias = db && gemm_deep_f32(g, bf16, false, false);
+  const bool fused_bias = db && (gemm_deep_f32(g, bf16, false, false) || gemm_pipe_f32_mc(g, bf16));
   if (fused_bias) g.colsum = bpart;
   if (gemm_launch<false, false>(g, n_slabs, bf16, st)) return 1;
   const int64_t nk = (int64_t)N * K;
