@@ -122,6 +122,15 @@ typedef struct {
 int rx_mf_score_fwd(const rx_mf_args* a, float* d_logits, int32_t* err_flag, int device,
                     void* stream);
 
+/* rx_mf_score_fwd followed by the loss of the MF family and GMF (vanilla_mf.py:35-39, gmf.py:41-45:
+ * F.binary_cross_entropy_with_logits, mean over B * N, fp64) in one launch plus the one-block sum of the
+ * block partials: d_loss [1] fp64, d_dlogits [B, N] = (sigmoid(x) - y) / (B N) (what the backward starts
+ * from), d_logits [B, N] (may be NULL).  ws: rx_mf_score_fwd_bce_workspace_bytes bytes. */
+size_t rx_mf_score_fwd_bce_workspace_bytes(int64_t B, int32_t dim);
+int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, int labels_f64, float* d_logits,
+                        float* d_dlogits, double* d_loss, void* ws, size_t ws_bytes, int32_t* err_flag,
+                        int device, void* stream);
+
 /* Backward of the above given g = dL/dlogits [B,N].  Writes per-occurrence gradients:
  *   d_user_occ [B, dim]   = sum_n g_bn * V[i_bn] * lin_w        (also the gradient of O rows)
  *   d_item_occ [B*N, dim] = g_bn * (U+O) * lin_w
@@ -253,6 +262,16 @@ int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_so
                   int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                   int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
                   void* stream);
+/* Several short lists (each of at most rx_sort_dedup_multi_max_len() = 8192 entries) in one launch, a
+ * workgroup per list; outputs per list as above, no workspace.  The two to four index lists of an
+ * MF-family batch (users, items, occupations, timestamp ranks) are sorted side by side. */
+#define RX_SORT_MULTI_MAX 4
+typedef struct rx_sort_list {
+  const int64_t* idx; int64_t n; int64_t n_rows;
+  int32_t* sorted_pos; int32_t* sorted_slot; int64_t* uniq_rows; int32_t* seg_off; int32_t* n_uniq; int32_t* inverse;
+} rx_sort_list;
+int rx_sort_dedup_multi_max_len(void);
+int rx_sort_dedup_multi(const rx_sort_list* lists, int32_t count, int32_t* err_flag, int device, void* stream);
 /* The same over the row list of an FM batch, read straight from the index matrices in `a`
  * (ex_idx, ex_base, item_idx, item_base, B, F, N, n_feat = rows of the table; the table pointers
  * are not touched): entry i < B*F is extra field i % F of sample i / F plus that field's base row,

@@ -1,19 +1,16 @@
-#!/usr/bin/env python3
-"""Print one train step's kernel timeline (us) from a rocprofv3 kernel_trace.csv.
-Usage: timeline.py kernel_trace.csv [anchor kernel substring] [which occurrence of the anchor]"""
-import csv
-import sys
-
+"""Print the kernel timeline of the last few steps from a rocprofv3 --kernel-trace CSV:
+start offset, duration, gap to the previous kernel's end on the same queue, kernel name."""
+import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-anchor = sys.argv[2] if len(sys.argv) > 2 else "fm2_fwd"
-idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
-k = int(sys.argv[3]) if len(sys.argv) > 3 else len(idx) - 2
-s, e = idx[k], idx[k + 1]
-t0 = int(rows[s]["Start_Timestamp"])
-busy = 0
-for r in rows[s:e]:
-    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    busy += en - st
-    print(f"{(st - t0) / 1e3:9.1f} {(en - st) / 1e3:8.1f} q{r['Queue_Id']} {r['Kernel_Name'].replace('void ', '')[:90]}")
-print(f"step span {(int(rows[e]['Start_Timestamp']) - t0) / 1e3:.1f} us, kernel busy {busy / 1e3:.1f} us, {e - s} launches")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+mid = int(sys.argv[3]) if len(sys.argv) > 3 else None        # optional: start at this fraction (percent) of the trace
+tail = rows[-n:] if mid is None else rows[len(rows) * mid // 100:][:n]
+t0 = int(tail[0]["Start_Timestamp"])
+last_end = {}
+for r in tail:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    q = r.get("Queue_Id", "?")
+    gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+    last_end[q] = e
+    print(f"{(s - t0) / 1e3:9.2f} us  dur {(e - s) / 1e3:7.2f}  gap {gap:7.2f}  q{q:>3}  {r['Kernel_Name'][:70]}")

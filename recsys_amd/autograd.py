@@ -47,6 +47,22 @@ def presort(idx: Tensor, n_rows: int, out=None):
     return si
 
 
+def presort_many(lists, outs=None):
+    """``presort`` of several index tensors; short lists share one launch (ops.sort_dedup_multi)."""
+    flats = []
+    for t, _ in lists:
+        f = t.reshape(-1)
+        if not f.is_contiguous():
+            raise ValueError("presort: the index tensor must be contiguous")
+        flats.append(f)
+    sis = ops.sort_dedup_multi([(f, rows) for f, (_, rows) in zip(flats, lists)], outs)
+    for f, (_, rows), si in zip(flats, lists, sis):
+        _PRESORTED[_sort_key(f, rows)] = (f, si)
+    while len(_PRESORTED) > 512:
+        _PRESORTED.pop(next(iter(_PRESORTED)))
+    return sis
+
+
 _CAPTURE_CACHE: list = []
 
 
@@ -139,9 +155,13 @@ class MFScore(Function):
 
     @staticmethod
     def backward(ctx, g):
+        return _mf_backward(ctx, g.contiguous())
+
+
+def _mf_backward(ctx, g):
+        """Gradients of everything an MF-family score reads, from dL/dlogit ``g`` [B, N]."""
         U, V, users, items = ctx.args
         kw = ctx.kw
-        g = g.contiguous()
         user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, **kw)
         su = sorted_index(users, U.shape[0])
         si = sorted_index(items, V.shape[0])
@@ -164,6 +184,29 @@ class MFScore(Function):
         if kw["lin_b"] is not None:
             glb = ops.reduce_sum(g.reshape(-1)).reshape(kw["lin_b"].shape)
         return (None, None, None, None, gU, gV, gO, gUT, gT, gub, gib, gb, glw, glb)
+
+
+class MFLoss(Function):
+    """Forward + BCE loss of the MF family / GMF as one launch (rx_mf_score_fwd_bce): the forward leaves
+    dL/dlogit, so the backward starts at rx_mf_score_bwd with no loss kernel in between.  Same arguments
+    as MFScore plus the labels [B, N]."""
+
+    @staticmethod
+    def forward(ctx, users, items, occs, temps, U, V, O, UT, T, user_bias, item_bias, bias, lin_w, lin_b, labels):
+        kw = dict(O=O, occs=occs, UT=UT, T=T, temps=temps, user_bias=user_bias, item_bias=item_bias,
+                  bias=bias, lin_w=None if lin_w is None else lin_w.reshape(-1), lin_b=lin_b)
+        ctx.kw = kw
+        ctx.args = (U, V, users, items)
+        ctx.lin_w = lin_w
+        loss, ctx.dlogits, _ = ops.mf_score_fwd_bce(U, V, users, items, labels.contiguous(), **kw)
+        return loss if labels.dtype == torch.float64 else loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.dlogits
+        if not _UNIT_LOSS_GRAD:   # an upstream factor other than 1 (loss * c): scale the saved gradient
+            d = d * g.to(torch.float32)
+        return _mf_backward(ctx, d) + (None,)
 
 
 # ------------------------------------------------------------------ FM second order (+ DeepFM tower input)
@@ -880,7 +923,7 @@ def backward_from_loss(loss: Tensor) -> None:
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward")):
+    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward", "MFLossBackward")):
         loss.backward(gradient=one)
     else:
         _UNIT_LOSS_GRAD = True

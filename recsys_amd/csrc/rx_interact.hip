@@ -62,16 +62,10 @@ __device__ __forceinline__ RowRegs<VEC, CH> row_zero() {
   _Pragma("unroll") for (int k = 0; k < CH; ++k) _Pragma("unroll") for (int i = 0; i < VEC; ++i)
 
 // ================================================================= MF-family score
-template <int VEC, int CH>
-__global__ void __launch_bounds__(RX_BLOCK)
-mf_fwd_kernel(rx_mf_args a, float* __restrict__ logits, int group, int32_t* err_flag) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t b = gid / group;
-  const int lg = (int)(gid % group);
-  if (b >= a.B) return;
+// The logits of sample b, formed by its lane group; lane 0 of the group hands each to `emit(n, logit)`.
+template <int VEC, int CH, typename Emit>
+__device__ __forceinline__ void mf_forward_sample(const rx_mf_args& a, int64_t b, int lg, int group, int32_t* ef, Emit emit) {
   const int dim = a.dim;
-  int32_t* ef = lg == 0 ? err_flag : nullptr;
-
   const int64_t u = a.users[b];
   const bool u_ok = rx_row_ok(u, a.n_users, ef);
   RowRegs<VEC, CH> ue = row_load<VEC, CH>(a.user_table + u * dim, u_ok, lg, group, dim);
@@ -109,8 +103,55 @@ mf_fwd_kernel(rx_mf_args a, float* __restrict__ logits, int group, int32_t* err_
     if (lg == 0) {
       float bt = base;
       if (a.item_bias && ok) bt += a.item_bias[it];
-      logits[b * N + n] = (bt + acc) + extra;
+      emit(n, (bt + acc) + extra);
     }
+  }
+}
+
+template <int VEC, int CH>
+__global__ void __launch_bounds__(RX_BLOCK)
+mf_fwd_kernel(rx_mf_args a, float* __restrict__ logits, int group, int32_t* err_flag) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid / group;
+  const int lg = (int)(gid % group);
+  if (b >= a.B) return;
+  const int N = a.N;
+  mf_forward_sample<VEC, CH>(a, b, lg, group, lg == 0 ? err_flag : nullptr, [&](int n, float x) { logits[b * N + n] = x; });
+}
+
+// Forward + loss of the MF family / GMF in one launch: the lane that holds a logit also forms its BCE term
+// and dL/dlogit = (sigmoid(x) - y) / (B N) in fp64 (the arithmetic of bce_kernel); every block stores the
+// fp64 sum of its terms, bce_final_kernel adds the block sums in a fixed order.
+template <int VEC, int CH, bool F64>
+__global__ void __launch_bounds__(RX_BLOCK)
+mf_fwd_bce_kernel(rx_mf_args a, const void* __restrict__ labels, float* __restrict__ logits, float* __restrict__ dlogits,
+                  double* __restrict__ partial, int group, int32_t* err_flag) {
+  __shared__ double wsum[RX_BLOCK / 64];
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid / group;
+  const int lg = (int)(gid % group);
+  double term = 0.0;
+  if (b < a.B) {
+    const int N = a.N;
+    const double inv_m = 1.0 / ((double)a.B * (double)N);
+    mf_forward_sample<VEC, CH>(a, b, lg, group, lg == 0 ? err_flag : nullptr, [&](int n, float xf) {
+      const int64_t at = b * N + n;
+      const double x = (double)xf;
+      const double y = F64 ? reinterpret_cast<const double*>(labels)[at] : (double)reinterpret_cast<const float*>(labels)[at];
+      const double e = exp(-fabs(x));
+      term += fmax(x, 0.0) - x * y + log1p(e);
+      const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+      dlogits[at] = (float)((sig - y) * inv_m);
+      if (logits) logits[at] = xf;
+    });
+  }
+  term = rx_wave_sum_f64(term);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < RX_BLOCK / 64; ++w) t += wsum[w];
+    partial[blockIdx.x] = t;
   }
 }
 
@@ -135,6 +176,46 @@ extern "C" int rx_mf_score_fwd(const rx_mf_args* a, float* d_logits, int32_t* er
   if (rx_fused_shape(a->dim, &sh, "rx_mf_score_fwd")) return 1;
   const unsigned grid = (unsigned)rx_cdiv(a->B * sh.group, RX_BLOCK);
   RX_DISPATCH_SHAPE(sh, mf_fwd_kernel, dim3(grid), dim3(RX_BLOCK), 0, (hipStream_t)stream, *a, d_logits, sh.group, err_flag);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void bce_final_kernel(const double* __restrict__ partial, int n, int64_t M, double* __restrict__ loss);
+
+// workspace: one fp64 partial per block
+extern "C" size_t rx_mf_score_fwd_bce_workspace_bytes(int64_t B, int32_t dim) {
+  (void)dim;   // a lane group is at most one wavefront: an upper bound on the grid whatever the row width
+  const int64_t grid = rx_cdiv((B > 0 ? B : 1) * 64, RX_BLOCK);
+  return rx_align_up((size_t)grid * sizeof(double), 256);
+}
+
+extern "C" int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, int labels_f64, float* d_logits,
+                                   float* d_dlogits, double* d_loss, void* ws, size_t ws_bytes,
+                                   int32_t* err_flag, int device, void* stream) {
+  RX_ENTER(device);
+  if (mf_check(a, "rx_mf_score_fwd_bce")) return 1;
+  RX_REQUIRE(a->B >= 1, "rx_mf_score_fwd_bce: empty batch");
+  RX_REQUIRE(d_labels && d_dlogits && d_loss && ws, "rx_mf_score_fwd_bce: null argument");
+  RX_REQUIRE(ws_bytes >= rx_mf_score_fwd_bce_workspace_bytes(a->B, a->dim) && ((uintptr_t)ws & 15) == 0, "rx_mf_score_fwd_bce: workspace too small or unaligned");
+  RxRowShape sh;
+  if (rx_fused_shape(a->dim, &sh, "rx_mf_score_fwd_bce")) return 1;
+  const unsigned grid = (unsigned)rx_cdiv(a->B * sh.group, RX_BLOCK);
+  double* partial = (double*)ws;
+  hipStream_t st = (hipStream_t)stream;
+#define MF_BCE(V, C)                                                                                                                                \
+  do {                                                                                                                                              \
+    if (labels_f64) hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, true>), dim3(grid), dim3(RX_BLOCK), 0, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, err_flag); \
+    else hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, false>), dim3(grid), dim3(RX_BLOCK), 0, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, err_flag);           \
+  } while (0)
+  if (sh.vec == 4 && sh.chunks == 1) MF_BCE(4, 1);
+  else if (sh.vec == 4 && sh.chunks == 2) MF_BCE(4, 2);
+  else if (sh.vec == 4) MF_BCE(4, 4);
+  else if (sh.chunks == 1) MF_BCE(1, 1);
+  else if (sh.chunks == 2) MF_BCE(1, 2);
+  else MF_BCE(1, 4);
+#undef MF_BCE
+  RX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B * (int64_t)a->N, d_loss);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -10,8 +10,12 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+import os
+
 from ... import autograd as rxa
 from ..base import HotPathModule, as_index
+
+_FUSED_LOSS = os.environ.get("RX_NO_FUSED_MF_LOSS") != "1"   # A/B timing: forward and loss as two launches
 
 
 class VanillaMF(HotPathModule):
@@ -50,6 +54,21 @@ class VanillaMF(HotPathModule):
         return rxa.MFScore.apply(users, items, e["occs"], e["temps"], self.user_embedding.weight,
                                  self.item_embedding.weight, e["O"], e["UT"], e["T"], e["user_bias"],
                                  e["item_bias"], e["bias"], None, None)
+
+
+    def loss(self, inputs):
+        """BCE loss (vanilla_mf.py:35-39).  On the GPU with one label per logit the logits, the loss and
+        dL/dlogit come out of one launch (autograd.MFLoss); otherwise the generic two-step path."""
+        labels, items = inputs["label"], inputs.get("item_code")
+        users = inputs["user_code"]
+        if (_FUSED_LOSS and items is not None and isinstance(labels, torch.Tensor) and labels.is_cuda and users.is_cuda
+                and labels.dtype in (torch.float32, torch.float64) and items.dim() == 2 and tuple(labels.shape) == tuple(items.shape)
+                and users.shape[0] > 0):
+            e = self._extras(inputs)
+            return rxa.MFLoss.apply(as_index(users, "user_code"), as_index(items, "item_code"), e["occs"], e["temps"],
+                                    self.user_embedding.weight, self.item_embedding.weight, e["O"], e["UT"], e["T"],
+                                    e["user_bias"], e["item_bias"], e["bias"], None, None, labels)
+        return super().loss(inputs)
 
 
 class BiasMF(VanillaMF):

@@ -74,6 +74,19 @@ class GMF(HotPathModule):
                                  None, None, None, None, None, None, self.linear.weight, self.linear.bias)
 
 
+    def loss(self, inputs, pointwise=False):
+        """BCE loss (gmf.py:41-45); list-wise on the GPU the forward launch also forms the loss and dL/dlogit
+        (autograd.MFLoss)."""
+        labels, items, users = inputs["label"], inputs.get("item_code"), inputs["user_code"]
+        if (not pointwise and os.environ.get("RX_NO_FUSED_MF_LOSS") != "1" and items is not None and isinstance(labels, torch.Tensor)
+                and labels.is_cuda and users.is_cuda and labels.dtype in (torch.float32, torch.float64) and items.dim() == 2
+                and tuple(labels.shape) == tuple(items.shape) and users.shape[0] > 0):
+            return rxa.MFLoss.apply(as_index(users, "user_code"), as_index(items, "item_code"), None, None,
+                                    self.user_embedding.weight, self.item_embedding.weight, None, None, None, None, None, None,
+                                    self.linear.weight, self.linear.bias, labels)
+        return super().loss(inputs, pointwise)
+
+
 class MLP(HotPathModule):
     _sparse_names = ["user_embedding.weight", "item_embedding.weight"]
 
