@@ -180,7 +180,9 @@ def graph_sharded(w, device, world):
         opt.step()
         return loss.detach()
 
-    w["graphed"] = ShardedGraphStep(step, w["batches"], device, warmup=3)
+    # RX_BENCH_SHARDED_NO_AHEAD=1: every graph does its own batch's index work up front (A/B)
+    w["graphed"] = ShardedGraphStep(step, w["batches"], device, warmup=3,
+                                    model=None if os.environ.get("RX_BENCH_SHARDED_NO_AHEAD") == "1" else model)
     w["desc"]["launch"] = w["desc"]["launch"].replace("eager, asynchronous", "one HIP graph per step (exchanges recorded inside)")
     return w
 

@@ -70,7 +70,8 @@ ms_e, la = timed(lambda i: step_a(batches[i % K]), 0, STEPS)
 print("eager ms/step", ms_e, flush=True)
 
 b, step_b = build()
-gs = ShardedGraphStep(step_b, batches, dev, warmup=3)
+gs = ShardedGraphStep(step_b, batches, dev, warmup=3, model=b if os.environ.get("AHEAD", "1") == "1" else None)
+print("index work one batch ahead:", gs.ahead, flush=True)
 print("recorded", flush=True)
 ms_g, lb = timed(lambda i: gs(i % K), 0, STEPS)
 print("graph ms/step", ms_g, flush=True)

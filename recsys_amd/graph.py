@@ -259,7 +259,12 @@ class ShardedGraphStep:
     these graphs in the same order.  Call ``release()`` before ``destroy_process_group()``: tearing
     the group down while recorded collectives are alive blocks."""
 
-    def __init__(self, step_fn, batches, device, warmup: int = 3):
+    def __init__(self, step_fn, batches, device, warmup: int = 3, model=None):
+        """``model``: the sharded model, when its batch-only index work (``prepare_static``: occurrence
+        list, sort + dedup, owner buckets) should leave the critical path: the graph of batch i then
+        does that work for batch i+1 on the forward pass's side stream, into buffers the graph of batch i+1 reads,
+        instead of doing its own up front.  Needs at least two batches; replays must then follow the
+        batch order (``slot``, ``slot + 1``, ... cyclically), as every driver here does."""
         if ops._INDEX_CHECK != "deferred":
             raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
         self.batches = list(batches)
@@ -274,13 +279,33 @@ class ShardedGraphStep:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         pool = None
-        for b in self.batches:
+        self.ahead = model is not None and len(self.batches) >= 2 and bool(getattr(model, "capacity", None)) \
+            and hasattr(model, "prepare_static")
+        if self.ahead:
+            self.prepared = [model.prepare_static(b) for b in self.batches]      # static buffers, filled eagerly once
+            torch.cuda.synchronize(device)
+        K = len(self.batches)
+        for i, b in enumerate(self.batches):
             g = torch.cuda.CUDAGraph()
             clear_sort_cache()
             # thread-local error mode: the process group's watchdog thread polls the events of earlier
             # collectives while this thread records, which the global mode turns into a capture error
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                loss = step_fn(b)
+                if self.ahead:
+                    # the next batch's index work rides on the stream the forward pass forks for its
+                    # owner-side sort (after that sort and the send-buffer fill): two concurrent
+                    # branches in the graph, not three
+                    nxt = (i + 1) % K
+                    model._side_work = lambda: model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
+                    loss = step_fn(self.prepared[i])
+                    rec = torch.cuda.current_stream(device)
+                    if model._side_work is not None:          # no forward pass took it: do it here
+                        model._side_work = None
+                        model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
+                    else:
+                        rec.wait_stream(model._pos["owner_side"])                 # join before the graph ends
+                else:
+                    loss = step_fn(b)
             clear_sort_cache()
             pool = pool or g.pool()
             self.graphs.append(g)
@@ -296,3 +321,4 @@ class ShardedGraphStep:
     def release(self) -> None:
         self.graphs.clear()
         self.losses.clear()
+        self.prepared = []

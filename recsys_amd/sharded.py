@@ -302,6 +302,7 @@ class ShardedFieldFM(torch.nn.Module):
         self.bias = ShardedTable(n, 1, device, group, backend, seed=2, full_weight=bw)
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=device))
         self._pos = {}
+        self._side_work = None      # one-shot callable run on the owner-side stream of the next training forward
         # slots per owner of the fixed-capacity exchange; None = exact sizes (one host read per step)
         self.capacity: Optional[int] = None
 
@@ -343,21 +344,55 @@ class ShardedFieldFM(torch.nn.Module):
             side = self._pos["side"] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)      # = the steps launched so far; the step launched next runs beside this
         with torch.cuda.stream(side):
-            flat = self._flat(sparse)
-            si = self.ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
-            packed = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
-            slot_of = packed[1].to(torch.int64)
-            occ_slot = slot_of[si.inverse.to(torch.int64)]       # occurrence -> distinct row -> slot
+            si, packed, flat, slot_of, occ_slot = self._index_work(sparse)
             done = torch.cuda.Event()
             done.record(side)
         out = dict(inputs)
         out["_rx_shard_prep"] = (si, packed, done, flat, slot_of, occ_slot)
         return out
 
+    def _index_work(self, sparse, old=None):
+        """The index work of prepare() on the current stream.  ``old``: an earlier result for a batch
+        of the same shape, overwritten in place (buffers that keep their addresses)."""
+        flat = self._flat(sparse)
+        if old is None:
+            si = self.ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
+            packed = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
+            slot_of = packed[1].to(torch.int64)
+            occ_slot = slot_of[si.inverse.to(torch.int64)]       # occurrence -> distinct row -> slot
+            return si, packed, flat, slot_of, occ_slot
+        si, packed, _, flat0, slot_of, occ_slot = old
+        flat0.copy_(flat)
+        self.ops.sort_dedup(flat0, self.feature.n_rows, want_inverse=True, out=si)
+        fresh = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
+        packed[0].copy_(fresh[0])
+        packed[1].copy_(fresh[1])
+        slot_of.copy_(fresh[1])
+        torch.index_select(slot_of, 0, si.inverse.to(torch.int64), out=occ_slot)
+        return si, packed, flat0, slot_of, occ_slot
+
+    def prepare_static(self, inputs, out=None):
+        """prepare() for recorded steps (graph.ShardedGraphStep): the same index work on the *current*
+        stream, no event, and with ``out`` (a batch this method prepared before) written into that
+        batch's buffers in place, so that a graph recorded against them finds every later result at the
+        same addresses.  The caller orders producer and consumer (fork / join inside the recording)."""
+        sparse = inputs["sparse"]
+        if not self.capacity or not sparse.is_cuda:
+            return inputs
+        if out is not None:
+            self._index_work(sparse, out["_rx_shard_prep"])
+            return out
+        si, packed, flat, slot_of, occ_slot = self._index_work(sparse)
+        res = dict(inputs)
+        res["_rx_shard_prep"] = (si, packed, None, flat, slot_of, occ_slot)
+        return res
+
     @staticmethod
     def _join_prep(prep, device):
         """Make the current stream wait for a prepare() result and own its tensors from here on."""
         si, packed, done, flat, slot_of, occ_slot = prep
+        if done is None:            # prepare_static: ordered by the caller, buffers never return to the allocator
+            return si, packed, slot_of, occ_slot
         main = torch.cuda.current_stream(device)
         main.wait_event(done)
         for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], flat,
@@ -528,6 +563,9 @@ class _ShardedFM(torch.autograd.Function):
                     ctx.sent = (torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=flat.device),
                                 torch.zeros(n_slots, dtype=torch.float32, device=flat.device), torch.cuda.Event())
                     ctx.sent[2].record(side)
+                    if model._side_work is not None:     # e.g. a recorded step doing the next batch's index work here
+                        work, model._side_work = model._side_work, None
+                        work()
             rows_p, bias_p = feat.gather_packed(plan), bias.gather_packed(plan)
             if occ_slot is None:
                 slot_of = plan["src_of"].to(torch.int64)

@@ -702,6 +702,7 @@ def test_sharded_step_replayed_as_a_graph_through_rccl_matches_eager_bitwise(mod
                          capture_output=True, text=True, timeout=150)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "bitwise equal True" in out.stdout and "group destroyed" in out.stdout, out.stdout[-2000:]
+    assert "index work one batch ahead: True" in out.stdout      # graph i prepares batch i+1 into static buffers
 
 
 @pytest.mark.parametrize("graphed", [False, True])
