@@ -262,16 +262,6 @@ int rx_sort_dedup(const int64_t* d_idx, int64_t n, int64_t n_rows, int32_t* d_so
                   int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                   int32_t* d_inverse, void* ws, size_t ws_bytes, int32_t* err_flag, int device,
                   void* stream);
-/* Several short lists (each of at most rx_sort_dedup_multi_max_len() = 8192 entries) in one launch, a
- * workgroup per list; outputs per list as above, no workspace.  The two to four index lists of an
- * MF-family batch (users, items, occupations, timestamp ranks) are sorted side by side. */
-#define RX_SORT_MULTI_MAX 4
-typedef struct rx_sort_list {
-  const int64_t* idx; int64_t n; int64_t n_rows;
-  int32_t* sorted_pos; int32_t* sorted_slot; int64_t* uniq_rows; int32_t* seg_off; int32_t* n_uniq; int32_t* inverse;
-} rx_sort_list;
-int rx_sort_dedup_multi_max_len(void);
-int rx_sort_dedup_multi(const rx_sort_list* lists, int32_t count, int32_t* err_flag, int device, void* stream);
 /* The same over the row list of an FM batch, read straight from the index matrices in `a`
  * (ex_idx, ex_base, item_idx, item_base, B, F, N, n_feat = rows of the table; the table pointers
  * are not touched): entry i < B*F is extra field i % F of sample i / F plus that field's base row,

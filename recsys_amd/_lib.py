@@ -52,12 +52,6 @@ class FGReduceArgs(C.Structure):
                 ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp), ("ld_w", i64), ("ld_w2", i64)]
 
 
-RX_SORT_MULTI_MAX = 4
-
-
-class SortList(C.Structure):
-    _fields_ = [("idx", vp), ("n", i64), ("n_rows", i64), ("sorted_pos", vp), ("sorted_slot", vp), ("uniq_rows", vp),
-                ("seg_off", vp), ("n_uniq", vp), ("inverse", vp)]
 
 
 RX_FM_NO_SECOND_ORDER = 1
@@ -109,8 +103,6 @@ PROTOTYPES = {
     "rx_bce_fwd_noalloc": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, C.c_int, vp]),
     "rx_sort_dedup_workspace_bytes": (sz, [i64]),
     "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
-    "rx_sort_dedup_multi_max_len": (C.c_int, []),
-    "rx_sort_dedup_multi": (C.c_int, [C.POINTER(SortList), i32, vp, C.c_int, vp]),
     "rx_sort_dedup_fm": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_segreduce_grid": (i64, [i64, i32]),
     "rx_segreduce_workspace_bytes": (sz, [i64, i32]),

@@ -47,22 +47,6 @@ def presort(idx: Tensor, n_rows: int, out=None):
     return si
 
 
-def presort_many(lists, outs=None):
-    """``presort`` of several index tensors; short lists share one launch (ops.sort_dedup_multi)."""
-    flats = []
-    for t, _ in lists:
-        f = t.reshape(-1)
-        if not f.is_contiguous():
-            raise ValueError("presort: the index tensor must be contiguous")
-        flats.append(f)
-    sis = ops.sort_dedup_multi([(f, rows) for f, (_, rows) in zip(flats, lists)], outs)
-    for f, (_, rows), si in zip(flats, lists, sis):
-        _PRESORTED[_sort_key(f, rows)] = (f, si)
-    while len(_PRESORTED) > 512:
-        _PRESORTED.pop(next(iter(_PRESORTED)))
-    return sis
-
-
 _CAPTURE_CACHE: list = []
 
 

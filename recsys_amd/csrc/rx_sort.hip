@@ -534,11 +534,11 @@ __device__ __forceinline__ void small_match(const uint32_t (&key)[SMALL_ITEMS], 
 }
 
 template <int RAW>
-__device__ __forceinline__ void
-sort_dedup_small_body(const RawSrc& src, int n, int64_t n_rows, int passes, int bits, int32_t* __restrict__ sorted_pos,
-                      int32_t* __restrict__ sorted_slot, int64_t* __restrict__ uniq_rows,
-                      int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq, int32_t* __restrict__ inverse,
-                      int32_t* err_flag) {
+__global__ void __launch_bounds__(SMALL_THREADS)
+sort_dedup_small_kernel(RawSrc src, int n, int64_t n_rows, int passes, int bits, int32_t* __restrict__ sorted_pos,
+                        int32_t* __restrict__ sorted_slot, int64_t* __restrict__ uniq_rows,
+                        int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq, int32_t* __restrict__ inverse,
+                        int32_t* err_flag) {
   // dynamic LDS: [SMALL_MAX] keys | [SMALL_MAX] positions | [SMALL_WAVES][SMALL_BINS] counters | [SMALL_BINS] digit starts
   extern __shared__ uint32_t dyn[];
   __shared__ uint32_t lds16[SMALL_WAVES];
@@ -653,65 +653,6 @@ sort_dedup_small_body(const RawSrc& src, int n, int64_t n_rows, int passes, int 
     n_uniq[0] = (int32_t)total;
     seg_off[total] = n;
   }
-}
-
-template <int RAW>
-__global__ void __launch_bounds__(SMALL_THREADS)
-sort_dedup_small_kernel(RawSrc src, int n, int64_t n_rows, int passes, int bits, int32_t* __restrict__ sorted_pos,
-                        int32_t* __restrict__ sorted_slot, int64_t* __restrict__ uniq_rows,
-                        int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq, int32_t* __restrict__ inverse,
-                        int32_t* err_flag) {
-  sort_dedup_small_body<RAW>(src, n, n_rows, passes, bits, sorted_pos, sorted_slot, uniq_rows, seg_off, n_uniq, inverse, err_flag);
-}
-
-// Several short lists in one launch, a workgroup each: the two to four index lists of an MF-family batch
-// (users, items, occupations, timestamp ranks) are sorted side by side instead of one after the other --
-// their one-workgroup sorts, ~20 us each, were the longest chain of the step.
-struct SmallList {
-  const int64_t* idx; int n; int passes, bits; int64_t n_rows;
-  int32_t* sorted_pos; int32_t* sorted_slot; int64_t* uniq_rows; int32_t* seg_off; int32_t* n_uniq; int32_t* inverse;
-};
-struct SmallBatch { SmallList l[RX_SORT_MULTI_MAX]; };
-
-__global__ void __launch_bounds__(SMALL_THREADS)
-sort_dedup_small_multi_kernel(SmallBatch b, int32_t* err_flag) {
-  const SmallList& L = b.l[blockIdx.x];
-  RawSrc src{};
-  src.idx = L.idx;
-  sort_dedup_small_body<1>(src, L.n, L.n_rows, L.passes, L.bits, L.sorted_pos, L.sorted_slot, L.uniq_rows, L.seg_off, L.n_uniq, L.inverse, err_flag);
-}
-
-extern "C" int rx_sort_dedup_multi_max_len(void) { return SMALL_MAX; }
-
-extern "C" int rx_sort_dedup_multi(const rx_sort_list* lists, int32_t count, int32_t* err_flag, int device, void* stream) {
-  RX_ENTER(device);
-  RX_REQUIRE(lists && count >= 1 && count <= RX_SORT_MULTI_MAX, "rx_sort_dedup_multi: 1..%d lists", RX_SORT_MULTI_MAX);
-  SmallBatch b{};
-  for (int k = 0; k < count; ++k) {
-    const rx_sort_list& q = lists[k];
-    RX_REQUIRE(q.n >= 1 && q.n <= SMALL_MAX, "rx_sort_dedup_multi: list %d has %lld entries (1..%d)", k, (long long)q.n, SMALL_MAX);
-    RX_REQUIRE(q.n_rows >= 1 && q.n_rows <= (1ll << 32), "rx_sort_dedup_multi: n_rows out of range");
-    RX_REQUIRE(q.idx && q.sorted_pos && q.uniq_rows && q.seg_off && q.n_uniq, "rx_sort_dedup_multi: null argument in list %d", k);
-    int bits = 1;
-    while (bits < 32 && (1ull << bits) < (unsigned long long)q.n_rows) ++bits;
-    const int passes = (bits + SMALL_BITS - 1) / SMALL_BITS;
-    SmallList& L = b.l[k];
-    L.idx = q.idx; L.n = (int)q.n; L.n_rows = q.n_rows; L.passes = passes; L.bits = (bits + passes - 1) / passes;
-    L.sorted_pos = q.sorted_pos; L.sorted_slot = q.sorted_slot; L.uniq_rows = q.uniq_rows; L.seg_off = q.seg_off;
-    L.n_uniq = q.n_uniq; L.inverse = q.inverse;
-  }
-  const size_t lds = (2 * (size_t)SMALL_MAX + SMALL_WAVES * SMALL_BINS + SMALL_BINS) * sizeof(uint32_t);
-  static bool attr_set[64] = {};
-  int dev = 0;
-  RX_HIP(hipGetDevice(&dev));
-  const bool known = dev >= 0 && dev < 64;
-  if (!known || !attr_set[dev]) {
-    RX_HIP(hipFuncSetAttribute((const void*)sort_dedup_small_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (known) attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL(sort_dedup_small_multi_kernel, dim3((unsigned)count), dim3(SMALL_THREADS), lds, (hipStream_t)stream, b, err_flag);
-  RX_LAUNCH_CHECK();
-  return 0;
 }
 
 static int sort_dedup_small(const RawSrc& raw, int raw_mode, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,

@@ -41,7 +41,7 @@ class HotPathModule(nn.Module):
             return inputs
         old = out.get("_rx_sorted") if out is not None else None
         res = dict(inputs)
-        res["_rx_sorted"] = rxa.presort_many(lists, old)      # short lists are sorted side by side in one launch
+        res["_rx_sorted"] = [rxa.presort(t, rows, out=old[k] if old else None) for k, (t, rows) in enumerate(lists)]
         return res
 
     def loss(self, inputs, *args, **kwargs):

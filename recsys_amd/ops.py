@@ -502,37 +502,6 @@ def sort_dedup(idx: Tensor, n_rows: int, want_inverse: bool = False, out: Option
     return out if out is not None else SortedIndex(n, n_rows, sorted_pos, sorted_slot, uniq, seg, nu, inv)
 
 
-def sort_dedup_multi(lists: Sequence[Tuple[Tensor, int]], outs: Optional[Sequence[Optional[SortedIndex]]] = None) -> List[SortedIndex]:
-    """rx_sort_dedup_multi: ``sort_dedup`` of up to 4 short index lists (each of at most 8192 entries) in
-    one launch, a workgroup per list.  ``lists``: (indices, n_rows) pairs; ``outs``: SortedIndex objects to
-    overwrite in place.  Anything that does not fit falls back to one ``sort_dedup`` call per list."""
-    from ._lib import SortList, RX_SORT_MULTI_MAX
-    outs = list(outs) if outs is not None else [None] * len(lists)
-    cap = int(lib.rx_sort_dedup_multi_max_len())
-    flats = [t.reshape(-1) for t, _ in lists]
-    if not (2 <= len(lists) <= RX_SORT_MULTI_MAX and all(f.is_cuda and f.dtype == torch.int64 and f.is_contiguous() and 1 <= f.numel() <= cap
-                                                          for f in flats) and len({f.device for f in flats}) == 1):
-        return [sort_dedup(t, rows, out=o) for (t, rows), o in zip(lists, outs)]
-    dev = flats[0].device
-    arr = (SortList * len(lists))()
-    res = []
-    for k, (f, (_, rows), o) in enumerate(zip(flats, lists, outs)):
-        n = f.numel()
-        if o is not None:
-            if o.n != n or o.n_rows != rows:
-                raise ValueError("sort_dedup_multi: an `out` was made for a different index list")
-            si = o
-        else:
-            si = SortedIndex(n, rows, torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
-                             torch.empty(n, dtype=torch.int64, device=dev), torch.empty(n + 1, dtype=torch.int32, device=dev),
-                             torch.empty(1, dtype=torch.int32, device=dev), None)
-        arr[k] = SortList(f.data_ptr(), n, int(rows), si.sorted_pos.data_ptr(), si.sorted_slot.data_ptr(), si.uniq_rows.data_ptr(),
-                          si.seg_off.data_ptr(), si.n_uniq.data_ptr(), 0 if si.inverse is None else si.inverse.data_ptr())
-        res.append(si)
-    check(lib.rx_sort_dedup_multi(arr, len(lists), _p(_err_flag(dev)), _dev(flats[0]), _stream(flats[0])), "rx_sort_dedup_multi")
-    return res
-
-
 def fm_sort_dedup(feat, ex_idx, ex_base, item_idx, item_base: int, out: Optional[SortedIndex] = None) -> SortedIndex:
     """sort_dedup(fm2_flat_indices(...)) without materialising the flat list (rx_sort_dedup_fm)."""
     a, B, F, N = _fm_args(feat, None, ex_idx, ex_base, item_idx, item_base)

@@ -893,28 +893,3 @@ def test_mlp_tower_under_dropout_matches_composite(ops):
     m.eval()
     a, b2 = m(batch), m(batch)
     assert torch.equal(a, b2)
-
-
-def test_sort_dedup_multi_equals_one_call_per_list(ops):
-    """rx_sort_dedup_multi (a workgroup per list, one launch) against rx_sort_dedup list by list: every
-    output bit for bit, also when written into existing buffers; lists beyond 8192 entries fall back."""
-    g = _gen(5)
-    specs = [(1024, 6040), (5120, 3706), (1024, 21), (1024, 2316)]
-    lists = [(torch.randint(0, rows, (n,), generator=g).cuda(), rows) for n, rows in specs]
-    for take in (2, 3, 4):
-        got = ops.sort_dedup_multi(lists[:take])
-        again = ops.sort_dedup_multi(lists[:take], got)          # in place
-        assert all(a is b for a, b in zip(got, again))
-        for (idx, rows), si in zip(lists[:take], got):
-            ref = ops.sort_dedup(idx, rows)
-            nu = int(ref.n_uniq.item())
-            assert int(si.n_uniq.item()) == nu
-            assert torch.equal(si.sorted_pos, ref.sorted_pos) and torch.equal(si.sorted_slot, ref.sorted_slot)
-            assert torch.equal(si.uniq_rows[:nu], ref.uniq_rows[:nu]) and torch.equal(si.seg_off[:nu + 1], ref.seg_off[:nu + 1])
-    big = [(torch.randint(0, 3706, (40960,), generator=g).cuda(), 3706), lists[0]]
-    got = ops.sort_dedup_multi(big)
-    ref = ops.sort_dedup(big[0][0], 3706)
-    assert torch.equal(got[0].sorted_pos, ref.sorted_pos)
-    ops.sort_dedup_multi([(torch.tensor([0, 7, 3]).cuda(), 5), (torch.tensor([1, 2]).cuda(), 5)])
-    with pytest.raises(IndexError):                                # the device flag, as after rx_sort_dedup
-        ops.raise_if_index_error()
