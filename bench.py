@@ -46,7 +46,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     torch.manual_seed(1234)
     # resident batches: enough that the rows a round touches exceed the 256 MiB Infinity Cache several
     # times over for the D = 16 tables (64 batches name about 1 GB of distinct rows), so that the
-    # step's table traffic comes from HBM; RX_BENCH_BATCHES overrides (10 = the round-1 figure)
+    # step's table traffic comes from HBM; RX_BENCH_BATCHES overrides (10 = a working set that fits the Infinity Cache)
     n_batches = int(os.environ.get("RX_BENCH_BATCHES", 64 if name in ("fm_criteo",) else 10))
     if name in ("deepfm_criteo_sharded", "deepfm_wide_d128_sharded"):
         # the Criteo-shaped DeepFM with its tables row-sharded and its BatchNorm tower data parallel
@@ -111,7 +111,7 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
         return graph_sharded(w, device, world) if use_graph else w
     if name in ("fm_criteo", "fm_wide_d128", "deepfm_criteo", "deepfm_criteo_bf16", "dcnv2_criteo"):
         dims = synthetic.criteo_field_dims()
-        B, D = 65536, int(os.environ.get("RX_BENCH_DIM", 16))      # RX_BENCH_DIM: width sweeps of the experiments in DESIGN.md
+        B, D = 65536, int(os.environ.get("RX_BENCH_DIM", 16))      # RX_BENCH_DIM: row-width sweeps
         if name == "fm_wide_d128":
             # one GPU's share of the 1 B-row x 128 configuration, unsharded: 125 M rows of 512 bytes (64 GB)
             dims, D = synthetic.criteo_field_dims(total_rows=125_000_000), 128
@@ -565,6 +565,11 @@ def extra_in_child(name, args, limit_s=420):
 
 # ----------------------------------------------------------------------------- main
 def main():
+    # stdout carries the result line and nothing else: libraries that write to file descriptor 1 on their own
+    # (RCCL's version banner at communicator set-up, gloo's connection messages) are sent to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -675,7 +680,7 @@ def main():
         return w, el, ops_ms, float(loss.item())
 
     if args.child_entry:       # one entry of other_workloads, printed for the parent process
-        print(json.dumps(extra_entry(args.workload, device, clip, run)))
+        print(json.dumps(extra_entry(args.workload, device, clip, run)), file=result_out, flush=True)
         return
     if args.op_profile and rank == 0:
         w = build_workload(args.workload, device, rank, world, clip, use_graph=False)
@@ -779,7 +784,7 @@ def main():
                                   for name in extras]
 
     if rank == 0 and world == 1 and args.workload == "fm_criteo" and os.environ.get("RX_BENCH_BATCHES") is None:
-        # the same workload cycling over 10 resident batches (the round-1 protocol): the rows a round
+        # the same workload cycling over 10 resident batches: the rows a round
         # touches then fit the 256 MiB Infinity Cache, so part of the table traffic never reaches HBM
         os.environ["RX_BENCH_BATCHES"] = "10"
         w10, el10, _, _ = run(args.workload, args.steps, args.warmup, None, use_graph, repeats=3)
@@ -795,7 +800,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload, out["config"], clip)
         out["cpu_baseline_adam"] = cpu_baseline(args.workload, out["config"], clip, budget_s=12.0, optimizer="adam")
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         # recorded collectives must be gone before the group is torn down (the teardown blocks otherwise)
         import gc

@@ -362,6 +362,8 @@ class ShardedFieldFM(torch.nn.Module):
             occ_slot = slot_of[si.inverse.to(torch.int64)]       # occurrence -> distinct row -> slot
             return si, packed, flat, slot_of, occ_slot
         si, packed, _, flat0, slot_of, occ_slot = old
+        if flat0.shape != flat.shape:
+            raise ValueError("prepare_static: `out` was prepared for a batch of another shape")
         flat0.copy_(flat)
         self.ops.sort_dedup(flat0, self.feature.n_rows, want_inverse=True, out=si)
         fresh = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)

@@ -157,6 +157,52 @@ def test_sharded_prepare_on_side_stream_is_bitwise_neutral():
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+def test_sharded_prepare_static_overwrites_in_place_and_steps_like_unprepared_batches():
+    """prepare_static(batch, out=earlier): every tensor of the earlier result keeps its address and
+    holds what a fresh preparation of the new batch holds; steps on batches prepared that way leave
+    the same weights, bit for bit, as steps on unprepared batches; a batch of another shape is refused."""
+    from recsys_amd.sharded import ShardedFieldFM
+    dims = [7, 1000, 13, 5000, 3, 211]
+    g = torch.Generator().manual_seed(11)
+    batches = [{"sparse": torch.stack([torch.randint(0, d, (400,), generator=g) for d in dims], 1).cuda(),
+                "label": (torch.rand(400, 1, generator=g) < 0.3).double().cuda()} for _ in range(3)]
+    torch.manual_seed(5)
+    state = {"feature_embedding.weight": torch.randn(sum(dims), 16), "bias_embedding.weight": torch.randn(sum(dims), 1)}
+
+    def tensors(prep):
+        si, packed, done, flat, slot_of, occ_slot = prep
+        assert done is None
+        nu = int(si.n_uniq.item())        # per-distinct-row outputs are defined for the first n_uniq entries only
+        whole = [si.sorted_pos, si.sorted_slot, si.n_uniq, si.inverse, packed[0], flat, occ_slot]
+        return whole + [si.seg_off[:nu + 1], packed[1][:nu], slot_of[:nu], si.uniq_rows[:nu]], si
+
+    out = []
+    for static in (False, True):
+        sh = ShardedFieldFM(dims, 16, "cuda", full_state=state)
+        sh.calibrate(batches)
+        sh.set_rule("sgd", 0.1, clip_norm=0.05)
+        slot = sh.prepare_static(batches[0]) if static else None
+        if static:
+            where = [t.data_ptr() for t in tensors(slot["_rx_shard_prep"])[0]]
+            again = sh.prepare_static(batches[1], out=slot)
+            held, _ = tensors(slot["_rx_shard_prep"])
+            assert again is slot and [t.data_ptr() for t in held] == where
+            fresh, _ = tensors(sh.prepare_static(batches[1])["_rx_shard_prep"])
+            assert all(torch.equal(a, b) for a, b in zip(held, fresh))
+            short = {k: v[:100] for k, v in batches[2].items()}
+            with pytest.raises(ValueError):
+                sh.prepare_static(short, out=slot)
+        for i in range(6):
+            b = batches[i % 3]
+            if static:
+                sh.prepare_static(b, out=slot)
+                b = dict(b, _rx_shard_prep=slot["_rx_shard_prep"])
+            loss = sh.loss(b); loss.backward(); sh.finish_step()
+        out.append((sh.feature.weight.clone(), sh.bias.weight.clone(), float(loss.item())))
+    assert out[0][2] == out[1][2]
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("fixed", [False, True])
 @pytest.mark.parametrize("shape", ["6_fields_d16", "26_fields_d128"])
 def test_sharded_deepfm_world1_matches_field_deepfm(fixed, shape):
