@@ -612,6 +612,13 @@ int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, const
 int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const int64_t* d_counts,
                      int32_t G, int64_t n, int64_t capacity, int64_t pad_rows, int64_t* d_packed,
                      int32_t* d_src_of, int32_t* err_flag, int device, void* stream);
+/* The gradient send buffer of that layout: d_rows [G * capacity, dim] (dim a multiple of 4) and
+ * the companion table's d_companion [G * capacity] (may be NULL).  Zeroes the padding slots only
+ * (slot offset >= d_counts[owner], the counts of rx_bucketize_by_owner); the used slots are written
+ * by the reduce (rx_segreduce_fm, RX_SEG_DENSE), so the buffer needs no whole fill.  Part of the
+ * model-parallel exchange the reference's single-process loop (recsys/utils.py:87-107) does not have. */
+int rx_zero_unused_slots(const int64_t* d_counts, int32_t G, int64_t capacity, int32_t dim,
+                         float* d_rows, float* d_companion, int device, void* stream);
 
 /* ------------------------------------------------------------------ evaluation
  * Top-k item codes per user from list-wise scores, replacing the host numpy

@@ -315,3 +315,34 @@ extern "C" int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_pe
   RX_LAUNCH_CHECK();
   return 0;
 }
+
+// Zeroes the padding slots of a fixed-capacity exchange buffer (slot off >= counts[owner] of every
+// owner group) and leaves the used ones alone: a thread per 16-byte piece of a row, the companion
+// entry by the row's first thread.
+__global__ void __launch_bounds__(RX_BLOCK)
+zero_unused_slots_kernel(const int64_t* __restrict__ counts, int64_t total, int64_t capacity, int vec,
+                         float4* __restrict__ rows, float* __restrict__ companion) {
+  const int64_t t = (int64_t)blockIdx.x * RX_BLOCK + threadIdx.x;
+  const int64_t slot = t / vec;
+  if (slot >= total) return;
+  const int piece = (int)(t - slot * vec);
+  const int64_t owner = slot / capacity;
+  if (slot - owner * capacity < counts[owner]) return;
+  rows[slot * vec + piece] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (piece == 0 && companion) companion[slot] = 0.f;
+}
+
+extern "C" int rx_zero_unused_slots(const int64_t* d_counts, int32_t G, int64_t capacity, int32_t dim,
+                                    float* d_rows, float* d_companion, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(G >= 1 && G <= 4096 && capacity >= 1 && (int64_t)G * capacity < (1ll << 31), "rx_zero_unused_slots: bad sizes");
+  RX_REQUIRE(dim >= 4 && dim % 4 == 0 && dim <= 4096, "rx_zero_unused_slots: dim must be a multiple of 4 (16-byte pieces)");
+  RX_REQUIRE(d_counts && d_rows, "rx_zero_unused_slots: null argument");
+  RX_REQUIRE(((uintptr_t)d_rows & 15) == 0, "rx_zero_unused_slots: rows must be 16-byte aligned");
+  const int64_t total = (int64_t)G * capacity;
+  const int vec = dim / 4;
+  hipLaunchKernelGGL(zero_unused_slots_kernel, dim3((unsigned)rx_cdiv(total * vec, RX_BLOCK)), dim3(RX_BLOCK), 0,
+                     (hipStream_t)stream, d_counts, total, capacity, vec, (float4*)d_rows, d_companion);
+  RX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1168,6 +1168,19 @@ def pack_by_owner(send_local: Tensor, perm: Tensor, counts: Tensor, capacity: in
     return packed, src_of
 
 
+def zero_unused_slots(rows: Tensor, companion: Optional[Tensor], counts: Tensor, capacity: int) -> None:
+    """rx_zero_unused_slots: zero the padding slots (offset >= counts[owner]) of a fixed-capacity send buffer
+    ``rows`` [G * capacity, dim] and of ``companion`` [G * capacity] in place; used slots are left as they are."""
+    _req(rows, torch.float32, "rows", 2)
+    G = counts.numel()
+    if counts.dtype != torch.int64 or not counts.is_contiguous() or rows.shape[0] != G * capacity or not rows.is_contiguous():
+        raise ValueError("zero_unused_slots: counts [G] int64, rows [G * capacity, dim] contiguous")
+    if companion is not None and (companion.dtype != torch.float32 or companion.numel() != rows.shape[0] or not companion.is_contiguous()):
+        raise ValueError("zero_unused_slots: companion must be float32 [G * capacity]")
+    check(lib.rx_zero_unused_slots(_p(counts), G, capacity, rows.shape[1], _p(rows), _p(companion), _dev(rows), _stream(rows)),
+          "rx_zero_unused_slots")
+
+
 TOPK_MAX_CANDIDATES = 1024   # widest score row rx_topk_codes takes (one wavefront per row, candidates in registers)
 
 

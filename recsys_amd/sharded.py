@@ -87,20 +87,21 @@ class ShardedTable:
 
     def pack_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int):
         """The local half of plan_fixed (no collective): owner buckets packed into ``capacity`` slots
-        each.  Returns (packed local row ids [G * capacity], slot of every list entry [n])."""
+        each.  Returns (packed local row ids [G * capacity], slot of every list entry [n], entries
+        per owner [G])."""
         counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
-        return self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1))
+        return self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1)) + (counts,)
 
     def plan_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int, packed=None):
         """Exchange plan with ``capacity`` slots per owner and equal all-to-all splits: no host-side
         sizes, so the step never waits for the host.  A group that does not fit sets the deferred
         RX_ERR_CAPACITY flag (``ops.raise_if_index_error``)."""
-        packed, src_of = packed if packed is not None else self.pack_fixed(idx, n_valid, capacity)
+        packed, src_of, counts = packed if packed is not None else self.pack_fixed(idx, n_valid, capacity)
         recv_idx = packed
         if not (self.G == 1 and not self.force_exchange):
             recv_idx = torch.empty_like(packed)
             dist.all_to_all_single(recv_idx, packed, group=self.group)
-        return dict(fixed=True, recv_idx=recv_idx, src_of=src_of, n_valid=n_valid, capacity=capacity, n=idx.numel())
+        return dict(fixed=True, recv_idx=recv_idx, src_of=src_of, counts=counts, n_valid=n_valid, capacity=capacity, n=idx.numel())
 
     def sort_received_ahead(self, plan, side) -> None:
         """The owner-side sort of a fixed-capacity plan needs only the slot ids that arrived in the
@@ -369,6 +370,7 @@ class ShardedFieldFM(torch.nn.Module):
         fresh = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
         packed[0].copy_(fresh[0])
         packed[1].copy_(fresh[1])
+        packed[2].copy_(fresh[2])
         slot_of.copy_(fresh[1])
         torch.index_select(slot_of, 0, si.inverse.to(torch.int64), out=occ_slot)
         return si, packed, flat0, slot_of, occ_slot
@@ -397,7 +399,7 @@ class ShardedFieldFM(torch.nn.Module):
             return si, packed, slot_of, occ_slot
         main = torch.cuda.current_stream(device)
         main.wait_event(done)
-        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], flat,
+        for t in (si.sorted_pos, si.sorted_slot, si.uniq_rows, si.seg_off, si.n_uniq, si.inverse, packed[0], packed[1], packed[2], flat,
                   slot_of, occ_slot):
             t.record_stream(main)
         return si, packed, slot_of, occ_slot
@@ -560,10 +562,16 @@ class _ShardedFM(torch.autograd.Function):
                 if side is None:
                     side = model._pos["owner_side"] = torch.cuda.Stream(device=flat.device)
                 feat.sort_received_ahead(plan, side)
-                with torch.cuda.stream(side):      # the zero-filled send buffers of the backward pass, off the critical path
+                with torch.cuda.stream(side):      # the send buffers of the backward pass, off the critical path
                     n_slots = plan["recv_idx"].numel()
-                    ctx.sent = (torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=flat.device),
-                                torch.zeros(n_slots, dtype=torch.float32, device=flat.device), torch.cuda.Event())
+                    if feat.dim % 4 == 0:           # the reduce writes every used slot: only the padding slots need zeros
+                        ctx.sent = (torch.empty(n_slots, feat.dim, dtype=torch.float32, device=flat.device),
+                                    torch.empty(n_slots, dtype=torch.float32, device=flat.device), torch.cuda.Event())
+                        plan["counts"].record_stream(side)
+                        ops.zero_unused_slots(ctx.sent[0], ctx.sent[1], plan["counts"], model.capacity)
+                    else:
+                        ctx.sent = (torch.zeros(n_slots, feat.dim, dtype=torch.float32, device=flat.device),
+                                    torch.zeros(n_slots, dtype=torch.float32, device=flat.device), torch.cuda.Event())
                     ctx.sent[2].record(side)
                     if model._side_work is not None:     # e.g. a recorded step doing the next batch's index work here
                         work, model._side_work = model._side_work, None

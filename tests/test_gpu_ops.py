@@ -893,3 +893,24 @@ def test_mlp_tower_under_dropout_matches_composite(ops):
     m.eval()
     a, b2 = m(batch), m(batch)
     assert torch.equal(a, b2)
+
+
+def test_zero_unused_slots_clears_the_padding_and_nothing_else(ops):
+    """rx_zero_unused_slots on a [G * capacity, dim] send buffer: slots at offset >= counts[owner] become
+    zero (rows and companion entries), used slots keep their bits; a full or overfull group is left alone."""
+    G, cap = 5, 37
+    counts = torch.tensor([0, 11, 37, 50, 36]).cuda()
+    for dim in (4, 16, 128):
+        rows = torch.randn(G * cap, dim, generator=_gen(dim)).cuda()
+        comp = torch.randn(G * cap, generator=_gen(dim + 1)).cuda()
+        want, want2 = rows.clone(), comp.clone()
+        for o in range(G):
+            want[o * cap + min(int(counts[o]), cap):(o + 1) * cap] = 0
+            want2[o * cap + min(int(counts[o]), cap):(o + 1) * cap] = 0
+        ops.zero_unused_slots(rows, comp, counts, cap)
+        assert torch.equal(rows, want) and torch.equal(comp, want2)
+        rows2 = want.clone().fill_(1.0)
+        ops.zero_unused_slots(rows2, None, counts, cap)
+        assert int((rows2 == 0).all(1).sum()) == sum(cap - min(int(c), cap) for c in counts)
+    with pytest.raises(ValueError):
+        ops.zero_unused_slots(torch.zeros(7, 4).cuda(), None, counts, cap)
