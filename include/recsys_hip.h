@@ -612,6 +612,16 @@ int rx_permute_rows(const float* d_rows, const int32_t* d_perm, int64_t n, const
 int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_perm, const int64_t* d_counts,
                      int32_t G, int64_t n, int64_t capacity, int64_t pad_rows, int64_t* d_packed,
                      int32_t* d_src_of, int32_t* err_flag, int device, void* stream);
+/* Index glue of the sharded FM step, one launch each.  rx_fm_flat_rows: the batch's occurrence list
+ * d_out [B * fields] from d_sparse [B, fields] (field-local indices) and d_offsets [fields], all
+ * (sample, field < fields - 1) entries first, then the last field's B entries (the order of rx_fm2_fwd's
+ * ex_idx / item_idx split; recsys/models/matrix_factorization/factorization_machine.py:33-41 adds the
+ * same offsets).  rx_compose_slots: d_slot_of [n_list] = d_src_of widened to 64 bits and
+ * d_occ_slot [n_occ] = d_src_of[d_inverse[i]] (occurrence -> distinct row -> exchange slot). */
+int rx_fm_flat_rows(const int64_t* d_sparse, const int64_t* d_offsets, int64_t B, int32_t fields,
+                    int64_t* d_out, int device, void* stream);
+int rx_compose_slots(const int32_t* d_src_of, const int32_t* d_inverse, int64_t n_list, int64_t n_occ,
+                     int64_t* d_slot_of, int64_t* d_occ_slot, int device, void* stream);
 /* The gradient send buffer of that layout: d_rows [G * capacity, dim] (dim a multiple of 4) and
  * the companion table's d_companion [G * capacity] (may be NULL).  Zeroes the padding slots only
  * (slot offset >= d_counts[owner], the counts of rx_bucketize_by_owner); the used slots are written

@@ -170,6 +170,8 @@ PROTOTYPES = {
     "rx_permute_rows": (C.c_int, [vp, vp, i64, vp, i32, vp, C.c_int, vp]),
     "rx_pack_by_owner": (C.c_int, [vp, vp, vp, i32, i64, i64, i64, vp, vp, vp, C.c_int, vp]),
     "rx_zero_unused_slots": (C.c_int, [vp, i32, i64, i32, vp, vp, C.c_int, vp]),
+    "rx_fm_flat_rows": (C.c_int, [vp, vp, i64, i32, vp, C.c_int, vp]),
+    "rx_compose_slots": (C.c_int, [vp, vp, i64, i64, vp, vp, C.c_int, vp]),
     "rx_topk_codes": (C.c_int, [vp, vp, i64, i32, i32, vp, C.c_int, vp]),
 }
 

@@ -316,6 +316,58 @@ extern "C" int rx_pack_by_owner(const int64_t* d_send_local, const int32_t* d_pe
   return 0;
 }
 
+// Occurrence list of an FM batch in the order the FM kernels use: all (sample, field < F) entries
+// first, then the last field's B entries; table row = field-local index + field offset.
+__global__ void __launch_bounds__(RX_BLOCK)
+fm_flat_rows_kernel(const int64_t* __restrict__ sparse, const int64_t* __restrict__ offsets, int64_t B, int fields,
+                    int64_t* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * RX_BLOCK + threadIdx.x;
+  if (t >= B * fields) return;
+  const int64_t b = t / fields;
+  const int f = (int)(t - b * fields);
+  const int F = fields - 1;
+  const int64_t row = sparse[t] + offsets[f];
+  out[f < F ? b * F + f : B * F + b] = row;
+}
+
+extern "C" int rx_fm_flat_rows(const int64_t* d_sparse, const int64_t* d_offsets, int64_t B, int32_t fields,
+                               int64_t* d_out, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(B >= 0 && fields >= 1 && fields <= 4096 && B * fields < (1ll << 40), "rx_fm_flat_rows: bad sizes");
+  if (B == 0) return 0;
+  RX_REQUIRE(d_sparse && d_offsets && d_out, "rx_fm_flat_rows: null argument");
+  hipLaunchKernelGGL(fm_flat_rows_kernel, dim3((unsigned)rx_cdiv(B * fields, RX_BLOCK)), dim3(RX_BLOCK), 0, (hipStream_t)stream,
+                     d_sparse, d_offsets, B, (int)fields, d_out);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
+// occurrence -> distinct row -> exchange slot, composed on the index side: slot_of[u] = src_of[u]
+// (64-bit copy of the list's slots) and occ_slot[i] = src_of[inverse[i]].
+__global__ void __launch_bounds__(RX_BLOCK)
+compose_slots_kernel(const int32_t* __restrict__ src_of, const int32_t* __restrict__ inverse, int64_t n_list, int64_t n_occ,
+                     int64_t* __restrict__ slot_of, int64_t* __restrict__ occ_slot) {
+  const int64_t t = (int64_t)blockIdx.x * RX_BLOCK + threadIdx.x;
+  if (t < n_list) slot_of[t] = src_of[t];
+  if (t < n_occ) {
+    const int32_t u = inverse[t];
+    occ_slot[t] = (u >= 0 && u < n_list) ? (int64_t)src_of[u] : -1;
+  }
+}
+
+extern "C" int rx_compose_slots(const int32_t* d_src_of, const int32_t* d_inverse, int64_t n_list, int64_t n_occ,
+                                int64_t* d_slot_of, int64_t* d_occ_slot, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(n_list >= 0 && n_occ >= 0 && n_list < (1ll << 31) && n_occ < (1ll << 40), "rx_compose_slots: bad sizes");
+  const int64_t n = n_list > n_occ ? n_list : n_occ;
+  if (n == 0) return 0;
+  RX_REQUIRE(d_src_of && d_slot_of && (n_occ == 0 || (d_inverse && d_occ_slot)), "rx_compose_slots: null argument");
+  hipLaunchKernelGGL(compose_slots_kernel, dim3((unsigned)rx_cdiv(n, RX_BLOCK)), dim3(RX_BLOCK), 0, (hipStream_t)stream,
+                     d_src_of, d_inverse, n_list, n_occ, d_slot_of, d_occ_slot);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 // Zeroes the padding slots of a fixed-capacity exchange buffer (slot off >= counts[owner] of every
 // owner group) and leaves the used ones alone: a thread per 16-byte piece of a row, the companion
 // entry by the row's first thread.

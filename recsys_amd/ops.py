@@ -1155,17 +1155,57 @@ def permute_rows(rows: Tensor, perm: Tensor, n_valid: Optional[Tensor] = None) -
     return out
 
 
-def pack_by_owner(send_local: Tensor, perm: Tensor, counts: Tensor, capacity: int, pad_rows: int = 1):
+def pack_by_owner(send_local: Tensor, perm: Tensor, counts: Tensor, capacity: int, pad_rows: int = 1,
+                  out: Optional[Tuple[Tensor, Tensor]] = None):
     """Owner-grouped list -> fixed-capacity send buffer.  Returns (packed [G * capacity] int64,
     src_of [n] int32: packed slot of every list position).  Padding slot i names local row
-    i % pad_rows (``pad_rows`` <= every owner's local height)."""
+    i % pad_rows (``pad_rows`` <= every owner's local height).  ``out``: a (packed, src_of) pair
+    from an earlier call with the same sizes, overwritten in place."""
     G, n = counts.numel(), send_local.numel()
-    packed = torch.empty(G * capacity, dtype=torch.int64, device=send_local.device)
-    src_of = torch.empty(n, dtype=torch.int32, device=send_local.device)
+    if out is not None:
+        packed, src_of = out
+        if (packed.dtype != torch.int64 or src_of.dtype != torch.int32 or packed.numel() != G * capacity or src_of.numel() != n
+                or not packed.is_contiguous() or not src_of.is_contiguous()):
+            raise ValueError("pack_by_owner: `out` was made for other sizes")
+    else:
+        packed = torch.empty(G * capacity, dtype=torch.int64, device=send_local.device)
+        src_of = torch.empty(n, dtype=torch.int32, device=send_local.device)
     check(lib.rx_pack_by_owner(_p(send_local), _p(perm), _p(counts), G, n, capacity, pad_rows, _p(packed), _p(src_of),
                                _p(_err_flag(send_local.device)), _dev(send_local), _stream(send_local)),
           "rx_pack_by_owner")
     return packed, src_of
+
+
+def fm_flat_rows(sparse: Tensor, offsets: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """rx_fm_flat_rows: [B, fields] field-local indices + [fields] offsets -> the occurrence list [B * fields]
+    (fields 0 .. fields-2 sample by sample, then the last field's B entries)."""
+    _idx(sparse, "sparse"); _idx(offsets, "offsets")
+    if sparse.dim() != 2 or offsets.numel() != sparse.shape[1] or not sparse.is_contiguous() or not offsets.is_contiguous():
+        raise ValueError("fm_flat_rows: sparse [B, fields] and offsets [fields], contiguous")
+    _same_device(sparse, offsets)
+    B, fields = sparse.shape
+    if out is None:
+        out = torch.empty(B * fields, dtype=torch.int64, device=sparse.device)
+    elif out.dtype != torch.int64 or out.numel() != B * fields or not out.is_contiguous() or out.device != sparse.device:
+        raise ValueError("fm_flat_rows: `out` was made for a batch of another shape")
+    check(lib.rx_fm_flat_rows(_p(sparse), _p(offsets), B, fields, _p(out), _dev(sparse), _stream(sparse)), "rx_fm_flat_rows")
+    return out
+
+
+def compose_slots(src_of: Tensor, inverse: Tensor, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """rx_compose_slots: (slot_of [n_list] int64 = src_of, occ_slot [n_occ] int64 = src_of[inverse])."""
+    if src_of.dtype != torch.int32 or inverse.dtype != torch.int32 or not src_of.is_contiguous() or not inverse.is_contiguous():
+        raise ValueError("compose_slots: src_of and inverse must be contiguous int32 vectors")
+    _same_device(src_of, inverse)
+    n_list, n_occ = src_of.numel(), inverse.numel()
+    if out is None:
+        out = (torch.empty(n_list, dtype=torch.int64, device=src_of.device), torch.empty(n_occ, dtype=torch.int64, device=src_of.device))
+    elif (out[0].dtype != torch.int64 or out[1].dtype != torch.int64 or out[0].numel() != n_list or out[1].numel() != n_occ
+          or not out[0].is_contiguous() or not out[1].is_contiguous()):
+        raise ValueError("compose_slots: `out` was made for lists of other lengths")
+    check(lib.rx_compose_slots(_p(src_of), _p(inverse), n_list, n_occ, _p(out[0]), _p(out[1]), _dev(src_of), _stream(src_of)),
+          "rx_compose_slots")
+    return out
 
 
 def zero_unused_slots(rows: Tensor, companion: Optional[Tensor], counts: Tensor, capacity: int) -> None:

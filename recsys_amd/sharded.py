@@ -85,11 +85,15 @@ class ShardedTable:
         dist.all_to_all_single(recv_idx, send_local[:m].contiguous(), recv, send, group=self.group)
         return dict(send=send, recv=recv, recv_idx=recv_idx, perm=perm[:m], n=m)
 
-    def pack_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int):
+    def pack_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int, out=None):
         """The local half of plan_fixed (no collective): owner buckets packed into ``capacity`` slots
         each.  Returns (packed local row ids [G * capacity], slot of every list entry [n], entries
         per owner [G])."""
         counts, send_local, perm = self.ops.bucketize_by_owner(idx, self.G, self.n_rows, n_valid)
+        if out is not None:         # an earlier result, overwritten in place (device backend only)
+            self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1), out=(out[0], out[1]))
+            out[2].copy_(counts)
+            return out
         return self.ops.pack_by_owner(send_local, perm, counts, capacity, max(self.n_rows // self.G, 1)) + (counts,)
 
     def plan_fixed(self, idx: torch.Tensor, n_valid: Optional[torch.Tensor], capacity: int, packed=None):
@@ -355,25 +359,21 @@ class ShardedFieldFM(torch.nn.Module):
     def _index_work(self, sparse, old=None):
         """The index work of prepare() on the current stream.  ``old``: an earlier result for a batch
         of the same shape, overwritten in place (buffers that keep their addresses)."""
-        flat = self._flat(sparse)
+        ops = self.ops
         if old is None:
-            si = self.ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
+            flat = ops.fm_flat_rows(sparse.contiguous(), self._offsets)
+            si = ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True)
             packed = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
-            slot_of = packed[1].to(torch.int64)
-            occ_slot = slot_of[si.inverse.to(torch.int64)]       # occurrence -> distinct row -> slot
+            slot_of, occ_slot = ops.compose_slots(packed[1], si.inverse)      # occurrence -> distinct row -> slot
             return si, packed, flat, slot_of, occ_slot
-        si, packed, _, flat0, slot_of, occ_slot = old
-        if flat0.shape != flat.shape:
+        si, packed, _, flat, slot_of, occ_slot = old
+        if flat.numel() != sparse.numel():
             raise ValueError("prepare_static: `out` was prepared for a batch of another shape")
-        flat0.copy_(flat)
-        self.ops.sort_dedup(flat0, self.feature.n_rows, want_inverse=True, out=si)
-        fresh = self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity)
-        packed[0].copy_(fresh[0])
-        packed[1].copy_(fresh[1])
-        packed[2].copy_(fresh[2])
-        slot_of.copy_(fresh[1])
-        torch.index_select(slot_of, 0, si.inverse.to(torch.int64), out=occ_slot)
-        return si, packed, flat0, slot_of, occ_slot
+        ops.fm_flat_rows(sparse.contiguous(), self._offsets, out=flat)
+        ops.sort_dedup(flat, self.feature.n_rows, want_inverse=True, out=si)
+        self.feature.pack_fixed(si.uniq_rows, si.n_uniq, self.capacity, out=packed)
+        ops.compose_slots(packed[1], si.inverse, out=(slot_of, occ_slot))
+        return si, packed, flat, slot_of, occ_slot
 
     def prepare_static(self, inputs, out=None):
         """prepare() for recorded steps (graph.ShardedGraphStep): the same index work on the *current*

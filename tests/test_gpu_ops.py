@@ -914,3 +914,30 @@ def test_zero_unused_slots_clears_the_padding_and_nothing_else(ops):
         assert int((rows2 == 0).all(1).sum()) == sum(cap - min(int(c), cap) for c in counts)
     with pytest.raises(ValueError):
         ops.zero_unused_slots(torch.zeros(7, 4).cuda(), None, counts, cap)
+
+
+def test_index_glue_kernels_equal_their_torch_formulas(ops):
+    """rx_fm_flat_rows against add + slice + cat, rx_compose_slots against widen + index; in place too."""
+    g = _gen(21)
+    dims = [7, 1000, 13, 5000, 3, 211]
+    offs = torch.tensor([0] + list(torch.tensor(dims).cumsum(0)[:-1])).cuda()
+    for B in (1, 300, 4097):
+        sparse = torch.stack([torch.randint(0, d, (B,), generator=g) for d in dims], 1).cuda()
+        glob = sparse + offs[None, :]
+        want = torch.cat([glob[:, :-1].reshape(-1), glob[:, -1]])
+        got = ops.fm_flat_rows(sparse, offs)
+        assert torch.equal(got, want)
+        again = ops.fm_flat_rows(sparse.flip(0).contiguous(), offs, out=got)          # in place
+        flipped = glob.flip(0)
+        assert again is got and torch.equal(got, torch.cat([flipped[:, :-1].reshape(-1), flipped[:, -1]]))
+    src_of = torch.randint(-1, 900, (500,), generator=g, dtype=torch.int32).cuda()
+    inverse = torch.randint(0, 500, (3000,), generator=g, dtype=torch.int32).cuda()
+    slot_of, occ = ops.compose_slots(src_of, inverse)
+    assert slot_of.dtype == occ.dtype == torch.int64
+    assert torch.equal(slot_of, src_of.long()) and torch.equal(occ, src_of.long()[inverse.long()])
+    out = (torch.zeros_like(slot_of), torch.zeros_like(occ))
+    assert ops.compose_slots(src_of, inverse, out=out) is out and torch.equal(out[1], occ)
+    with pytest.raises(ValueError):
+        ops.compose_slots(src_of, inverse, out=(out[0][:10], out[1]))
+    with pytest.raises(ValueError):
+        ops.fm_flat_rows(sparse, offs[:3])
