@@ -78,17 +78,25 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         K = len(prepared)
+        shared = self._shared_branch(dev)
         for i, b in enumerate(prepared):
             g = torch.cuda.CUDAGraph()
             self.opt.zero_grad()
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
-                fork = torch.cuda.Stream(device=dev)
-                fork.wait_stream(main)
-                with torch.cuda.stream(fork):
-                    self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
-                loss = self._eager(b)
+                if shared is None:
+                    fork = torch.cuda.Stream(device=dev)
+                    fork.wait_stream(main)
+                    with torch.cuda.stream(fork):
+                        self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
+                    loss = self._eager(b)
+                else:       # behind the model's own branch work, on its stream (see _shared_branch)
+                    fork = shared
+                    fork.wait_stream(main)
+                    loss = self._eager(b)
+                    with torch.cuda.stream(fork):
+                        self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
                 main.wait_stream(fork)
             if self._pool is None:
                 self._pool = g.pool()
@@ -98,8 +106,20 @@ class GraphedTrainStep:
         if self.cycle:
             self._record_cycle(prepared, dev)
 
+    def _shared_branch(self, dev):
+        """Models that already run part of their step on a second stream (``_branch_streams``: NeuMF's GMF
+        half, autograd.Branch) get the next batch's index preparation on that same stream, behind the
+        branch's own work of the step, instead of on a forked stream of its own: a recorded step then has
+        two concurrent branches, not three.  With three, replays crashed inside the HIP runtime now and
+        then (a host segmentation fault in hipGraphLaunch)."""
+        if not getattr(self.model, "_branch_streams", False):
+            return None
+        from .autograd import _side_stream_for
+        return _side_stream_for("branch", dev)
+
     def _record_cycle(self, prepared, dev) -> None:
         K = len(prepared)
+        shared = self._shared_branch(dev)
         seg = self.cycle_len if 0 < self.cycle_len < K else K
         for first in range(0, K, seg):
             slots = list(range(first, min(first + seg, K)))
@@ -109,23 +129,31 @@ class GraphedTrainStep:
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
-                fork = torch.cuda.Stream(device=dev)
+                fork = shared if shared is not None else torch.cuda.Stream(device=dev)
                 fork.wait_stream(main)
                 ready = None          # preparation of the slot the next step consumes
                 done = {}             # slot -> event recorded after this graph's step on it
-                for i in slots:
-                    if ready is not None:
-                        main.wait_event(ready)
-                    nxt = (i + 1) % K
+
+                def prepare_next(nxt):
                     with torch.cuda.stream(fork):
                         if nxt in done:
                             fork.wait_event(done[nxt])   # its sort result was read by a step of this graph
                         self.model.prepare(prepared[nxt], out=prepared[nxt])
-                        ready = torch.cuda.Event()
-                        ready.record(fork)
+                        ev = torch.cuda.Event()
+                        ev.record(fork)
+                    return ev
+
+                for i in slots:
+                    if ready is not None:
+                        main.wait_event(ready)
+                    nxt = (i + 1) % K
+                    if shared is None:
+                        ready = prepare_next(nxt)
                     losses.append(self._eager(prepared[i]))
                     done[i] = torch.cuda.Event()
                     done[i].record(main)
+                    if shared is not None:      # behind this step's branch work on the branch's stream
+                        ready = prepare_next(nxt)
                 main.wait_stream(fork)
             self.segments[first] = (g, len(slots), losses)
         self.cycle_graph = self.segments[0][0]
