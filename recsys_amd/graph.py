@@ -224,12 +224,17 @@ class GraphedTrainStep:
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
-                fork = torch.cuda.Stream(device=dev)     # one side stream for all steps of the recording
+                shared = self._shared_branch(dev)
+                fork = shared if shared is not None else torch.cuda.Stream(device=dev)     # one side stream for all steps of the recording
                 for s in order:
                     fork.wait_stream(main)       # behind the hand-over that refilled batch 1 - s
-                    with torch.cuda.stream(fork):
-                        self.model.prepare(prepared[1 - s], out=prepared[1 - s])
+                    if shared is None:
+                        with torch.cuda.stream(fork):
+                            self.model.prepare(prepared[1 - s], out=prepared[1 - s])
                     loss = self._eager(prepared[s])
+                    if shared is not None:       # behind the model's own branch work of this step (see _shared_branch)
+                        with torch.cuda.stream(fork):
+                            self.model.prepare(prepared[1 - s], out=prepared[1 - s])
                     epilogues[s](loss)
                     main.wait_stream(fork)
             clear_sort_cache()

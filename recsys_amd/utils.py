@@ -11,6 +11,8 @@ device (rx_topk_codes) instead of numpy argsort on the host (recsys/utils.py:40-
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -132,12 +134,12 @@ class LoopGraph:
                 optimizer.clip_norm = clip_norm
                 # Two static batches that take turns -- while the step runs on one, the index preparation
                 # (sort, dedup) of the other, which already holds the next batch, runs beside it on a forked
-                # stream, and the step's hand-over refills its own batch with the batch after next -- for
-                # models whose step is one chain of launches.  A model that already runs a branch of its own
-                # on a second stream (NeuMF's GMF half) keeps ONE static batch and one plain graph per step:
-                # graphs with a third concurrent branch have crashed the HIP runtime in hipGraphLaunch here
-                # (intermittently, on replay), so they are not recorded.
-                self.paired = not getattr(model, "_branch_streams", False)
+                # stream, and the step's hand-over refills its own batch with the batch after next.  A model
+                # that already runs a branch of its own on a second stream (NeuMF's GMF half) gets that
+                # preparation on the branch's stream (GraphedTrainStep._shared_branch): graphs with a third
+                # concurrent branch have crashed the HIP runtime in hipGraphLaunch here (intermittently, on
+                # replay).  RX_LOOP_ONE_BATCH=1 keeps such a model on ONE static batch and one graph per step.
+                self.paired = not (getattr(model, "_branch_streams", False) and os.environ.get("RX_LOOP_ONE_BATCH") == "1")
                 if self.paired:
                     pair = [{k: v.clone() for k, v in cut(i).items()} for _ in range(2)]
                     hand_over = [(lambda loss, b=b: ops.epoch_advance(self.epoch, b, n_full, self.cursor, self.ticket,

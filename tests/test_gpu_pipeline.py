@@ -721,7 +721,7 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
             ops.set_index_check("sync")
         if graphed:
             assert (step.epoch_slot if feed == "loader" else step.slot) is not None
-            paired = feed == "loader" and name != "NeuMF"     # two static batches take turns; not for the two-stream model
+            paired = feed == "loader"                         # two static batches take turns
             assert len(step.step.graphs) == (2 if paired else 1) and step.paired == paired
             assert not paired or step.step._pair_multi[1] == 8                  # ... and eight steps replay per launch
             if feed == "loader":
