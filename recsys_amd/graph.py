@@ -330,13 +330,16 @@ class ShardedGraphStep:
                     # branches in the graph, not three
                     nxt = (i + 1) % K
                     model._side_work = lambda: model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
-                    loss = step_fn(self.prepared[i])
+                    try:
+                        loss = step_fn(self.prepared[i])
+                        taken = model._side_work is None
+                    finally:
+                        model._side_work = None               # never left behind for a later, unrecorded forward pass
                     rec = torch.cuda.current_stream(device)
-                    if model._side_work is not None:          # no forward pass took it: do it here
-                        model._side_work = None
-                        model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
-                    else:
+                    if taken:
                         rec.wait_stream(model._pos["owner_side"])                 # join before the graph ends
+                    else:                                     # no forward pass took it: do it here
+                        model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
                 else:
                     loss = step_fn(b)
             clear_sort_cache()
