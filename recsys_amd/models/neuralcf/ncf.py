@@ -129,7 +129,7 @@ class MLP(HotPathModule):
 class NeuMF(HotPathModule):
     _sparse_names = ["user_embedding_gmf.weight", "item_embedding_gmf.weight",
                      "user_embedding_mlp.weight", "item_embedding_mlp.weight"]
-    _branch_streams = True      # forward() forks a second stream (see utils.LoopGraph)
+    _branch_streams = True      # forward() forks a second stream (see graph.GraphedTrainStep._shared_branch)
 
     def __init__(self, n_users, n_items, embedding_dim, mlp_dims=None, dropout=0.1):
         super().__init__()
