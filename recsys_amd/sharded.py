@@ -379,7 +379,10 @@ class ShardedFieldFM(torch.nn.Module):
         """prepare() for recorded steps (graph.ShardedGraphStep): the same index work on the *current*
         stream, no event, and with ``out`` (a batch this method prepared before) written into that
         batch's buffers in place, so that a graph recorded against them finds every later result at the
-        same addresses.  The caller orders producer and consumer (fork / join inside the recording)."""
+        same addresses.  Only the preparation is rewritten: the other entries of ``out`` (its index and
+        label tensors) stay as they are, so ``out`` is meant for a static batch whose tensors ``inputs``
+        are (or were copied into).  The caller orders producer and consumer (fork / join inside the
+        recording)."""
         sparse = inputs["sparse"]
         if not self.capacity or not sparse.is_cuda:
             return inputs
