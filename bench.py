@@ -224,6 +224,38 @@ def one_step(w, i):
     return loss
 
 
+def self_check(w, pos):
+    """Outside the timed regions: the next multi-step graph of the timed launch structure (or one
+    single-step graph) against EAGER steps on the same batches from the same weights -- own index
+    preparation, one launch per kernel, no replay.  Weights, buffers and the last loss must come out
+    bit for bit equal.  Returns (verdict, position after the check)."""
+    from recsys_amd.graph import GraphedTrainStep
+    gs, K, model = w.get("graphed"), len(w["batches"]), w["model"]
+    if not isinstance(gs, GraphedTrainStep):
+        return "skipped: the timed steps were not graph replays of a single-GPU step", pos
+    if any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules()):
+        return "skipped: dropout masks of a replay and of an eager step come from different generator states", pos
+    while gs.segments and not gs.segment_at(pos % K):
+        run_steps(w, pos, 1)
+        pos += 1
+    n = gs.segment_at(pos % K) or 1
+    state = list(model.parameters()) + list(model.buffers())
+    torch.cuda.synchronize()
+    saved = [t.detach().clone() for t in state]
+    loss_g = run_steps(w, pos, n).detach().clone()
+    after = [t.detach().clone() for t in state]
+    with torch.no_grad():
+        for t, s0 in zip(state, saved):
+            t.copy_(s0)
+    for j in range(n):
+        loss_e = gs._eager(w["batches"][(pos + j) % K])      # the raw batch: no prepared index lists
+    torch.cuda.synchronize()
+    bad = [i for i, (t, a) in enumerate(zip(state, after)) if not torch.equal(t.detach(), a)]
+    if bad or not torch.equal(loss_e.detach(), loss_g):
+        return f"FAILED: {n} replayed steps and {n} eager steps disagree (tensors {bad}, loss {float(loss_g)} vs {float(loss_e)})", pos + n
+    return f"ok ({n} steps of one graph launch == {n} eager steps, bitwise: {len(state)} tensors + loss)", pos + n
+
+
 # ----------------------------------------------------------------------------- per-op timing
 class OpTimer:
     """Wraps chosen functions of recsys_amd.ops with HIP events recorded on the launch stream."""
@@ -625,7 +657,7 @@ def main():
     ops.set_index_check("deferred")
     clip = None if args.no_clip else 1.0
 
-    def run(name, steps, warmup, timed_op=None, use_graph=True, repeats=1):
+    def run(name, steps, warmup, timed_op=None, use_graph=True, repeats=1, check=False):
         """Builds the workload, runs `warmup` untimed steps, then times `repeats` regions of EXACTLY `steps`
         steps each (barrier + synchronize on both sides, maximum over the ranks); returns the median
         region's time, and the list of all of them in w["region_s"]."""
@@ -666,6 +698,8 @@ def main():
                 el = float(t.item())
             regions.append(el)
             pos += steps
+        if check:
+            w["self_check"], pos = self_check(w, pos)
         ops.raise_if_index_error()
         w["region_s"] = regions
         el = sorted(regions)[len(regions) // 2]
@@ -708,7 +742,7 @@ def main():
         want = os.environ.get("RX_BENCH_SHARDED_GRAPH")
         use_graph = use_graph and want != "0" and (world == 1 or want == "1")
     w, el, ops_ms, last_loss = run(args.workload, args.steps, args.warmup, None if use_graph else dominant, use_graph,
-                                   repeats=args.repeats)
+                                   repeats=args.repeats, check=True)
     if use_graph:
         # the dominant kernel is timed with HIP events on the launch stream after a short eager pass of
         # the same steps (events cannot bracket a single node of a replayed graph)
@@ -723,7 +757,7 @@ def main():
                           "min": 1e3 * min(w["region_s"]) / args.steps, "max": 1e3 * max(w["region_s"]) / args.steps},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": workload_dtype(args.workload), "data": "synthetic",
         "config": dict(w["desc"], global_batch=B * world, parallelism=f"dp{world}" if world > 1 else "single"),
-        "final_loss": last_loss,
+        "final_loss": last_loss, "self_check": w.get("self_check"),
     }
     roof = None
     rho, round_rows = 1.0, None
@@ -801,6 +835,8 @@ def main():
         out["cpu_baseline_adam"] = cpu_baseline(args.workload, out["config"], clip, budget_s=12.0, optimizer="adam")
     if rank == 0:
         print(json.dumps(out), file=result_out, flush=True)
+    if str(out.get("self_check", "")).startswith("FAILED"):
+        raise SystemExit("bench.py: " + out["self_check"])
     if dist is not None:
         # recorded collectives must be gone before the group is torn down (the teardown blocks otherwise)
         import gc

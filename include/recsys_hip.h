@@ -42,6 +42,13 @@ extern "C" {
 
 int rx_abi_version(void);
 const char* rx_last_error(void);
+/* Per-device set-up, no counterpart in the reference: makes `device` current and resolves the
+ * addresses of the library's own device arrays there (rx_bce_fwd_noalloc's scratch).  Optional for
+ * eager use -- the first eager call that needs an address resolves it -- but REQUIRED before
+ * rx_bce_fwd_noalloc is recorded into a HIP graph on that device: the lookup may load the code
+ * object (an allocation) and is not legal under stream capture.  Idempotent, thread-safe; call it
+ * outside any capture. */
+int rx_init(int device);
 /* Measurement aid without a counterpart in the reference: writes the device wall clock (ticks of
  * the constant 100 MHz counter, 10 ns each) to *d_slot in stream order.  Works between the nodes
  * of a captured HIP graph, where HIP events cannot be queried per replay. */
@@ -239,7 +246,11 @@ int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int6
  * live in an 8 KiB device array inside the library (one copy per GPU, held until the process ends)
  * instead of a caller workspace, and the call issues no hipMalloc / hipFree.  M is limited to
  * 2^28 logits; a larger M is rejected with an error.  All calls on one GPU share that array: calls
- * that overlap on one GPU (different streams) race and must be ordered by the caller. */
+ * that overlap on one GPU (different streams) race and must be ordered by the caller.  The array's
+ * address on a device is resolved by rx_init(device) or, failing that, by the first EAGER call on
+ * that device; a first call made while `stream` is being captured is refused with an error (so the
+ * steady-state call, captured or not, touches no allocator: none of the library's, the runtime's or
+ * the caller's). */
 int rx_bce_fwd_noalloc(const float* d_logits, const void* d_labels, int labels_f64, int64_t M,
                        double* d_loss, float* d_dlogits, int device, void* stream);
 

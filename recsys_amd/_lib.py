@@ -84,6 +84,7 @@ class SegTable(C.Structure):
 PROTOTYPES = {
     "rx_abi_version": (C.c_int, []),
     "rx_last_error": (C.c_char_p, []),
+    "rx_init": (C.c_int, [C.c_int]),
     "rx_wall_clock": (C.c_int, [vp, C.c_int, vp]),
     "rx_gather_concat": (C.c_int, [C.POINTER(GatherSeg), C.c_int, vp, i64, i64, vp, C.c_int, vp]),
     "rx_gather_concat_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, C.c_int, vp]),
@@ -200,6 +201,17 @@ def _load():
 
 
 lib = _load()
+
+
+_initialised = set()
+
+
+def init_device(device: int) -> None:
+    """Per-device set-up of the library (rx_init): resolves the addresses of its own device arrays.
+    Must run outside stream capture; ``ops`` calls it the first time a device is used."""
+    if device not in _initialised:
+        check(lib.rx_init(int(device)), "rx_init")
+        _initialised.add(device)
 
 
 def check(status: int, what: str) -> None:

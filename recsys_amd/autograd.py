@@ -57,6 +57,11 @@ def clear_sort_cache() -> None:
     _CAPTURE_CACHE.clear()
 
 
+def clear_capture_sort_cache() -> None:
+    """Forget the sorts memoised during the current recording (between the steps of a multi-step one)."""
+    _CAPTURE_CACHE.clear()
+
+
 def sorted_index(idx: Tensor, n_rows: int):
     """``ops.sort_dedup`` with a small memo: NeuMF-style models look the same index tensor up in
     several tables of equal height (GMF and MLP embeddings), and one sort serves them all.  An

@@ -853,7 +853,7 @@ extern "C" int rx_bce_fwd(const float* d_logits, const void* d_labels, int label
 // ---- the same op for callers that may not allocate (HIP graph capture, tight serving loops): the
 // per-block partial sums live in a file-scope device array instead of a caller workspace.  Every
 // GPU holds its own copy of the array at its own address; the address is looked up once per device
-// and only that pointer is handed to kernels (the array's name is a host-side stand-in, not a
+// (rx_init, or the first eager call there) and only that pointer is handed to kernels (the array's name is a host-side stand-in, not a
 // device address).  bce_kernel overwrites partial[0 .. grid) and bce_final_kernel reads exactly those
 // entries, so nothing has to start at zero.  Calls that overlap on one GPU share the array and race.
 #include <mutex>
@@ -864,18 +864,48 @@ extern "C" int rx_bce_fwd(const float* d_logits, const void* d_labels, int label
 static __device__ __align__(256) double bce_scratch[RX_BCE_MAX_BLOCKS];  // 8 KiB per GPU, for the life of the process
 
 static std::mutex bce_scratch_mutex;
-static double* bce_scratch_ptr[RX_MAX_DEVICES];  // device address of bce_scratch on each GPU, filled on first use
+static double* bce_scratch_ptr[RX_MAX_DEVICES];  // device address of bce_scratch on each GPU, filled by rx_init
 
-static int bce_scratch_for(int device, double** out) {
+// Looks the array's address up for `device`, which must be current.  The lookup may make the runtime
+// load this library's code object onto the device (an allocation, and not legal while a stream of the
+// thread is being captured), so it belongs to set-up: rx_init, or the first EAGER call on a device.
+static int bce_scratch_resolve(int device) {
   RX_REQUIRE(device < RX_MAX_DEVICES, "rx_bce_fwd_noalloc: device ordinal %d beyond %d", device, RX_MAX_DEVICES - 1);
   std::lock_guard<std::mutex> lock(bce_scratch_mutex);
   if (!bce_scratch_ptr[device]) {
     double* p = nullptr;
-    RX_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(bce_scratch)));  // `device` is current (RX_ENTER)
+    RX_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(bce_scratch)));
     RX_REQUIRE(p, "rx_bce_fwd_noalloc: hipGetSymbolAddress returned a null address");
     bce_scratch_ptr[device] = p;
   }
-  *out = bce_scratch_ptr[device];
+  return 0;
+}
+
+extern "C" int rx_init(int device) {
+  RX_ENTER(device);
+  return bce_scratch_resolve(device);
+}
+
+static int bce_scratch_for(int device, hipStream_t st, double** out) {
+  RX_REQUIRE(device < RX_MAX_DEVICES, "rx_bce_fwd_noalloc: device ordinal %d beyond %d", device, RX_MAX_DEVICES - 1);
+  double* p;
+  {
+    std::lock_guard<std::mutex> lock(bce_scratch_mutex);
+    p = bce_scratch_ptr[device];
+  }
+  if (!p) {
+    // not set up on this device yet: fine for an eager call (it does the set-up now), an error under
+    // capture, where the lookup's side effects are not allowed
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    RX_HIP(hipStreamIsCapturing(st, &cap));
+    RX_REQUIRE(cap == hipStreamCaptureStatusNone,
+               "rx_bce_fwd_noalloc: device %d is not initialised and the stream is being captured; call rx_init(%d) "
+               "(or make one eager call) before recording", device, device);
+    if (bce_scratch_resolve(device)) return 1;
+    std::lock_guard<std::mutex> lock(bce_scratch_mutex);
+    p = bce_scratch_ptr[device];
+  }
+  *out = p;
   return 0;
 }
 
@@ -886,9 +916,9 @@ extern "C" int rx_bce_fwd_noalloc(const float* d_logits, const void* d_labels, i
   RX_REQUIRE(M >= 1, "rx_bce_fwd_noalloc: empty input");
   RX_REQUIRE(M <= RX_BCE_NOALLOC_MAX_M, "rx_bce_fwd_noalloc: M=%lld beyond the supported maximum of %lld logits", (long long)M, (long long)RX_BCE_NOALLOC_MAX_M);
   double* partial = nullptr;
-  if (bce_scratch_for(device, &partial)) return 1;
-  const int grid = (int)std::min<int64_t>(rx_cdiv(M, RX_BLOCK), RX_BCE_MAX_BLOCKS);
   hipStream_t st = (hipStream_t)stream;
+  if (bce_scratch_for(device, st, &partial)) return 1;
+  const int grid = (int)std::min<int64_t>(rx_cdiv(M, RX_BLOCK), RX_BCE_MAX_BLOCKS);
   if (labels_f64)
     hipLaunchKernelGGL(bce_kernel<true>, dim3(grid), dim3(RX_BLOCK), 0, st, d_logits, d_labels, M, partial, d_dlogits);
   else

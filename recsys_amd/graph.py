@@ -33,7 +33,7 @@ from typing import Dict, List
 import torch
 
 from . import ops
-from .autograd import backward_from_loss, clear_sort_cache
+from .autograd import backward_from_loss, clear_capture_sort_cache, clear_sort_cache
 
 
 class GraphedTrainStep:
@@ -52,6 +52,10 @@ class GraphedTrainStep:
         self.segments: Dict[int, tuple] = {}          # first slot -> (graph, number of steps, losses)
 
     def _eager(self, batch):
+        if torch.cuda.is_current_stream_capturing():
+            # a recording of several steps refills its static batches through raw pointers between the steps
+            # (no version bump), so a sort memoised by an earlier step of the recording must not serve this one
+            clear_capture_sort_cache()
         self.opt.zero_grad()
         loss = self.model.loss(batch)
         backward_from_loss(loss)

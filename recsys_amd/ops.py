@@ -36,6 +36,7 @@ def _err_flag(device: torch.device) -> Tensor:
     key = device.index if device.index is not None else torch.cuda.current_device()
     t = _err_flags.get(key)
     if t is None:
+        _lib.init_device(key)      # first use of this device: the library's per-device set-up (outside any capture)
         t = torch.zeros(1, dtype=torch.int32, device=device)
         _err_flags[key] = t
     return t

@@ -130,7 +130,13 @@ class FusedOptimizer:
         self._sq_used = 0
         self._dense_state = {}
         self._step = 0
+        # Adam's step count also lives on the device and is advanced on the stream, so that a recorded graph
+        # of the step reads the count of the replay, not the one of the recording.  Made here, never lazily
+        # inside a step: a counter created (and filled) while a graph is being recorded would be reset to the
+        # recording's value by every replay.
         self._step_dev = None
+        if self.dense_kind == "adam" and self.dense and self.dense[0].is_cuda:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.dense[0].device)
         self.last_total_norm: Optional[torch.Tensor] = None
 
     def detach(self):
@@ -270,8 +276,15 @@ class FusedOptimizer:
             ops.multi_dense_update([p.data for p, _ in chunk], [g for _, g in chunk], mode, self.lr, self.eps,
                                    scale=scale, states=states)
 
+    @property
+    def step_count(self) -> int:
+        """Optimizer steps taken so far (graph replays included: read from the device counter when there is one)."""
+        return int(self._step_dev.item()) if self._step_dev is not None else self._step
+
     def step(self):
-        self._step += 1
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if not capturing:          # a recording executes nothing: only the device counter follows the replays
+            self._step += 1
         some = self.sparse[0] if self.sparse else (self.dense[0] if self.dense else None)
         if some is not None and some.is_cuda:
             from .autograd import join_branches
@@ -283,9 +296,8 @@ class FusedOptimizer:
         if self.dense_kind == "adam" and self.dense:
             # the step count also lives on the device, advanced on the stream: a recorded graph of this
             # step then reads the count of the replay, not the one of the recording
-            if self._step_dev is None:
-                self._step_dev = torch.full((1,), self._step - 1, dtype=torch.int32, device=self.dense[0].device)
-            self._step_dev.add_(1)
+            if self._step_dev is not None:
+                self._step_dev.add_(1)
         scale = None
         if self._deferred:
             self._reduce_deferred()

@@ -45,7 +45,28 @@ def model_kwargs(rec):
 
 ELEMENTWISE_FLOOR = 1e-3     # entries at least this fraction of max|expected| are also held element-wise
 ELEMENTWISE_FACTOR = 100.0   # ... to ELEMENTWISE_FACTOR * rtol relative to the entry itself
-WORST = {"ratio": 0.0, "what": "", "rel": 0.0, "rtol": 0.0}   # largest element-wise error / rtol seen this session
+WORST = {}                   # category -> largest element-wise error / rtol seen this session
+
+
+def _category(what: str, rtol: float) -> str:
+    """Which class of comparison a check belongs to (for the end-of-run report): the 3-step optimizer
+    states are compared at 1e-4 and would otherwise hide how close logits and gradients come."""
+    w = what.lower()
+    if rtol >= 1e-3:
+        return "bf16 operands"
+    for tag in ("sgd3", "adagrad3", "adam3"):
+        if tag in w:
+            return "weights after 3 steps"
+    for tag in ("sgd1", "adagrad1", "adam1", "updated", "rows", "after", "weight", "tower ", "deep_mlp."):
+        if tag in w and "grad " not in w:
+            return "weights after 1-2 steps"
+    if "grad" in w or "norm" in w:
+        return "gradients"
+    if "logit" in w:
+        return "logits"
+    if "loss" in w:
+        return "loss"
+    return "other (kernels against torch / numpy)"
 
 
 def assert_close(actual, expected, rtol=1e-5, what="", atol=0.0, elem_rtol=None):
@@ -76,8 +97,9 @@ def assert_close(actual, expected, rtol=1e-5, what="", atol=0.0, elem_rtol=None)
         rel = np.where(big, np.maximum(d - atol, 0.0) / np.where(big, np.abs(e), 1.0), 0.0)
         i = int(np.argmax(rel))
         worst = float(rel.flat[i])
-        if rtol > 0 and worst / rtol > WORST["ratio"]:
-            WORST.update(ratio=worst / rtol, what=what, rel=worst, rtol=rtol)
+        cat = _category(what, rtol)
+        if rtol > 0 and worst / rtol > WORST.get(cat, {"ratio": 0.0})["ratio"]:
+            WORST[cat] = dict(ratio=worst / rtol, what=what, rel=worst, rtol=rtol)
         limit = ELEMENTWISE_FACTOR * rtol if elem_rtol is None else elem_rtol
         if worst > limit:
             raise AssertionError(
@@ -86,10 +108,12 @@ def assert_close(actual, expected, rtol=1e-5, what="", atol=0.0, elem_rtol=None)
 
 
 def pytest_terminal_summary(terminalreporter):
-    if WORST["ratio"] > 0:
+    if WORST:
         terminalreporter.write_line(
-            f"assert_close: worst element-wise relative error on entries >= {ELEMENTWISE_FLOOR:g} * max|e|: "
-            f"{WORST['rel']:.3e} = {WORST['ratio']:.1f} x rtol ({WORST['rtol']:g}) in '{WORST['what']}'")
+            f"assert_close: worst element-wise relative error on entries >= {ELEMENTWISE_FLOOR:g} * max|e|, per class of comparison:")
+        for cat, w in sorted(WORST.items(), key=lambda kv: -kv[1]["ratio"]):
+            terminalreporter.write_line(
+                f"  {cat:38s} {w['rel']:.3e} = {w['ratio']:6.1f} x rtol ({w['rtol']:g}) in '{w['what']}'")
 
 
 def adagrad_well_conditioned(actual, expected, grad, gmax=None, floor=1e-4):

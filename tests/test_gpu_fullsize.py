@@ -91,16 +91,23 @@ def test_fm_forward_permutation_invariance_full_size(setup):
     assert_close(logits.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, what="FM logits at full size")
 
 
-def test_fused_step_matches_dense_restatement_full_size(setup):
+_FUSED_STEP_RESULT = {}
+
+
+@pytest.mark.parametrize("line_rows", [False, True], ids=["rows_back_to_back", "rows_in_whole_lines"])
+def test_fused_step_matches_dense_restatement_full_size(setup, line_rows):
     """One fused SGD step with global clip 1.0 at the benchmark size against dense gradients,
     clip_grad_norm_ and a dense SGD update made of plain torch ops; rows that the batch does not
-    touch must stay bit-identical."""
+    touch must stay bit-identical.  ``line_rows``: the layout bench.py times (every row in a 128-byte
+    line of its own with the bias entry behind it) -- same parameters and arithmetic, so the two
+    layouts must also agree with each other bit for bit (loss, norm, every weight)."""
     from recsys_amd.models import fields
     from recsys_amd.optim import FusedOptimizer
     dims, batch, dev = setup["dims"], setup["batch"], setup["dev"]
     torch.manual_seed(0)
     with torch.device(dev):
-        m = fields.FieldFM(dims, D)
+        m = fields.FieldFM(dims, D, line_rows=line_rows)
+    assert m.lines_packed() == line_rows
     w0, b0 = m.feature_embedding.weight.detach().clone(), m.bias_embedding.weight.detach().clone()
     # reference: autograd through plain torch ops, dense gradients
     wr, br = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
@@ -116,6 +123,7 @@ def test_fused_step_matches_dense_restatement_full_size(setup):
     with torch.no_grad():
         wr -= lr * wr.grad
         br -= lr * br.grad
+    del e, s, logits
     # fused path
     opt = FusedOptimizer(m, kind="sgd", lr=lr, clip_norm=1.0)
     m.train()
@@ -131,6 +139,16 @@ def test_fused_step_matches_dense_restatement_full_size(setup):
     assert torch.equal(w1[~touched], w0[~touched]) and torch.equal(b1[~touched], b0[~touched]), "untouched rows moved"
     assert_close(w1[touched].cpu().numpy(), wr.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated rows")
     assert_close(b1[touched].cpu().numpy(), br.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated bias rows")
+    if line_rows:   # the padding behind the bias entry stays zero: the update writes the line whole
+        buf = w1.as_strided((sum(dims), 2 * D), (2 * D, 1), w1.storage_offset())
+        assert not buf[:, D + 1:].any(), "padding columns of a line were written"
+    mine = (loss.detach().clone(), opt.last_total_norm.clone(), w1[touched].contiguous().clone(), b1[touched].contiguous().clone())
+    other = _FUSED_STEP_RESULT.get(not line_rows)
+    _FUSED_STEP_RESULT[line_rows] = mine
+    if other is not None:
+        for a, b, what in zip(mine, other, ("loss", "norm", "rows", "bias rows")):
+            assert torch.equal(a, b), f"{what}: the two table layouts disagree bitwise"
+        _FUSED_STEP_RESULT.clear()
 
 
 def test_fused_step_on_table_beyond_2G_elements():

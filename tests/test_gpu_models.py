@@ -149,7 +149,7 @@ def _oracle_case(name, dim, B, N, seed, n_users=6040, n_items=3706, n_occ=21, ma
 @pytest.mark.parametrize("name,dim,B,N", [
     ("VanillaMF", 64, 1024, 5), ("BiasMF", 32, 512, 5), ("SideFeaturesMF", 64, 512, 5), ("TemporalMF", 64, 777, 5),
     ("FactorizationMachine", 16, 2048, 5), ("FactorizationMachine", 128, 300, 1), ("GMF", 64, 1024, 5),
-    ("MLP", 64, 1024, 5), ("NeuMF", 64, 2048, 5), ("WidenDeep", 16, 1024, 5),
+    ("MLP", 64, 1024, 5), ("NeuMF", 64, 2048, 5), ("NeuMF", 64, 8192, 5), ("WidenDeep", 16, 1024, 5),
     ("DeepFactorizationMachine", 16, 1024, 5), ("VanillaMF", 20, 100, 100), ("NeuMF", 8, 33, 100),
 ])
 def test_oracle_parity_ml1m_shapes(name, dim, B, N):

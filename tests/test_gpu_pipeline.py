@@ -338,6 +338,57 @@ def test_round_graph_matches_eager_bitwise(name):
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("name", ["FieldFM_line_rows", "FieldFM", "VanillaMF"])
+def test_segment_graphs_match_eager_bitwise(name):
+    """The launch structure bench.py times: ``cycle_len`` < number of resident batches, i.e. one graph per
+    SEGMENT of consecutive slots (here 3 + 3 + 2 over 8 batches) with the index preparation of the next
+    slot running ahead on the side stream across segment boundaries, mixed with single-step replays.
+    Three rounds in cyclic slot order give the same weights, bit for bit, as eager steps."""
+    from recsys_amd import ops, synthetic
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.models.fields import FieldFM
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    dims = [7, 1000, 13, 5000, 3, 211]
+    K = 8
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(6)
+        with torch.device("cuda"):
+            if name.startswith("FieldFM"):
+                m = FieldFM(dims, 16, line_rows=name.endswith("line_rows"))
+                batches = [synthetic.criteo_batch(dims, 300, seed=40 + i, device="cuda") for i in range(K)]
+            else:
+                m = VanillaMF(d["n_users"], d["n_items"], 16)
+                batches = [synthetic.ml1m_batch(256, seed=20 + i, device="cuda") for i in range(K)]
+        m.train()
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True, cycle=True, cycle_len=3)
+                gs.add_batches(batches)
+                assert sorted(gs.segments) == [0, 3, 6] and [gs.segment_at(s) for s in (0, 3, 6)] == [3, 3, 2]
+                assert gs.segment_at(1) == 0
+                gs(0); gs(1); gs(2)                                   # round 1: single steps, then segments
+                gs.run_cycle(3); gs.run_cycle(6)
+                gs.run_cycle(0); gs(3); gs(4); gs(5); gs.run_cycle(6)  # round 2: mixed
+                gs.run_cycle(0); gs.run_cycle(3); gs(6); gs(7)         # round 3
+                loss = gs.losses[7]
+            else:
+                for i in [0, 0] + list(range(K)) * 3:
+                    opt.zero_grad(); loss = m.loss(batches[i]); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_sharded_fm_one_rank_through_rccl():
     """A one-rank process group on the nccl (RCCL) backend with the collectives forced on: the
     all-to-all calls, their split-size handling and dtypes run for real on the GPU, and the step
@@ -683,7 +734,7 @@ def test_device_loader_epochs_are_reproducible_from_the_seed():
 
 
 @pytest.mark.parametrize("feed", ["loader", "batches"])
-@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF", "NeuMF"])
+@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF", "NeuMF", "VanillaMF_without_prepare"])
 def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
     """utils.LoopGraph: two epochs with the step replayed as a graph give the same weights and epoch
     losses, bit for bit, as the eager loop on the same seeded loader -- both when the recorded step
@@ -706,6 +757,11 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
         if name == "NeuMF":      # two-stream model (GMF half on a branch); no dropout: its masks differ between graph and eager
             from recsys_amd.models.neuralcf import NeuMF
             model = NeuMF(data.n_users, data.n_items, 16, dropout=0.0).cuda().train()
+        elif name == "VanillaMF_without_prepare":
+            class Unprepared(mf.VanillaMF):
+                def _index_lists(self, inputs):
+                    return []
+            model = Unprepared(**kw).cuda().train()
         else:
             model = getattr(mf, name)(**kw).cuda().train()
         opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
