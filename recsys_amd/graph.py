@@ -28,12 +28,82 @@ Dense Adam keeps its step count in device memory and advances it inside the reco
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import torch
 
 from . import ops
 from .autograd import backward_from_loss, clear_capture_sort_cache, clear_sort_cache
+
+
+def _prep_stream(dev) -> "torch.cuda.Stream":
+    """The one stream per device on which recordings fork the next batch's index preparation (a new
+    stream per recording would leave the process with as many HIP streams as it has graphs, all
+    multiplexed onto the device's few hardware queues)."""
+    from .autograd import _side_stream_for
+    return _side_stream_for("prep", dev)
+
+
+_MAX_WIDTH = int(os.environ.get("RX_GRAPH_MAX_WIDTH", 2))
+_hip = None
+
+
+def recorded_shape(g: "torch.cuda.CUDAGraph") -> dict:
+    """Nodes, edges, roots and the widest level (longest-path layering: the nodes of one level cannot
+    reach one another, so a launch may run that many at once) of a recording made with
+    ``keep_graph=True``, from the runtime's own queries (hipGraphGetNodes / hipGraphGetEdges)."""
+    global _hip
+    import collections
+    import ctypes as C
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+    raw = C.c_void_p(g.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if _hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (C.c_void_p * max(n.value, 1))()
+    _hip.hipGraphGetNodes(raw, nodes, C.byref(n))
+    ne = C.c_size_t(0)
+    if _hip.hipGraphGetEdges(raw, None, None, C.byref(ne)) != 0:
+        raise RuntimeError("hipGraphGetEdges failed")
+    src, dst = (C.c_void_p * max(ne.value, 1))(), (C.c_void_p * max(ne.value, 1))()
+    _hip.hipGraphGetEdges(raw, src, dst, C.byref(ne))
+    succ, indeg = collections.defaultdict(list), collections.Counter()
+    for i in range(ne.value):
+        succ[src[i]].append(dst[i])
+        indeg[dst[i]] += 1
+    names = [nodes[i] for i in range(n.value)]
+    level = {x: 0 for x in names if indeg[x] == 0}
+    roots, todo = len(level), list(level)
+    while todo:
+        x = todo.pop()
+        for y in succ[x]:
+            level[y] = max(level.get(y, 0), level[x] + 1)
+            indeg[y] -= 1
+            if indeg[y] == 0:
+                todo.append(y)
+    per_level = collections.Counter(level.values())
+    return {"nodes": n.value, "edges": ne.value, "roots": roots, "widest_level": max(per_level.values(), default=0)}
+
+
+def _new_graph() -> "torch.cuda.CUDAGraph":
+    return torch.cuda.CUDAGraph(keep_graph=True) if _MAX_WIDTH > 0 else torch.cuda.CUDAGraph()
+
+
+def _check_width(g: "torch.cuda.CUDAGraph", what: str) -> None:
+    """Refuse a recording in which more than ``RX_GRAPH_MAX_WIDTH`` (default 2) kernels can run at once.
+    Replays of three-wide recordings of these steps (a valid DAG of kernel nodes only, one edge fewer
+    than its two-wide form) ended in a host segmentation fault inside hipGraphLaunch now and then on
+    this runtime (4 hardware queues per process); two-wide ones have not.  0 switches the check off."""
+    if _MAX_WIDTH <= 0:
+        return
+    shape = recorded_shape(g)
+    if shape["widest_level"] > _MAX_WIDTH:
+        raise RuntimeError(f"{what}: the recorded step has {shape['widest_level']} concurrent branches "
+                           f"({shape['nodes']} nodes, {shape['roots']} roots); at most {_MAX_WIDTH} are replayed "
+                           "(RX_GRAPH_MAX_WIDTH)")
+    g.instantiate()
 
 
 class GraphedTrainStep:
@@ -84,13 +154,13 @@ class GraphedTrainStep:
         K = len(prepared)
         shared = self._shared_branch(dev)
         for i, b in enumerate(prepared):
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             self.opt.zero_grad()
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
                 if shared is None:
-                    fork = torch.cuda.Stream(device=dev)
+                    fork = _prep_stream(dev)
                     fork.wait_stream(main)
                     with torch.cuda.stream(fork):
                         self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
@@ -102,6 +172,7 @@ class GraphedTrainStep:
                     with torch.cuda.stream(fork):
                         self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
                 main.wait_stream(fork)
+            _check_width(g, "GraphedTrainStep.add_batches")
             if self._pool is None:
                 self._pool = g.pool()
             self.graphs.append(g)
@@ -116,8 +187,8 @@ class GraphedTrainStep:
         branch's own work of the step, instead of on a forked stream of its own: a recorded step then has
         two concurrent branches, not three.  With three, replays crashed inside the HIP runtime now and
         then (a host segmentation fault in hipGraphLaunch)."""
-        if not getattr(self.model, "_branch_streams", False):
-            return None
+        if not getattr(self.model, "_branch_streams", False) or os.environ.get("RX_GRAPH_OWN_FORK") == "1":
+            return None     # (RX_GRAPH_OWN_FORK=1: the three-branch recording, for profiles/graph_shape_probe.py only)
         from .autograd import _side_stream_for
         return _side_stream_for("branch", dev)
 
@@ -127,13 +198,13 @@ class GraphedTrainStep:
         seg = self.cycle_len if 0 < self.cycle_len < K else K
         for first in range(0, K, seg):
             slots = list(range(first, min(first + seg, K)))
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             losses: List[torch.Tensor] = []
             self.opt.zero_grad()
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
-                fork = shared if shared is not None else torch.cuda.Stream(device=dev)
+                fork = shared if shared is not None else _prep_stream(dev)
                 fork.wait_stream(main)
                 ready = None          # preparation of the slot the next step consumes
                 done = {}             # slot -> event recorded after this graph's step on it
@@ -159,6 +230,7 @@ class GraphedTrainStep:
                     if shared is not None:      # behind this step's branch work on the branch's stream
                         ready = prepare_next(nxt)
                 main.wait_stream(fork)
+            _check_width(g, "GraphedTrainStep (multi-step segment)")
             self.segments[first] = (g, len(slots), losses)
         self.cycle_graph = self.segments[0][0]
         self.cycle_losses = self.segments[0][2]
@@ -193,13 +265,14 @@ class GraphedTrainStep:
                     self._eager(batch)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
+        g = _new_graph()
         self.opt.zero_grad()
         clear_sort_cache()   # the recording must hold its own sort kernels (see autograd.sorted_index)
         with torch.cuda.graph(g, pool=self._pool):
             loss = self._eager(batch)
             if epilogue is not None:
                 epilogue(loss)
+        _check_width(g, "GraphedTrainStep.add_batch")
         clear_sort_cache()   # memo entries made while recording point into the graph's pool
         if self._pool is None:
             self._pool = g.pool()
@@ -223,13 +296,13 @@ class GraphedTrainStep:
         prepared = [self.model.prepare(b) for b in batches]      # static preparation buffers (filled eagerly once)
 
         def record(order):
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             self.opt.zero_grad()
             clear_sort_cache()
             with torch.cuda.graph(g, pool=self._pool):
                 main = torch.cuda.current_stream(dev)
                 shared = self._shared_branch(dev)
-                fork = shared if shared is not None else torch.cuda.Stream(device=dev)     # one side stream for all steps of the recording
+                fork = shared if shared is not None else _prep_stream(dev)     # one side stream for all steps of the recording
                 for s in order:
                     fork.wait_stream(main)       # behind the hand-over that refilled batch 1 - s
                     if shared is None:
@@ -241,6 +314,7 @@ class GraphedTrainStep:
                             self.model.prepare(prepared[1 - s], out=prepared[1 - s])
                     epilogues[s](loss)
                     main.wait_stream(fork)
+            _check_width(g, "GraphedTrainStep.add_pair")
             clear_sort_cache()
             if self._pool is None:
                 self._pool = g.pool()
@@ -323,7 +397,7 @@ class ShardedGraphStep:
             torch.cuda.synchronize(device)
         K = len(self.batches)
         for i, b in enumerate(self.batches):
-            g = torch.cuda.CUDAGraph()
+            g = _new_graph()
             clear_sort_cache()
             # thread-local error mode: the process group's watchdog thread polls the events of earlier
             # collectives while this thread records, which the global mode turns into a capture error
@@ -346,6 +420,7 @@ class ShardedGraphStep:
                         model.prepare_static(self.batches[nxt], out=self.prepared[nxt])
                 else:
                     loss = step_fn(b)
+            _check_width(g, "ShardedGraphStep")
             clear_sort_cache()
             pool = pool or g.pool()
             self.graphs.append(g)

@@ -389,6 +389,35 @@ def test_segment_graphs_match_eager_bitwise(name):
         assert torch.equal(sa[k], sb[k]), k
 
 
+def test_recording_with_three_concurrent_branches_is_refused(monkeypatch):
+    """graph.py replays recordings of at most two concurrent branches (three-wide ones crashed the host
+    inside hipGraphLaunch now and then).  NeuMF already runs its GMF half on a second stream; with the
+    next batch's index sorts forced onto a third one the recording must be refused, and the same
+    model records fine with those sorts behind the GMF half."""
+    from recsys_amd import graph, ops, synthetic
+    from recsys_amd.models.neuralcf import NeuMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    torch.manual_seed(5)
+    with torch.device("cuda"):
+        m = NeuMF(d["n_users"], d["n_items"], 16, dropout=0.0)
+    m.train()
+    batches = [synthetic.ml1m_batch(256, seed=20 + i, device="cuda") for i in range(3)]
+    opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+    ops.set_index_check("deferred")
+    try:
+        gs = graph.GraphedTrainStep(m, opt, warmup=1, pipeline=True)
+        gs.add_batches(batches)
+        shape = graph.recorded_shape(gs.graphs[0])
+        assert shape["widest_level"] == 2 and shape["roots"] == 1 and shape["nodes"] > 20
+        monkeypatch.setenv("RX_GRAPH_OWN_FORK", "1")
+        with pytest.raises(RuntimeError, match="concurrent branches"):
+            graph.GraphedTrainStep(m, opt, warmup=0, pipeline=True).add_batches(batches)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_index_check("sync")
+
+
 def test_sharded_fm_one_rank_through_rccl():
     """A one-rank process group on the nccl (RCCL) backend with the collectives forced on: the
     all-to-all calls, their split-size handling and dtypes run for real on the GPU, and the step
