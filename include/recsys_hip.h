@@ -302,7 +302,9 @@ int rx_sort_dedup_fm(const rx_fm_args* a, int32_t* d_sorted_pos, int32_t* d_sort
  * d_sq_part (may be NULL) [rx_segreduce_grid(n, dim)] receives per-block sums of G_u^2.
  * ws: rx_segreduce_workspace_bytes(n, dim) bytes, 16-byte aligned (cross-piece partial sums). */
 enum { RX_SEG_DENSE = 0, RX_SEG_COMPACT = 1, RX_SEG_SGD = 2, RX_SEG_ADAGRAD = 3,
-       RX_SEG_ROWWISE_ADAGRAD = 4 };
+       RX_SEG_ROWWISE_ADAGRAD = 4,
+       RX_SEG_SGD_SPEC = 5,      /* rx_fg_reduce / rx_fg_row_update(_clip) only, see rx_fg_reduce_args.undo */
+       RX_SEG_SGD_SPEC_REDO = 6  /* rx_fg_row_update(_clip) only: redo the rows from their records whatever the factor */ };
 int64_t rx_segreduce_grid(int64_t n, int32_t dim);
 size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim);
 int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,
@@ -424,6 +426,20 @@ typedef struct {
                                               target2 == target + dim with ld_w2 == ld_w == 2 * dim (row and
                                               companion entry in one line, the rest of the line padding) makes
                                               the SGD update write whole lines: the padding is rewritten as 0 */
+  /* RX_SEG_SGD_SPEC, the clipped SGD step (recsys/utils.py:101-103: clip_grad_norm_ then step) in ONE pass
+   * over the distinct rows when the clip does not bite: the reduce takes the step with a clip factor of 1
+   * (multiplying by 1 is exact, so these are the bits of the clipped step whenever norm <= max_norm), writes
+   * sq_part, and leaves an undo record at each run's last position p:
+   *   undo [p, 0 .. dim) = G_u, undo[p, dim .. 2 dim) = the row before the step        ([B * n_fields, 2 * dim])
+   *   undo2[p, 0] = companion gradient, undo2[p, 1] = companion entry before the step  ([B * n_fields, 2])
+   * In the line layout (above) undo2 is NULL and the pair sits in the row's own line, columns dim + 1 and
+   * dim + 2.  rx_fg_row_update / rx_fg_row_update_clip with the same mode and d_compact = undo, d_compact2 =
+   * undo2 then end at once when the clip factor is exactly 1, and otherwise redo every row from its record as
+   * old - lr * (factor * G_u): bit for bit what RX_SEG_COMPACT + rx_fg_row_update(RX_SEG_SGD) leave.
+   * RX_SEG_SGD_SPEC_REDO (update calls only) redoes the rows even for a factor of 1: with a factor of 0 it puts
+   * the rows back as they were (a second backward pass before the step must read the old rows), and the step
+   * then applies such records with the final factor. */
+  float* undo; float* undo2;
 } rx_fg_reduce_args;
 int64_t rx_fg_reduce_grid(int64_t n, int32_t dim);
 size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim);

@@ -67,6 +67,20 @@ if D == 16:
     timed("line/fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(ltab, lbias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
     timed("line/fg_reduce", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=ltab, target2=comp2, want_sq=True, sq_out=sq))
     timed("line/fg_row_update", lambda i: ops.fg_row_update(comp, fgs[i % 4], _lib.RX_SEG_SGD, ltab, lr=0.05, scale=scale, compact2=comp2, table2=lbias))
+    # the clipped SGD step taken inside the reduce (undo records beside), and the second launch when the clip does
+    # not bite (every block forms the factor, finds 1 and ends) / when it does (rows redone from the records)
+    undo = torch.empty(B * nf, 32, device=dev)
+    timed("line/fg_reduce_spec", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_SGD_SPEC, ltab, target2=lbias, lr=1e-9, want_sq=True, sq_out=sq, undo=undo))
+    timed("line/fg_update_spec_idle", lambda i: ops.fg_row_update(undo, fgs[i % 4], _lib.RX_SEG_SGD_SPEC, ltab, lr=1e-9, table2=lbias, clip_parts=sq, max_norm=1e30))
+    timed("line/fg_update_spec_redo", lambda i: ops.fg_row_update(undo, fgs[i % 4], _lib.RX_SEG_SGD_SPEC, ltab, lr=1e-9, table2=lbias, clip_parts=sq, max_norm=1e-30))
+    if os.environ.get("ADJ") == "1":     # experiment: 256-byte row stride, the undo record in the line behind the row's (needs a -DFG_EXP_ADJ build)
+        del buf, ltab, lbias
+        buf4 = torch.zeros(base[-1], 64, device=dev)
+        buf4[:, :16].copy_(table)
+        atab, abias = buf4[:, :16], buf4[:, 16]
+        timed("adj/fm2_fwd_bce", lambda i: ops.fm2_fwd_bce(atab, abias, batches[i % 4][:, :nf - 1], ex_base, batches[i % 4][:, nf - 1:], base[nf - 1], labels))
+        timed("adj/fg_reduce", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_COMPACT, comp, table=atab, target2=comp2, want_sq=True, sq_out=sq))
+        timed("adj/fg_reduce_spec", lambda i: ops.fg_reduce(T, g, fgs[i % 4], _lib.RX_SEG_SGD_SPEC, atab, target2=abias, lr=1e-9, want_sq=True, sq_out=sq, undo=undo))
 if os.environ.get("SORTED") == "1":
     # the same ops on occurrence lists ordered by ascending row inside every field (any order that keeps a
     # row's occurrences together is valid input): what the bin order costs in memory locality

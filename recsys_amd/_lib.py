@@ -49,7 +49,8 @@ class FGReduceArgs(C.Structure):
     _fields_ = [("T", vp), ("ld_T", i64), ("g", vp), ("ld_g", i64), ("deep", vp), ("deep_ld", i64), ("B", i64),
                 ("n_fields", i32), ("dim", i32), ("mode", i32), ("premultiplied", i32), ("srow", vp), ("sb", vp),
                 ("target", vp), ("state", vp), ("table", vp), ("target2", vp), ("state2", vp), ("n_rows", i64),
-                ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp), ("ld_w", i64), ("ld_w2", i64)]
+                ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp), ("ld_w", i64), ("ld_w2", i64),
+                ("undo", vp), ("undo2", vp)]
 
 
 
@@ -176,7 +177,7 @@ PROTOTYPES = {
     "rx_topk_codes": (C.c_int, [vp, vp, i64, i32, i32, vp, C.c_int, vp]),
 }
 
-RX_SEG_DENSE, RX_SEG_COMPACT, RX_SEG_SGD, RX_SEG_ADAGRAD, RX_SEG_ROWWISE_ADAGRAD = range(5)
+RX_SEG_DENSE, RX_SEG_COMPACT, RX_SEG_SGD, RX_SEG_ADAGRAD, RX_SEG_ROWWISE_ADAGRAD, RX_SEG_SGD_SPEC, RX_SEG_SGD_SPEC_REDO = range(7)
 RX_ERR_INDEX = 1
 RX_ERR_CAPACITY = 2
 RX_ABI_VERSION = 1

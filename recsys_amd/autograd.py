@@ -361,6 +361,12 @@ def table_backward_fm(feat, bias_table, si, tsum, g, n_fields_ex: int, deep=None
     return grad, grad2
 
 
+def _before_table_read(param) -> None:
+    if getattr(param, "_rx_sparse", None) is not None:
+        from .optim import before_table_read
+        before_table_read(param)
+
+
 class FM2(Function):
     """FM bias + second-order term over one shared table (rx_fm2_fwd / _bwd).  Returns
     ``(logits[B,N] or None, deep[B*N, deep_cols] or None)``.  ``deep`` holds the gathered rows
@@ -370,6 +376,7 @@ class FM2(Function):
     @staticmethod
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, want_deep, second_order=True,
                 deep_cols=None, want_logits=True, extra=None, presort=None, field_base=None):
+        _before_table_read(feat)
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         n_items = item_idx.shape[1] if item_idx.dim() == 2 else 1
         # with one item per sample the backward needs only T_b = sum of the sample's rows (plus the
@@ -420,6 +427,7 @@ class FMLoss(Function):
 
     @staticmethod
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, labels, presort, field_base):
+        _before_table_read(feat)
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         loss, gt, _ = ops.fm2_fwd_bce(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, labels.contiguous())
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)

@@ -640,12 +640,22 @@ struct FgRed {
   const float* clip_parts; int64_t clip_n; float clip_max; float* clip_scale_out; float* clip_norm_out;
   int64_t ldw, ldw2;   // row strides of the table (a.table, or a.target in the update modes) and of the companion table
   int line;            // the companion entry sits right behind its row in a line of 2 * dim floats: SGD writes whole lines
+  float* undo;         // RX_SEG_SGD_SPEC: [positions][2 * dim] = gradient | the row before the step, at each run's last position
+  int force;           // RX_SEG_SGD_SPEC update: redo the rows even for a clip factor of 1 (they were put back before)
+  float* undo2;        // ... and [positions][2] = companion gradient | companion entry before the step (NULL in the line layout,
+                       //     where the two ride in the row's own line behind the entry)
 };
 
 // Second half of a row's line in the whole-line layout: the companion entry, then zeros.
 template <int GROUP>
 __device__ __forceinline__ void fg_store_line_tail(float* w_row, float v2, int lg) {
   *reinterpret_cast<float4*>(w_row + GROUP * 4 + lg * 4) = make_float4(lg == 0 ? v2 : 0.f, 0.f, 0.f, 0.f);
+}
+
+// The same in the speculative step: entry, its gradient and its value before the step, then zeros.
+template <int GROUP>
+__device__ __forceinline__ void fg_store_line_tail_undo(float* w_row, float v2, float g2, float old2, int lg) {
+  *reinterpret_cast<float4*>(w_row + GROUP * 4 + lg * 4) = lg == 0 ? make_float4(v2, g2, old2, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // Everything that happens once the sum of a run is known: G = sum_b g_b T_b (+ tower slices),
@@ -668,9 +678,30 @@ __device__ __forceinline__ float fg_finish(const FgRed& a, float4 G, float g2, f
     if (has2 && lg == 0) a.target2[at] = g2;
     return sq;
   }
-  G.x *= scale; G.y *= scale; G.z *= scale; G.w *= scale;
   float4 x = e;
   float* w = a.target + (int64_t)row * a.ldw + lg * 4;
+  if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    // The step as if the clip factor were 1 (times one is exact, so these are the bits of the clipped
+    // step whenever the norm stays inside the bound), plus what the second launch needs to redo the
+    // row exactly when it does not: the gradient and the row as it was.
+    // (records are written once and, unless the clip bites, never read: streaming stores keep them from
+    // displacing table lines in the cache -- 68 -> 60 us for this launch at B = 65536 x 26 fields)
+    float* u = a.undo + p * (2 * dim);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f Gv = {G.x, G.y, G.z, G.w}, ev = {e.x, e.y, e.z, e.w};
+    __builtin_nontemporal_store(Gv, reinterpret_cast<v4f*>(u + lg * 4));
+    __builtin_nontemporal_store(ev, reinterpret_cast<v4f*>(u + dim + lg * 4));
+    x.x = x.x - a.lr * G.x; x.y = x.y - a.lr * G.y; x.z = x.z - a.lr * G.z; x.w = x.w - a.lr * G.w;
+    const float new2 = old2 - a.lr * g2;
+    if (a.line) fg_store_line_tail_undo<GROUP>(a.target + (int64_t)row * a.ldw, new2, g2, old2, lg);
+    else if (has2 && lg == 0) {
+      a.target2[(int64_t)row * a.ldw2] = new2;
+      *reinterpret_cast<float2*>(a.undo2 + p * 2) = make_float2(g2, old2);
+    }
+    *reinterpret_cast<float4*>(w) = x;
+    return sq;
+  }
+  G.x *= scale; G.y *= scale; G.z *= scale; G.w *= scale;
   if constexpr (MODE == RX_SEG_SGD) {
     x.x = x.x - a.lr * G.x; x.y = x.y - a.lr * G.y; x.z = x.z - a.lr * G.z; x.w = x.w - a.lr * G.w;
     const float new2 = old2 - a.lr * (g2 * scale);
@@ -766,7 +797,7 @@ fg_reduce_kernel(FgRed a) {
       old2[s] = 0.f;
       if (endf[s]) {
         e[s] = *reinterpret_cast<const float4*>(tab + (int64_t)rw[s + 1] * a.ldw + lg * 4);
-        if (MODE == RX_SEG_SGD && has2 && lg == 0) old2[s] = a.target2[(int64_t)rw[s + 1] * a.ldw2];
+        if ((MODE == RX_SEG_SGD || MODE == RX_SEG_SGD_SPEC) && has2 && lg == 0) old2[s] = a.target2[(int64_t)rw[s + 1] * a.ldw2];
       }
     }
 #pragma unroll
@@ -901,7 +932,7 @@ fg_combine_kernel(FgRed a, int64_t n_windows) {
   const bool shortrun = has_tail && !(meta1 & FG_META_GOES_ON);
   if (shortrun) {
     const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)tail * a.ldw + lg * 4);
-    const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[(int64_t)tail * a.ldw2] : 0.f;
+    const float old2 = ((MODE == RX_SEG_SGD || MODE == RX_SEG_SGD_SPEC) && a.target2 && lg == 0) ? a.target2[(int64_t)tail * a.ldw2] : 0.f;
     G.x += H.x; G.y += H.y; G.z += H.z; G.w += H.w;
     const int64_t p_end = (win + 1) * W + (int64_t)(meta1 & 0xFFFFu) - 1;
     sq += fg_finish<GROUP, MODE>(a, G, g2a + g2b, e, old2, tail, p_end, lg, scale);
@@ -945,7 +976,7 @@ fg_combine_kernel(FgRed a, int64_t n_windows) {
     }
     if (slot == 0) {
       const float4 e = *reinterpret_cast<const float4*>(tab + (int64_t)row * a.ldw + lg * 4);
-      const float old2 = (MODE == RX_SEG_SGD && a.target2 && lg == 0) ? a.target2[(int64_t)row * a.ldw2] : 0.f;
+      const float old2 = ((MODE == RX_SEG_SGD || MODE == RX_SEG_SGD_SPEC) && a.target2 && lg == 0) ? a.target2[(int64_t)row * a.ldw2] : 0.f;
       sq += fg_finish<GROUP, MODE>(a, A, a2, e, old2, row, p_end, lg, scale);
     }
   }
@@ -995,10 +1026,17 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
   float scale = 1.f;
   if constexpr (CLIP) scale = fg_clip_scale(a, clip_wsum);   // before any thread leaves: it holds a block barrier
   else scale = a.scale ? a.scale[0] : 1.f;
-  const int64_t gid = ((int64_t)blockIdx.x * RX_BLOCK + threadIdx.x) / GROUP;
+  if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    // the reduce already took the step with a factor of 1: nothing to do unless the clip bites
+    if (scale == 1.f && !a.force) return;
+  }
   const int lg = threadIdx.x % GROUP;
+  // (the speculative step launches a small grid that strides over the list: in the common case every block
+  // only forms the clip factor and ends, so few blocks make that cheap; the other modes launch one lane
+  // group per FG_UPD positions and take the loop once)
+  for (int64_t gid = ((int64_t)blockIdx.x * RX_BLOCK + threadIdx.x) / GROUP; gid * FG_UPD < a.n;
+       gid += (int64_t)gridDim.x * (RX_BLOCK / GROUP)) {
   const int64_t p0 = gid * FG_UPD;
-  if (p0 >= a.n) return;
   const bool has2 = a.target2 != nullptr;
   uint32_t row[FG_UPD + 1];
   if (p0 + FG_UPD < a.n) {
@@ -1017,11 +1055,25 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
     endf[j] = row[j] != FG_NONE && row[j] != row[j + 1] && (int64_t)row[j] < a.n_rows;
     g2[j] = 0.f; old2[j] = 0.f;
     if (endf[j]) {
-      G[j] = *reinterpret_cast<const float4*>(compact + (p0 + j) * DIM + lg * 4);
-      x[j] = *reinterpret_cast<const float4*>(a.target + (int64_t)row[j] * a.ldw + lg * 4);
-      if (has2 && lg == 0) {
-        g2[j] = compact2[p0 + j];
-        if (MODE == RX_SEG_SGD) old2[j] = a.target2[(int64_t)row[j] * a.ldw2];
+      if constexpr (MODE == RX_SEG_SGD_SPEC) {   // gradient and the row before the step, side by side
+        G[j] = *reinterpret_cast<const float4*>(compact + (p0 + j) * (2 * DIM) + lg * 4);
+        x[j] = *reinterpret_cast<const float4*>(compact + (p0 + j) * (2 * DIM) + DIM + lg * 4);
+        if (has2 && lg == 0) {
+          if (a.line) {
+            const float4 t = *reinterpret_cast<const float4*>(a.target + (int64_t)row[j] * a.ldw + DIM);
+            g2[j] = t.y; old2[j] = t.z;
+          } else {
+            const float2 t = *reinterpret_cast<const float2*>(compact2 + (p0 + j) * 2);
+            g2[j] = t.x; old2[j] = t.y;
+          }
+        }
+      } else {
+        G[j] = *reinterpret_cast<const float4*>(compact + (p0 + j) * DIM + lg * 4);
+        x[j] = *reinterpret_cast<const float4*>(a.target + (int64_t)row[j] * a.ldw + lg * 4);
+        if (has2 && lg == 0) {
+          g2[j] = compact2[p0 + j];
+          if (MODE == RX_SEG_SGD) old2[j] = a.target2[(int64_t)row[j] * a.ldw2];
+        }
       }
     }
   }
@@ -1031,11 +1083,13 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
     const uint32_t r = row[j];
     float4 g = G[j], w = x[j];
     g.x *= scale; g.y *= scale; g.z *= scale; g.w *= scale;
-    if constexpr (MODE == RX_SEG_SGD) {
+    if constexpr (MODE == RX_SEG_SGD || MODE == RX_SEG_SGD_SPEC) {
       w.x = w.x - a.lr * g.x; w.y = w.y - a.lr * g.y; w.z = w.z - a.lr * g.z; w.w = w.w - a.lr * g.w;
       const float new2 = old2[j] - a.lr * (g2[j] * scale);
-      if (a.line) fg_store_line_tail<GROUP>(a.target + (int64_t)r * a.ldw, new2, lg);   // lane 0 of the group holds the entry
-      else if (has2 && lg == 0) a.target2[(int64_t)r * a.ldw2] = new2;
+      if (a.line) {
+        if constexpr (MODE == RX_SEG_SGD_SPEC) fg_store_line_tail_undo<GROUP>(a.target + (int64_t)r * a.ldw, new2, g2[j], old2[j], lg);
+        else fg_store_line_tail<GROUP>(a.target + (int64_t)r * a.ldw, new2, lg);   // lane 0 of the group holds the entry
+      } else if (has2 && lg == 0) a.target2[(int64_t)r * a.ldw2] = new2;
     } else if constexpr (MODE == RX_SEG_ADAGRAD) {
       float* sp = a.state + (int64_t)r * DIM + lg * 4;
       float4 s = *reinterpret_cast<const float4*>(sp);
@@ -1043,7 +1097,7 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
       w.x -= a.lr * (g.x / (sqrtf(s.x) + a.eps)); w.y -= a.lr * (g.y / (sqrtf(s.y) + a.eps));
       w.z -= a.lr * (g.z / (sqrtf(s.z) + a.eps)); w.w -= a.lr * (g.w / (sqrtf(s.w) + a.eps));
       *reinterpret_cast<float4*>(sp) = s;
-    } else {
+    } else if constexpr (MODE == RX_SEG_ROWWISE_ADAGRAD) {
       float q = g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
       q = rx_group_sum(q, GROUP);
       const float s_new = a.state[r] + q / (float)DIM;
@@ -1060,6 +1114,7 @@ fg_row_update_kernel(FgRed a, const float* __restrict__ compact, const float* __
       }
     }
     *reinterpret_cast<float4*>(a.target + (int64_t)r * a.ldw + lg * 4) = w;
+  }
   }
 }
 
@@ -1101,6 +1156,7 @@ extern "C" size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim) {
       case RX_SEG_COMPACT: FG_LAUNCH_MODE(GROUPV, RX_SEG_COMPACT); break;              \
       case RX_SEG_SGD: FG_LAUNCH_MODE(GROUPV, RX_SEG_SGD); break;                      \
       case RX_SEG_ADAGRAD: FG_LAUNCH_MODE(GROUPV, RX_SEG_ADAGRAD); break;              \
+      case RX_SEG_SGD_SPEC: FG_LAUNCH_MODE(GROUPV, RX_SEG_SGD_SPEC); break;            \
       default: FG_LAUNCH_MODE(GROUPV, RX_SEG_ROWWISE_ADAGRAD); break;                  \
     }                                                                                  \
   } while (0)
@@ -1112,7 +1168,7 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
   const int n_fields = r->n_fields, dim = r->dim, mode = r->mode;
   RX_REQUIRE(B >= 0 && n_fields >= 1 && n_fields <= RX_FG_MAX_FIELDS, "rx_fg_reduce: bad shape");
   RX_REQUIRE(fg_group_of(dim), "rx_fg_reduce: dim %d unsupported (16, 32, 64 or 128)", dim);
-  RX_REQUIRE(mode >= RX_SEG_DENSE && mode <= RX_SEG_ROWWISE_ADAGRAD, "rx_fg_reduce: unknown mode %d", mode);
+  RX_REQUIRE(mode >= RX_SEG_DENSE && mode <= RX_SEG_SGD_SPEC, "rx_fg_reduce: unknown mode %d", mode);
   const int64_t n = B * n_fields;
   if (n == 0) return 0;
   RX_REQUIRE(n < (1ll << 31), "rx_fg_reduce: too many occurrences");
@@ -1135,7 +1191,13 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
   a.target2 = r->target2; a.state2 = r->state2; a.n_rows = r->n_rows; a.lr = r->lr; a.eps = r->eps; a.scale = r->scale; a.sq_part = r->sq_part;
   a.ldw = r->ld_w ? r->ld_w : dim; a.ldw2 = r->ld_w2 ? r->ld_w2 : 1;
   RX_REQUIRE(a.ldw >= dim && a.ldw % 4 == 0 && a.ldw2 >= 1, "rx_fg_reduce: table row stride must be a multiple of 4 floats and >= dim");
-  a.line = !grad_mode && mode == RX_SEG_SGD && r->target2 && r->target2 == r->target + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
+  a.line = !grad_mode && (mode == RX_SEG_SGD || mode == RX_SEG_SGD_SPEC) && r->target2 && r->target2 == r->target + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
+  if (mode == RX_SEG_SGD_SPEC) {
+    RX_REQUIRE(r->undo && rx_aligned16(r->undo), "rx_fg_reduce: the speculative step needs its (16-byte aligned) undo buffer [B * n_fields, 2 * dim]");
+    RX_REQUIRE(!r->target2 || a.line || (r->undo2 && ((uintptr_t)r->undo2 & 7) == 0), "rx_fg_reduce: the speculative step needs undo2 [B * n_fields, 2] for a companion table outside the row's line");
+    RX_REQUIRE(!a.line || dim >= 4, "rx_fg_reduce: line layout needs room for the undo pair");
+    a.undo = r->undo; a.undo2 = a.line ? nullptr : r->undo2;
+  }
   const size_t nw = (size_t)fg_windows(n, dim);
   char* w = (char*)ws;
   a.partials = (float*)w; w += rx_align_up(nw * 2 * dim * sizeof(float), 256);
@@ -1156,10 +1218,15 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
   return 0;
 }
 
+#define FG_SPEC_GRID 512   /* blocks of the speculative step's second launch (two per CU) */
 #define FG_UPDATE_GROUP(GROUPV)                                                                                                        \
   do {                                                                                                                                 \
     const unsigned grid = (unsigned)rx_cdiv(rx_cdiv(n, FG_UPD) * GROUPV, RX_BLOCK);                                                    \
-    if (a.clip_parts) {                                                                                                               \
+    if (mode == RX_SEG_SGD_SPEC) {                                                                                                    \
+      const unsigned sgrid = grid < FG_SPEC_GRID ? grid : FG_SPEC_GRID;                                                                \
+      if (a.clip_parts) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD_SPEC, true>), dim3(sgrid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+      else hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD_SPEC>), dim3(sgrid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
+    } else if (a.clip_parts) {                                                                                                        \
       if (mode == RX_SEG_SGD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_SGD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
       else if (mode == RX_SEG_ADAGRAD) hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ADAGRAD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
       else hipLaunchKernelGGL((fg_row_update_kernel<GROUPV, RX_SEG_ROWWISE_ADAGRAD, true>), dim3(grid), dim3(RX_BLOCK), 0, st, a, d_compact, d_compact2); \
@@ -1200,18 +1267,24 @@ static int fg_row_update_run(const float* d_compact, int32_t dim, const uint32_t
                              int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n >= 0 && fg_group_of(dim), "rx_fg_row_update: bad shape (dim 16, 32, 64 or 128)");
-  RX_REQUIRE(mode >= RX_SEG_SGD && mode <= RX_SEG_ROWWISE_ADAGRAD, "rx_fg_row_update: unknown mode %d", mode);
-  RX_REQUIRE((d_compact2 == nullptr) == (d_w2 == nullptr), "rx_fg_row_update: companion gradient and table come as a pair");
+  RX_REQUIRE(mode >= RX_SEG_SGD && mode <= RX_SEG_SGD_SPEC_REDO, "rx_fg_row_update: unknown mode %d", mode);
+  const bool force = mode == RX_SEG_SGD_SPEC_REDO;
+  if (force) mode = RX_SEG_SGD_SPEC;
+  const bool spec_line = mode == RX_SEG_SGD_SPEC && d_w2 && d_w2 == d_w + dim && (ld_w ? ld_w : dim) == 2 * dim && (ld_w2 ? ld_w2 : 1) == 2 * dim;
+  RX_REQUIRE(spec_line ? d_compact2 == nullptr : (d_compact2 == nullptr) == (d_w2 == nullptr),
+             "rx_fg_row_update: companion gradient and table come as a pair (the speculative step in the line layout keeps the pair in the line)");
+  RX_REQUIRE(mode != RX_SEG_SGD_SPEC || d_scale || d_parts, "rx_fg_row_update: the speculative step needs the clip factor or the partial sums");
   if (n == 0) return 0;
   RX_REQUIRE(d_compact && d_srow && d_w && rx_aligned16(d_compact) && rx_aligned16(d_w) && rx_aligned16(d_srow), "rx_fg_row_update: null or unaligned argument");
-  RX_REQUIRE(mode == RX_SEG_SGD || (d_state && (!d_w2 || d_state2)), "rx_fg_row_update: Adagrad needs its state buffers");
+  RX_REQUIRE(mode == RX_SEG_SGD || mode == RX_SEG_SGD_SPEC || (d_state && (!d_w2 || d_state2)), "rx_fg_row_update: Adagrad needs its state buffers");
   RX_REQUIRE(n_rows >= 1, "rx_fg_row_update: n_rows must be positive");
   FgRed a{};
   a.srow = d_srow; a.n = n; a.dim = dim; a.target = d_w; a.state = d_state; a.target2 = d_w2; a.state2 = d_state2;
   a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
   a.ldw = ld_w ? ld_w : dim; a.ldw2 = ld_w2 ? ld_w2 : 1;
   RX_REQUIRE(a.ldw >= dim && a.ldw % 4 == 0 && a.ldw2 >= 1, "rx_fg_row_update: table row stride must be a multiple of 4 floats and >= dim");
-  a.line = mode == RX_SEG_SGD && d_w2 && d_w2 == d_w + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
+  a.line = (mode == RX_SEG_SGD || mode == RX_SEG_SGD_SPEC) && d_w2 && d_w2 == d_w + dim && a.ldw == 2 * dim && a.ldw2 == a.ldw;
+  a.force = force ? 1 : 0;
   a.clip_parts = d_parts; a.clip_n = n_parts; a.clip_max = max_norm; a.clip_scale_out = d_scale_out; a.clip_norm_out = d_norm_out;
   hipStream_t st = (hipStream_t)stream;
   switch (fg_group_of(dim)) {

@@ -686,9 +686,13 @@ def fg_reduce_grid(n: int, dim: int) -> int:
 def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tensor, *, table: Optional[Tensor] = None,
               state: Optional[Tensor] = None, target2: Optional[Tensor] = None, state2: Optional[Tensor] = None,
               lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None, want_sq: bool = False,
-              sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None, premultiplied: bool = False) -> Optional[Tensor]:
+              sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None, premultiplied: bool = False,
+              undo: Optional[Tensor] = None, undo2: Optional[Tensor] = None) -> Optional[Tensor]:
     """rx_fg_reduce: the N == 1 FM backward over a field-grouped occurrence list (see FieldGroups).
     In RX_SEG_COMPACT mode ``target`` / ``target2`` have one row per POSITION (fg.n rows).
+    RX_SEG_SGD_SPEC (the clipped SGD step taken at once with factor 1): ``undo`` [fg.n, 2 * dim] and, unless
+    the companion entry sits in the row's line, ``undo2`` [fg.n, 2] receive what fg_row_update needs to redo
+    the rows when the clip bites.
     ``tsum`` [B, dim] and ``g`` [B] may be column blocks of one wider matrix (unit inner stride for
     ``tsum``, any stride for ``g``); ``premultiplied``: ``tsum`` already holds g_b * T_b."""
     for t, name in ((tsum, "T"), (g, "g")):
@@ -728,6 +732,15 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
                     ("scale", scale), ("sq_part", sq)):
         setattr(a, name, 0 if t is None else t.data_ptr())
     a.n_rows, a.lr, a.eps = fg.n_rows, lr, eps
+    if mode == _lib.RX_SEG_SGD_SPEC:
+        _req(undo, torch.float32, "undo", 2)
+        if undo.shape[0] < fg.n or undo.shape[1] != 2 * dim:
+            raise ValueError("fg_reduce: undo must be [positions, 2 * dim]")
+        if undo2 is not None:
+            _req(undo2, torch.float32, "undo2", 2)
+            if undo2.shape[0] < fg.n or undo2.shape[1] != 2:
+                raise ValueError("fg_reduce: undo2 must be [positions, 2]")
+        a.undo, a.undo2 = undo.data_ptr(), (undo2.data_ptr() if undo2 is not None else 0)
     grad_mode = mode in (_lib.RX_SEG_COMPACT, _lib.RX_SEG_DENSE)
     a.ld_w, a.ld_w2 = _table_strides(table if grad_mode else target, None if grad_mode else target2, dim)
     ws = _ws(int(lib.rx_fg_reduce_workspace_bytes(fg.n, dim)), tsum.device)
@@ -766,18 +779,19 @@ def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *,
     squares; the launch forms the clip factor itself (rx_fg_row_update_clip) and (scale, norm) are
     returned as one-element tensors."""
     _req(compact, torch.float32, "compact", 2)
-    ld_w, ld_w2 = _table_strides(table, table2, compact.shape[1])
+    dim = compact.shape[1] // 2 if mode in (_lib.RX_SEG_SGD_SPEC, _lib.RX_SEG_SGD_SPEC_REDO) else compact.shape[1]    # the speculative step's undo records: gradient | old row
+    ld_w, ld_w2 = _table_strides(table, table2, dim)
     if clip_parts is not None:
         _req(clip_parts, torch.float32, "clip_parts")
         if scale is not None or not clip_parts.is_contiguous():
             raise ValueError("fg_row_update: give either a scale or contiguous partial sums")
         out = torch.empty(2, dtype=torch.float32, device=table.device)
-        check(lib.rx_fg_row_update_clip(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
+        check(lib.rx_fg_row_update_clip(_p(compact), dim, _p(fg.srow), fg.n, mode, _p(table), _p(state),
                                         _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(clip_parts),
                                         clip_parts.numel(), float(max_norm), _p(out[0:1]), _p(out[1:2]), ld_w, ld_w2,
                                         _dev(table), _stream(table)), "rx_fg_row_update_clip")
         return out[0:1], out[1:2]
-    check(lib.rx_fg_row_update(_p(compact), compact.shape[1], _p(fg.srow), fg.n, mode, _p(table), _p(state),
+    check(lib.rx_fg_row_update(_p(compact), dim, _p(fg.srow), fg.n, mode, _p(table), _p(state),
                                _p(compact2), _p(table2), _p(state2), fg.n_rows, lr, eps, _p(scale), ld_w, ld_w2,
                                _dev(table), _stream(table)), "rx_fg_row_update")
 

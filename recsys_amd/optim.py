@@ -25,6 +25,8 @@ from . import _lib, ops
 _SEPARATE_CLIP_LAUNCH = os.environ.get("RX_SEPARATE_CLIP") == "1"   # A/B timing of the clip factor formed inside the row update
 _ONE_LAUNCH_PER_TABLE = os.environ.get("RX_NO_MULTI_TABLE") == "1"   # A/B timing of the multi-table launches
 
+_NO_SPECULATION = os.environ.get("RX_NO_SPECULATIVE_SGD") == "1"   # A/B: clipped SGD over field groups always in two phases
+
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
 
 
@@ -77,12 +79,30 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
             ops.fg_reduce(tsum, g, si, self.mode, table, state=state, target2=table2, state2=state2,
                           lr=self.lr, eps=self.eps, deep=deep, premultiplied=premultiplied)
             return
-        compact = torch.empty(si.n, tsum.shape[1], dtype=torch.float32, device=table.device)
+        dim = tsum.shape[1]
+        sq_out = self.owner._sq_slice(si.n, dim, table.device, ops.fg_reduce_grid(si.n, dim))
+        if self.owner._pending:
+            # not the first backward pass since the last step (gradient accumulation): rows that an earlier
+            # pass of this step already moved go back first, and this pass keeps to the two-phase form
+            self.owner._restore_speculative()
+        elif self.kind == "sgd" and not _NO_SPECULATION and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr)):
+            # Clipped SGD in one pass over the distinct rows when the clip does not bite: the reduce takes the
+            # step with a factor of 1 and leaves undo records; step() redoes the rows only when the norm turns
+            # out to exceed the bound (rx_fg_reduce_args.undo).  Bit-identical to the two-phase form either way.
+            line = (bias_table is not None and table2.data_ptr() == table.data_ptr() + 4 * dim
+                    and table.stride(0) == 2 * dim and table2.stride(0) == 2 * dim)
+            undo = torch.empty(si.n, 2 * dim, dtype=torch.float32, device=table.device)
+            undo2 = torch.empty(si.n, 2, dtype=torch.float32, device=table.device) if bias_table is not None and not line else None
+            sq = ops.fg_reduce(tsum, g, si, _lib.RX_SEG_SGD_SPEC, table, target2=table2, lr=self.lr, want_sq=True, sq_out=sq_out,
+                               deep=deep, premultiplied=premultiplied, undo=undo, undo2=undo2)
+            self.owner._pending.append((self, feat, undo, si, sq, (rule2, bias_table, undo2) if bias_table is not None else None, "spec"))
+            self.owner._has_spec = True
+            return
+        compact = torch.empty(si.n, dim, dtype=torch.float32, device=table.device)
         compact2 = torch.empty(si.n, dtype=torch.float32, device=table.device) if bias_table is not None else None
         sq = ops.fg_reduce(tsum, g, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2, want_sq=True,
-                           sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device, ops.fg_reduce_grid(si.n, tsum.shape[1])),
-                           deep=deep, premultiplied=premultiplied)
-        self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
+                           sq_out=sq_out, deep=deep, premultiplied=premultiplied)
+        self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None, False))
         return
     if self.owner.clip_norm is None:
         ops.segreduce_fm(tsum, g, n_fields_ex, si, self.mode, table, state=state, target2=table2, state2=state2,
@@ -92,10 +112,20 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
     compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
     sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2,
                           want_sq=True, sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device), deep=deep)
-    self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None))
+    self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None, False))
 
 
 SparseRule.apply_fm = _rule_apply_fm
+
+
+def before_table_read(param) -> None:
+    """Called by the forward passes that gather from ``param``: rows that a speculative clipped step has
+    already moved (backward done, step() still to come) are put back first, so that whatever runs between
+    backward and step -- another forward + backward for gradient accumulation, an evaluation -- sees the
+    weights of before the step, as with torch.optim.SGD."""
+    rule = getattr(param, "_rx_sparse", None)
+    if rule is not None and rule.owner._has_spec:
+        rule.owner._restore_speculative()
 
 
 class FusedOptimizer:
@@ -125,6 +155,8 @@ class FusedOptimizer:
             p._rx_sparse = rule
             self.rules.append(rule)
         self._pending = []
+        self._has_spec = False                        # a pending entry whose rows the reduce already moved (speculative clipped SGD)
+        self._zero = None
         self._deferred = []                            # reduces queued by the backward while a clip is set
         self._sq_buf: Optional[torch.Tensor] = None   # norm partials of all table reduces of a step, back to back
         self._sq_used = 0
@@ -145,9 +177,27 @@ class FusedOptimizer:
             if hasattr(p, "_rx_sparse"):
                 del p._rx_sparse
 
+    def _restore_speculative(self):
+        """Put back the rows of pending speculative entries (factor 0 applied to their undo records) and
+        mark the entries: step() then redoes them with the final clip factor whatever its value."""
+        if not self._has_spec:
+            return
+        for k, e in enumerate(self._pending):
+            rule, param, undo, si, sq, comp, flag = e
+            if flag != "spec":
+                continue
+            if self._zero is None or self._zero.device != param.device:
+                self._zero = torch.zeros(1, dtype=torch.float32, device=param.device)
+            rule2, param2, undo2 = comp if comp is not None else (None, None, None)
+            ops.fg_row_update(undo, si, _lib.RX_SEG_SGD_SPEC_REDO, param.data, lr=rule.lr, scale=self._zero, compact2=undo2,
+                              table2=param2.data if param2 is not None else None)
+            self._pending[k] = (rule, param, undo, si, sq, comp, "redo")
+        self._has_spec = False
+
     def zero_grad(self, set_to_none: bool = True):
         for p in self.dense:
             p.grad = None
+        self._restore_speculative()        # gradients dropped without a step: the rows go back
         self._pending.clear()
         self._deferred.clear()
         self._sq_used = 0
@@ -178,7 +228,7 @@ class FusedOptimizer:
                 if sq is None:
                     sq = torch.empty(ops.segreduce_grid(si.n, d), dtype=torch.float32, device=dev)
                 items.append(ops.TableReduce(occ, si, compact, d, occ_ld=occ_ld, occ2=occ2, target2=compact2, sq=sq))
-                made.append((rule, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None))
+                made.append((rule, param, compact, si, sq, (rule2, param2, compact2) if param2 is not None else None, False))
             ops.segreduce_multi(items, _lib.RX_SEG_COMPACT)
             self._pending.extend(made)
 
@@ -187,10 +237,13 @@ class FusedOptimizer:
         factor, or unscaled when the clip was switched off between backward and step.  Tables of one
         width and rule share a launch."""
         plain = []
-        for (rule, param, compact, si, _, comp) in self._pending:
+        for (rule, param, compact, si, _, comp, spec) in self._pending:
             if isinstance(si, ops.FieldGroups):
                 rule2, param2, compact2 = comp if comp is not None else (None, None, None)
-                ops.fg_row_update(compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr,
+                if spec == "spec" and scale is None:
+                    continue        # the clip was switched off after the backward pass: the rows already hold the plain step
+                mode = {"spec": _lib.RX_SEG_SGD_SPEC, "redo": _lib.RX_SEG_SGD_SPEC_REDO}.get(spec, rule.mode)
+                ops.fg_row_update(compact, si, mode, param.data, state=rule._state_for(param), lr=rule.lr,
                                   eps=rule.eps, scale=scale, compact2=compact2,
                                   table2=param2.data if param2 is not None else None,
                                   state2=rule2._state_for(param2) if rule2 is not None else None)
@@ -327,10 +380,10 @@ class FusedOptimizer:
                     and len(parts) == 1 and parts[0].is_contiguous() and not _SEPARATE_CLIP_LAUNCH):
                 # one field-grouped table and nothing else (the FM): every block of the row update adds the
                 # partial sums itself, which takes the one-block clip launch off the step's critical path
-                rule, param, compact, si, _, comp = e0
+                rule, param, compact, si, _, comp, spec = e0
                 rule2, param2, compact2 = comp if comp is not None else (None, None, None)
                 scale, self.last_total_norm = ops.fg_row_update(
-                    compact, si, rule.mode, param.data, state=rule._state_for(param), lr=rule.lr, eps=rule.eps,
+                    compact, si, {"spec": _lib.RX_SEG_SGD_SPEC, "redo": _lib.RX_SEG_SGD_SPEC_REDO}.get(spec, rule.mode), param.data, state=rule._state_for(param), lr=rule.lr, eps=rule.eps,
                     compact2=compact2, table2=param2.data if param2 is not None else None,
                     state2=rule2._state_for(param2) if rule2 is not None else None,
                     clip_parts=parts[0], max_norm=float(self.clip_norm))
@@ -344,5 +397,6 @@ class FusedOptimizer:
                                                              float(self.clip_norm))
         self._update_pending_rows(scale)
         self._pending.clear()
+        self._has_spec = False
         self._sq_used = 0
         self._dense_step_all(scale)

@@ -214,6 +214,25 @@ def test_reduce_modes_match_an_fp64_scatter_add(dim, with_deep):
         if mode == _lib.RX_SEG_SGD:
             assert_close(wa, (table.double() - lr * 0.37 * Gref).float(), rtol=1e-5, what="scaled sgd")
 
+    # speculative clipped SGD: the reduce takes the step with factor 1 and leaves undo records; the row
+    # update ends at once for a factor of exactly 1 and otherwise redoes the rows -- bit for bit the
+    # two-phase results either way, and the same partial sums of squares
+    for factor in (0.37, 1.0):
+        scale = torch.tensor([factor], device="cuda")
+        wb, wb2 = table.clone(), bias.clone()
+        ops.fg_row_update(comp, fg, _lib.RX_SEG_SGD, wb, lr=lr, scale=scale, compact2=comp2, table2=wb2)
+        ws, ws2 = table.clone(), bias.clone()
+        undo = torch.full((fg.n, 2 * dim), float("nan"), device="cuda")
+        undo2 = torch.full((fg.n, 2), float("nan"), device="cuda")
+        sq_s = ops.fg_reduce(T, g, fg, _lib.RX_SEG_SGD_SPEC, ws, target2=ws2, lr=lr, want_sq=True, deep=deep, undo=undo, undo2=undo2)
+        assert torch.equal(sq_s, sq)
+        assert torch.equal(ws, w) and torch.equal(ws2, w2)                  # the plain step, as RX_SEG_SGD leaves it
+        assert torch.equal(undo[end][:, :dim], comp[end]) and torch.equal(undo[end][:, dim:], table[r[end]])
+        assert torch.equal(undo2[end][:, 0], comp2[end]) and torch.equal(undo2[end][:, 1], bias[r[end]])
+        ops.fg_row_update(undo, fg, _lib.RX_SEG_SGD_SPEC, ws, lr=lr, scale=scale, compact2=undo2, table2=ws2)
+        assert torch.equal(ws, wb) and torch.equal(ws2, wb2), factor
+        assert torch.equal(ws[~touched], table[~touched])
+
 
 def test_two_backward_passes_before_one_clipped_step():
     """Gradient accumulation over two batches with a clip: both pending row updates reach the table
@@ -308,6 +327,98 @@ def test_clip_factor_formed_inside_the_row_update_equals_the_separate_launch_bit
     assert float(na[0]) > 0.02          # the clip was active
 
 
+@pytest.mark.parametrize("line_rows", [False, True])
+@pytest.mark.parametrize("model", ["fm", "deepfm"])
+def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_rows, monkeypatch):
+    """FusedOptimizer(kind="sgd", clip_norm=...) over field groups takes the step inside the reduce and only
+    redoes rows when the norm exceeds the bound.  With a bound that bites on every step, on none, and on some
+    (it sits between the norms of the steps), losses, norms and weights must equal the two-phase form
+    (RX_NO_SPECULATIVE_SGD) bit for bit -- for the FM (clip factor formed inside the row update) and for the
+    DeepFM, whose tower gradients share the norm (clip factor from its own launch)."""
+    from recsys_amd import optim, synthetic
+    from recsys_amd.models import fields
+    if model == "deepfm" and line_rows:
+        pytest.skip("the whole-line layout is an FM table option")
+    dims = [7, 1000, 13, 5000, 3, 211, 40000]
+    mk = (lambda s: synthetic.criteo_batch(dims, 3000, seed=s, device="cuda"))
+    batches = [mk(s) for s in (1, 2, 3, 4)]
+
+    def run(clip, speculate):
+        monkeypatch.setattr(optim, "_NO_SPECULATION", not speculate)
+        torch.manual_seed(0)
+        with torch.device("cuda"):
+            m = fields.FieldFM(dims, 16, line_rows=line_rows) if model == "fm" else fields.FieldDeepFM(dims, 16, n_dense=13, dropout=0.0)
+        m.train()
+        opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip)
+        losses, norms = [], []
+        for b in batches:
+            opt.zero_grad()
+            loss = m.loss(b)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone()); norms.append(opt.last_total_norm.clone())
+        return [p.detach().clone() for p in m.parameters()], losses, norms
+
+    _, _, norms = run(1e9, False)
+    nv = sorted(float(x) for x in norms)
+    assert nv[0] < nv[-1]
+    for clip in (0.5 * nv[0], 2.0 * nv[-1], 0.5 * (nv[1] + nv[2])):
+        wa, la, na = run(clip, False)
+        wb, lb, nb = run(clip, True)
+        assert all(torch.equal(x, y) for x, y in zip(la, lb)), clip
+        assert all(torch.equal(x, y) for x, y in zip(na, nb)), clip
+        assert all(torch.equal(x, y) for x, y in zip(wa, wb)), clip
+
+
+@pytest.mark.parametrize("line_rows", [False, True])
+def test_forward_between_backward_and_step_sees_the_rows_of_before_the_step(line_rows):
+    """The speculative clipped SGD step moves rows during the backward pass.  A forward pass that comes
+    before step() (an evaluation, or the next micro-batch of a gradient accumulation) must still see the old
+    rows: it puts them back, and step() then applies the records with the final factor -- same weights as
+    with the two-phase form, bit for bit.  zero_grad() without a step drops the update altogether."""
+    from recsys_amd import optim, synthetic
+    from recsys_amd.models import fields
+    dims = [7, 1000, 13, 5000, 3, 211]
+    batch = synthetic.criteo_batch(dims, 900, seed=3, device="cuda")
+    other = synthetic.criteo_batch(dims, 900, seed=4, device="cuda")
+
+    def fresh():
+        torch.manual_seed(0)
+        with torch.device("cuda"):
+            m = fields.FieldFM(dims, 16, line_rows=line_rows)
+        return m.train()
+
+    def two_phase(clip):
+        m = fresh()
+        old = optim._NO_SPECULATION
+        optim._NO_SPECULATION = True
+        try:
+            opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip)
+            opt.zero_grad(); m.loss(batch).backward(); opt.step()
+        finally:
+            optim._NO_SPECULATION = old
+        return [p.detach().clone() for p in m.parameters()]
+
+    for clip in (1e9, 1e-3):          # idle and biting
+        ref = two_phase(clip)
+        m = fresh()
+        w0 = [p.detach().clone() for p in m.parameters()]
+        logits0 = m(other).detach().clone()
+        opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip)
+        opt.zero_grad()
+        m.loss(batch).backward()
+        assert opt._has_spec and not torch.equal(m.feature_embedding.weight.detach(), w0[0])   # rows already moved
+        assert torch.equal(m(other).detach(), logits0)                                          # ... and were put back for this
+        assert all(torch.equal(p.detach(), q) for p, q in zip(m.parameters(), w0))
+        opt.step()
+        assert all(torch.equal(p.detach(), q) for p, q in zip(m.parameters(), ref)), clip
+        # dropped gradients: backward, then zero_grad without a step
+        m2 = fresh()
+        opt2 = optim.FusedOptimizer(m2, kind="sgd", lr=0.1, clip_norm=clip)
+        opt2.zero_grad(); m2.loss(batch).backward(); opt2.zero_grad()
+        assert all(torch.equal(p.detach(), q) for p, q in zip(m2.parameters(), w0))
+
+
 # ------------------------------------------------------------------ rows in whole cache lines
 def _line_model(dims, dim, line_rows, how):
     from recsys_amd.models import fields
@@ -371,7 +482,8 @@ def test_line_rows_train_bit_identically_to_back_to_back_rows(kind, clip):
     assert len(sa) == len(sb_) and all(torch.equal(x, y) for x, y in zip(sa, sb_))
     fw = mb.feature_embedding.weight
     whole = torch.as_strided(fw.detach(), (fw.shape[0], 32), (32, 1))
-    assert int((whole[:, 17:] != 0).sum()) == 0
+    # (the clipped SGD step keeps the bias gradient and the previous bias value in columns 17 and 18)
+    assert int((whole[:, 19 if (kind, clip) == ("sgd", 0.02) else 17:] != 0).sum()) == 0
     assert not torch.equal(ma.feature_embedding.weight.detach(), _line_model(dims, 16, False, "on_device").feature_embedding.weight.detach())
 
 

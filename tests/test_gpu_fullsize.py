@@ -139,9 +139,9 @@ def test_fused_step_matches_dense_restatement_full_size(setup, line_rows):
     assert torch.equal(w1[~touched], w0[~touched]) and torch.equal(b1[~touched], b0[~touched]), "untouched rows moved"
     assert_close(w1[touched].cpu().numpy(), wr.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated rows")
     assert_close(b1[touched].cpu().numpy(), br.detach()[touched].cpu().numpy(), rtol=1e-5, what="updated bias rows")
-    if line_rows:   # the padding behind the bias entry stays zero: the update writes the line whole
+    if line_rows:   # the update writes the line whole: bias entry, its gradient and previous value, then zeros
         buf = w1.as_strided((sum(dims), 2 * D), (2 * D, 1), w1.storage_offset())
-        assert not buf[:, D + 1:].any(), "padding columns of a line were written"
+        assert not buf[:, D + 3:].any(), "padding columns of a line were written"
     mine = (loss.detach().clone(), opt.last_total_norm.clone(), w1[touched].contiguous().clone(), b1[touched].contiguous().clone())
     other = _FUSED_STEP_RESULT.get(not line_rows)
     _FUSED_STEP_RESULT[line_rows] = mine
