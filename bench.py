@@ -375,6 +375,27 @@ def embedding_bytes_per_sample(desc, rho):
     return F * (8 + 4 * D + 4) + 4 + 4 + 4 * F * D + 8 * F + rho * F * 2 * (4 * D + 4)
 
 
+# random 128-byte line accesses per second the card sustains (profiles/access_probe.py, uniform row reads of a 2 GiB
+# D = 16 table, and of a 64 MiB one that the 256 MiB Infinity Cache holds): profiles/round2/access_probe.txt
+LINE_CEILING_HBM, LINE_CEILING_CACHE = 38e9, 55e9
+
+
+def line_accesses_per_step(desc, rho, speculative=True):
+    """128-byte line accesses of one fm_criteo step (D = 16, rows in whole lines), the unit the memory system
+    moves: ``random`` ones (one per row / record touched at an unpredictable address) and ``streaming`` ones
+    (bytes of the sequentially read or written arrays / 128)."""
+    B, F = desc["batch_per_gpu"], desc["fields"]
+    n = B * F
+    per_distinct = 3 if speculative else 6     # row read + row write + undo record | row read + compact write; compact, bias gradient, row read, row write
+    random = n + n + rho * n * per_distinct    # forward row reads, backward record reads, distinct-row traffic
+    stream_bytes = (2 * 8 * n            # index matrix: forward + grouping
+                    + 8 * B + 128 * B    # labels, backward records written by the forward
+                    + 2 * 4 * n          # transposed keys: written, read
+                    + 2 * 4 * n          # packed words of the shared bins: written, read (upper bound)
+                    + 2 * 8 * n)         # grouped rows + samples: written, read by the reduce
+    return {"random": random, "streaming": stream_bytes / 128.0}
+
+
 def workload_dtype(name):
     """Arithmetic type of the path: embedding work is fp32 everywhere; the bf16 workloads round the
     tower / cross GEMM operands to bf16 (fp32 accumulation, fp32 master weights)."""
@@ -758,6 +779,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": workload_dtype(args.workload), "data": "synthetic",
         "config": dict(w["desc"], global_batch=B * world, parallelism=f"dp{world}" if world > 1 else "single"),
         "final_loss": last_loss, "self_check": w.get("self_check"),
+        "grad_norm_last_step": (float(w["opt"].last_total_norm.item()) if getattr(w["opt"], "last_total_norm", None) is not None else None),
     }
     roof = None
     rho, round_rows = 1.0, None
@@ -793,6 +815,17 @@ def main():
                                 "distinct_rows_per_round": round_rows,
                                 "table_bytes_touched_per_round": None if round_rows is None else round_rows * (4 * w["desc"]["dim"] + 4),
                                 "infinity_cache_bytes": 256 * 1024 * 1024}
+    if args.workload == "fm_criteo" and w["desc"].get("dim") == 16:
+        spec = os.environ.get("RX_NO_SPECULATIVE_SGD") != "1" and clip is not None
+        la = line_accesses_per_step(w["desc"], rho, spec)
+        tot = la["random"] + la["streaming"]
+        out["roofline_lines"] = {
+            "lines_per_step": tot, "random_lines_per_step": la["random"], "streaming_lines_per_step": la["streaming"],
+            "achieved_Glines_s": tot / (el / args.steps) / 1e9,
+            "ceiling_Glines_s": {"random_from_hbm": LINE_CEILING_HBM / 1e9, "random_from_infinity_cache": LINE_CEILING_CACHE / 1e9},
+            "frac_of_hbm_random_ceiling": tot / (el / args.steps) / LINE_CEILING_HBM,
+            "note": "a D = 16 row is half of a 128-byte line: by lines moved, not by bytes asked for, is how this step is bound "
+                    "(profiles/round3/fetch_size_calibration.txt: 2 x FETCH_SIZE equals the lines moved for 64-byte and 128-byte rows alike)"}
     if world > 1:
         # what a weak-scaling efficiency of this line is to be computed against: the SAME sharded workload at
         # one rank, which the --gpus 1 line reports under other_workloads (its main line is the unsharded

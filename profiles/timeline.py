@@ -4,8 +4,15 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-mid = int(sys.argv[3]) if len(sys.argv) > 3 else None        # optional: start at this fraction (percent) of the trace
-tail = rows[-n:] if mid is None else rows[len(rows) * mid // 100:][:n]
+mid = sys.argv[3] if len(sys.argv) > 3 else None        # optional: start at this fraction (percent) of the trace, or "name:K" = at the K-th kernel whose name contains `name`
+if mid is None:
+    tail = rows[-n:]
+elif ":" in mid:
+    name, k = mid.rsplit(":", 1)
+    hits = [i for i, r in enumerate(rows) if name in r["Kernel_Name"]]
+    tail = rows[hits[int(k)]:][:n]
+else:
+    tail = rows[len(rows) * int(mid) // 100:][:n]
 t0 = int(tail[0]["Start_Timestamp"])
 last_end = {}
 for r in tail:

@@ -46,6 +46,11 @@ def _prep_stream(dev) -> "torch.cuda.Stream":
 
 
 _MAX_WIDTH = int(os.environ.get("RX_GRAPH_MAX_WIDTH", 2))
+# Multi-step recordings: the index preparation of slot i + 1 is tied to the start of step i.  Left free to run
+# ahead (RX_GRAPH_FREE_RUNNING=1, the earlier form) the replayed graph does not overlap the two branches as
+# recorded: the kernel trace shows the side branch's ten preparations back to back with the main branch stalled
+# behind them for most of that time, then the ten steps alone.
+_LOCKSTEP = os.environ.get("RX_GRAPH_FREE_RUNNING") != "1"
 _hip = None
 
 
@@ -210,6 +215,10 @@ class GraphedTrainStep:
                 done = {}             # slot -> event recorded after this graph's step on it
 
                 def prepare_next(nxt):
+                    if _LOCKSTEP and shared is None:
+                        # the preparation starts where the step beside it starts (behind the previous step's last
+                        # launch) instead of running ahead freely: see _LOCKSTEP
+                        fork.wait_stream(main)
                     with torch.cuda.stream(fork):
                         if nxt in done:
                             fork.wait_event(done[nxt])   # its sort result was read by a step of this graph
