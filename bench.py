@@ -437,7 +437,12 @@ def run_train_loop(name, device, clip):
     with torch.device(device):
         model = (VanillaMF if name.startswith("mf_") else NeuMF)(data.n_users, data.n_items, 64)
     model.train()
-    opt = FusedOptimizer(model, kind="sgd", lr=0.05, clip_norm=clip)
+    if name.endswith("_adam"):
+        # the reference pipelines' own optimizer (recsys/pipelines/neuralcf/neumf.py:10: Adam(lr=1e-3) over all
+        # parameters, dense table gradients, clip_grad_norm_ 1.0) turned into its fused, graph-replayable equivalent
+        opt = FusedOptimizer.from_torch(torch.optim.Adam(model.parameters(), lr=1e-3), model, clip_norm=clip)
+    else:
+        opt = FusedOptimizer(model, kind="sgd", lr=0.05, clip_norm=clip)
     step = LoopGraph(model, opt)      # index checks are already deferred for the whole bench
     for epoch in range(2):
         torch.cuda.synchronize(device)
@@ -450,6 +455,7 @@ def run_train_loop(name, device, clip):
     n = data.implicit_matrix.nnz
     return {"workload": name, "samples_per_s": n / el, "ms_per_step": 1e3 * el / len(dl), "steps": len(dl), "dtype": "f32",
             "epoch_mean_loss": float(running.item()) / len(dl),
+            "optimizer": "Adam(lr=1e-3) on dense gradients of every parameter, as the reference pipelines build it" if name.endswith("_adam") else "fused sparse SGD",
             "what": "one epoch of train_epoch over ImplicitData's device loader, timed end to end: negative sampling and shuffle on "
                     "the device, then one graph launch per step (the recorded step ends with rx_epoch_advance: running loss, "
                     "copy of the next batch's slices into the static batch, cursor); the short last batch runs eagerly"}
@@ -572,7 +578,7 @@ def extra_entry(name, device, clip, run):
     """One entry of ``other_workloads``: a further single-GPU workload timed briefly."""
     if name.endswith("_eval_loop"):
         return run_eval_loop(name, device)
-    if name.endswith("_train_loop"):
+    if name.endswith("_train_loop") or name.endswith("_train_loop_adam"):
         return run_train_loop(name, device, clip)
     # the 64 GB-table workloads need a longer warm-up (allocator growth, first touches)
     n2, wu2 = (96, 24) if name in ("fm_wide_d128", "fm_criteo_sharded") else (30, 5)
@@ -635,7 +641,7 @@ def main():
     ap.add_argument("--op-profile", action="store_true", help="print average HIP-event time of every op to stderr")
     ap.add_argument("--extras-in-process", action="store_true", help="time the --extra workloads in this process instead of one child process each")
     ap.add_argument("--child-entry", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,neumf_ml1m,neumf_ml1m_train_loop,neumf_ml1m_eval_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
+    ap.add_argument("--extra", default="mf_ml1m,mf_ml1m_train_loop,mf_ml1m_train_loop_adam,neumf_ml1m,neumf_ml1m_train_loop,neumf_ml1m_train_loop_adam,neumf_ml1m_eval_loop,deepfm_criteo,deepfm_criteo_bf16,dcnv2_criteo,fm_wide_d128,fm_criteo_sharded,deepfm_wide_d128_sharded",
                     help="comma list of further single-GPU workloads to time briefly and append (\"none\" to skip)")
     args = ap.parse_args()
 

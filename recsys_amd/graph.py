@@ -111,6 +111,28 @@ def _check_width(g: "torch.cuda.CUDAGraph", what: str) -> None:
     g.instantiate()
 
 
+def refuse_live_autograd_graphs(model) -> None:
+    """A step must not be recorded while an autograd graph of an EARLIER step over these parameters is
+    still alive (typically a loss tensor of an eager step that was kept in a variable).  Such a graph
+    keeps the parameters' gradient-accumulation nodes alive, and those nodes stay bound to the stream
+    they were made on -- for an eager step the legacy default stream.  The recorded backward pass
+    would then run them there, which drags the default stream into the capture; on this runtime
+    that ends in a host segmentation fault inside hipStreamEndCapture (reproduced with dense table
+    gradients: profiles/stale_autograd_probe.py).  Detected here instead: a mark left on a
+    parameter's accumulation node survives only if something else holds that node."""
+    if os.environ.get("RX_ALLOW_LIVE_AUTOGRAD") == "1":      # profiles/stale_autograd_probe.py only
+        return
+    token = object()
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        torch.autograd.graph.get_gradient_edge(p).node.metadata["rx_live_probe"] = token
+        if torch.autograd.graph.get_gradient_edge(p).node.metadata.get("rx_live_probe") is token:
+            torch.autograd.graph.get_gradient_edge(p).node.metadata.pop("rx_live_probe", None)
+            raise RuntimeError(f"cannot record the train step: an autograd graph of an earlier step still references "
+                               f"parameter {name!r} (a loss tensor kept alive?); delete or detach it first")
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False,
                  cycle_len: int = 0):
@@ -148,6 +170,7 @@ class GraphedTrainStep:
         if ops._INDEX_CHECK != "deferred":
             raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
         dev = next(self.model.parameters()).device
+        refuse_live_autograd_graphs(self.model)
         prepared = [self.model.prepare(b) for b in batches]          # static buffers, filled eagerly once
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -182,7 +205,8 @@ class GraphedTrainStep:
                 self._pool = g.pool()
             self.graphs.append(g)
             self.batches.append(b)
-            self.losses.append(loss)
+            self.losses.append(loss.detach())      # detached: no autograd graph outlives its recording
+            del loss
         if self.cycle:
             self._record_cycle(prepared, dev)
 
@@ -233,7 +257,7 @@ class GraphedTrainStep:
                     nxt = (i + 1) % K
                     if shared is None:
                         ready = prepare_next(nxt)
-                    losses.append(self._eager(prepared[i]))
+                    losses.append(self._eager(prepared[i]).detach())
                     done[i] = torch.cuda.Event()
                     done[i].record(main)
                     if shared is not None:      # behind this step's branch work on the branch's stream
@@ -266,6 +290,7 @@ class GraphedTrainStep:
         if ops._INDEX_CHECK != "deferred":
             raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
         dev = next(self.model.parameters()).device
+        refuse_live_autograd_graphs(self.model)
         if not self.graphs:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -278,7 +303,7 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         clear_sort_cache()   # the recording must hold its own sort kernels (see autograd.sorted_index)
         with torch.cuda.graph(g, pool=self._pool):
-            loss = self._eager(batch)
+            loss = self._eager(batch).detach()
             if epilogue is not None:
                 epilogue(loss)
         _check_width(g, "GraphedTrainStep.add_batch")
@@ -302,6 +327,7 @@ class GraphedTrainStep:
         if ops._INDEX_CHECK != "deferred":
             raise RuntimeError("graph capture needs ops.set_index_check('deferred'): a captured step cannot sync")
         dev = next(self.model.parameters()).device
+        refuse_live_autograd_graphs(self.model)
         prepared = [self.model.prepare(b) for b in batches]      # static preparation buffers (filled eagerly once)
 
         def record(order):
@@ -317,7 +343,7 @@ class GraphedTrainStep:
                     if shared is None:
                         with torch.cuda.stream(fork):
                             self.model.prepare(prepared[1 - s], out=prepared[1 - s])
-                    loss = self._eager(prepared[s])
+                    loss = self._eager(prepared[s]).detach()
                     if shared is not None:       # behind the model's own branch work of this step (see _shared_branch)
                         with torch.cuda.stream(fork):
                             self.model.prepare(prepared[1 - s], out=prepared[1 - s])

@@ -33,6 +33,9 @@ class _FieldTable(HotPathModule):
             offs.append(offs[-1] + d)
         self._offsets = offs
         self._field_base = tuple(offs) + (self.n_features,)   # host row offsets of every field + table height
+        # device copy of the non-item fields' offsets: a buffer outside the state_dict, so that it follows the module
+        # across devices and no forward pass has to create it (not possible while a graph is recorded)
+        self.register_buffer("_ex_base", torch.tensor(offs[:-1], dtype=torch.int64), persistent=False)
 
     # ---- whole-line rows -------------------------------------------------------------------------
     # MI355X moves memory in 128-byte lines.  A D = 16 row is 64 bytes, its bias entry 4 bytes in another
@@ -74,10 +77,9 @@ class _FieldTable(HotPathModule):
         sparse = as_index(inputs["sparse"], "sparse")
         if sparse.dim() != 2 or sparse.shape[1] != self.n_fields:
             raise ValueError(f"sparse: expected [B, {self.n_fields}], got {tuple(sparse.shape)}")
-        base = getattr(self, "_ex_base", None)
-        if base is None or base.device != sparse.device:
-            base = torch.tensor(self._offsets[:-1], dtype=torch.int64, device=sparse.device)
-            self._ex_base = base
+        base = self._ex_base
+        if base.device != sparse.device:
+            base = base.to(sparse.device)
         F = self.n_fields - 1
         return sparse[:, :F], base, sparse[:, F:], self._offsets[-1]
 

@@ -18,6 +18,10 @@ class SharedTableMixin:
         self.n_occupations, self.max_timestamp_rank = n_occupations, max_timestamp_rank
         self.embedding_dim = embedding_dim
         self.n_features = n_users + n_items + n_occupations + max_timestamp_rank
+        # first table row of the user / occupation / timestamp-rank blocks; a buffer (outside the state_dict) so that it
+        # follows the module across devices and no forward pass has to create it (not possible while a graph is recorded)
+        self.register_buffer("_ex_base", torch.tensor([0, n_users + n_items, n_users + n_items + n_occupations], dtype=torch.int64),
+                             persistent=False)
 
     def _field_indices(self, inputs):
         users = as_index(inputs["user_code"], "user_code")
@@ -25,11 +29,9 @@ class SharedTableMixin:
         occ = as_index(inputs["user_occupation"], "user_occupation")
         ts = as_index(inputs["item_timestamp_rank"], "item_timestamp_rank")
         ex_idx = torch.stack([users, occ, ts], dim=1).contiguous()
-        base = getattr(self, "_ex_base", None)
-        if base is None or base.device != users.device:
-            base = torch.tensor([0, self.n_users + self.n_items, self.n_users + self.n_items + self.n_occupations],
-                                dtype=torch.int64, device=users.device)
-            self._ex_base = base
+        base = self._ex_base
+        if base.device != users.device:      # (the batch lives elsewhere than the module: fails later with a clear message)
+            base = base.to(users.device)
         return ex_idx, base, items, self.n_users
 
 

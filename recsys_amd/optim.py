@@ -134,33 +134,52 @@ class FusedOptimizer:
     ``kind`` in {"sgd", "adagrad", "rowwise_adagrad"} applies to the parameters the model lists
     in ``model.sparse_parameters()``; all other parameters are stepped densely with
     ``dense_kind`` (default: "sgd" for sgd, "adagrad" otherwise; "adam" allowed).
+    ``kind="dense_adam"``: no sparse rule at all -- dense table gradients and Adam on every parameter,
+    the reference pipelines' optimizer (``from_torch`` builds it from a ``torch.optim.Adam``).
     API mirrors torch.optim: ``zero_grad()``, ``step()``."""
 
     def __init__(self, model, kind: str = "sgd", lr: float = 0.01, eps: float = 1e-10,
                  clip_norm: Optional[float] = None, dense_kind: Optional[str] = None,
                  betas=(0.9, 0.999), adam_eps: float = 1e-8):
-        if kind not in _MODES:
+        if kind not in _MODES and kind != "dense_adam":
             raise ValueError(f"unknown sparse optimizer {kind!r}")
         self.kind, self.lr, self.eps, self.clip_norm = kind, lr, eps, clip_norm
-        self.dense_kind = dense_kind or ("sgd" if kind == "sgd" else "adagrad")
+        self.dense_kind = dense_kind or ("sgd" if kind == "sgd" else "adam" if kind == "dense_adam" else "adagrad")
         if self.dense_kind not in ("sgd", "adagrad", "adam"):
             raise ValueError(f"unknown dense optimizer {self.dense_kind!r}")
+        if kind == "dense_adam" and self.dense_kind != "adam":
+            raise ValueError("kind='dense_adam' steps every parameter with Adam")
         self.betas, self.adam_eps = betas, adam_eps
-        self.sparse: List[torch.nn.Parameter] = list(model.sparse_parameters())
+        # kind="dense_adam": what the reference's pipelines build -- torch.optim.Adam over ALL parameters behind
+        # clip_grad_norm_ (recsys/pipelines/neuralcf/neumf.py:10, recsys/utils.py:101-103).  No parameter carries a
+        # sparse rule: the tables' gradients come out of the backward pass as dense [rows, dim] arrays (sort +
+        # segmented reduce, RX_SEG_DENSE) and every tensor, tables included, takes a fused Adam step with the device-side
+        # step count -- so this step, too, records into a HIP graph and replays (utils.LoopGraph).
+        self.sparse: List[torch.nn.Parameter] = [] if kind == "dense_adam" else list(model.sparse_parameters())
         ids = {id(p) for p in self.sparse}
         self.dense: List[torch.nn.Parameter] = [p for p in model.parameters() if id(p) not in ids]
+        self._dense_state = {}
         self.rules = []
         for p in self.sparse:
             rule = SparseRule(kind, lr, eps, self)
             p._rx_sparse = rule
             self.rules.append(rule)
+        # Optimizer state exists from the start: a buffer first made (and zero-filled) inside a step that is
+        # being recorded into a graph would be zeroed again by every replay.
+        for p, rule in zip(self.sparse, self.rules):
+            rule._state_for(p)
+        if self.dense_kind == "adagrad":
+            for p in self.dense:
+                self._dense_state_for(p)
+        elif self.dense_kind == "adam":
+            for p in self.dense:
+                self._dense_state_for(p)
         self._pending = []
         self._has_spec = False                        # a pending entry whose rows the reduce already moved (speculative clipped SGD)
         self._zero = None
         self._deferred = []                            # reduces queued by the backward while a clip is set
         self._sq_buf: Optional[torch.Tensor] = None   # norm partials of all table reduces of a step, back to back
         self._sq_used = 0
-        self._dense_state = {}
         self._step = 0
         # Adam's step count also lives on the device and is advanced on the stream, so that a recorded graph
         # of the step reads the count of the replay, not the one of the recording.  Made here, never lazily
@@ -170,6 +189,27 @@ class FusedOptimizer:
         if self.dense_kind == "adam" and self.dense and self.dense[0].is_cuda:
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=self.dense[0].device)
         self.last_total_norm: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_torch(cls, optimizer, model, clip_norm=None):
+        """The fused equivalent of a plain ``torch.optim.Adam`` / ``torch.optim.SGD`` built over all of
+        ``model.parameters()`` (one parameter group, no weight decay, no amsgrad / momentum, no step taken yet),
+        or None when the optimizer is anything else.  utils.train_loop(graph=True) uses it so that a pipeline
+        written like the reference's -- ``optim.Adam(model.parameters(), lr=1e-3)`` -- replays as a HIP graph."""
+        groups = getattr(optimizer, "param_groups", None)
+        if not groups or len(groups) != 1 or len(optimizer.state) != 0:
+            return None
+        g = groups[0]
+        if {id(p) for p in g["params"]} != {id(p) for p in model.parameters()}:
+            return None
+        if g.get("weight_decay", 0) or g.get("maximize", False):
+            return None
+        if type(optimizer) is torch.optim.Adam and not g.get("amsgrad", False):
+            return cls(model, kind="dense_adam", lr=float(g["lr"]), clip_norm=clip_norm, betas=tuple(g["betas"]),
+                       adam_eps=float(g["eps"]))
+        if type(optimizer) is torch.optim.SGD and not g.get("momentum", 0) and not g.get("nesterov", False) and not g.get("dampening", 0):
+            return cls(model, kind="sgd", lr=float(g["lr"]), clip_norm=clip_norm)
+        return None
 
     def detach(self):
         """Remove the sparse rules (parameters go back to producing dense gradients)."""
@@ -286,6 +326,18 @@ class FusedOptimizer:
         self._sq_used += need
         return out
 
+    def _dense_state_for(self, p):
+        st = self._dense_state.get(id(p))
+        if st is None:
+            if self.dense_kind == "adagrad":
+                st = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
+            elif self.dense_kind == "adam":
+                st = (torch.zeros_like(p.data, memory_format=torch.contiguous_format), torch.zeros_like(p.data, memory_format=torch.contiguous_format))
+            else:
+                return None
+            self._dense_state[id(p)] = st
+        return st
+
     def _dense_update(self, p, scale):
         g = p.grad
         if g is None:
@@ -295,14 +347,9 @@ class FusedOptimizer:
         if self.dense_kind == "sgd":
             ops.dense_sgd(w, g, self.lr, scale)
         elif self.dense_kind == "adagrad":
-            st = self._dense_state.get(id(p))
-            if st is None:
-                st = self._dense_state[id(p)] = torch.zeros_like(w)
-            ops.dense_adagrad(w, g, st, self.lr, self.eps, scale)
+            ops.dense_adagrad(w, g, self._dense_state_for(p), self.lr, self.eps, scale)
         else:
-            st = self._dense_state.get(id(p))
-            if st is None:
-                st = self._dense_state[id(p)] = (torch.zeros_like(w), torch.zeros_like(w))
+            st = self._dense_state_for(p)
             ops.dense_adam(w, g, st[0], st[1], self.lr, self.betas[0], self.betas[1], self.adam_eps,
                            self._step_dev if self._step_dev is not None else self._step, scale)
 
@@ -322,10 +369,7 @@ class FusedOptimizer:
             if mode == _lib.RX_SEG_ADAGRAD:
                 states = []
                 for p, _ in chunk:
-                    st = self._dense_state.get(id(p))
-                    if st is None:
-                        st = self._dense_state[id(p)] = torch.zeros_like(p.data)
-                    states.append(st)
+                    states.append(self._dense_state_for(p))
             ops.multi_dense_update([p.data for p, _ in chunk], [g for _, g in chunk], mode, self.lr, self.eps,
                                    scale=scale, states=states)
 

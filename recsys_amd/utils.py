@@ -195,8 +195,17 @@ def train_epoch(model, optimizer, train_dl, clip_norm, step_fn=None):
 
 
 def train_loop(model, data, optimizer, num_epochs, clip_norm, k=10, graph=False):
-    """recsys/utils.py:84-117.  ``graph=True`` (GPU, FusedOptimizer): the step is replayed as a HIP
-    graph from the third batch on (``LoopGraph``)."""
+    """recsys/utils.py:84-117.  ``graph=True`` (GPU): the step is replayed as a HIP graph from the third
+    batch on (``LoopGraph``).  That needs a FusedOptimizer; a plain ``torch.optim.Adam`` / ``SGD`` over all
+    parameters -- what the reference's pipelines pass (recsys/pipelines/neuralcf/neumf.py:10) -- is
+    replaced by its fused equivalent (``FusedOptimizer.from_torch``: same arithmetic, the torch object's
+    own state is not advanced)."""
+    if graph and not isinstance(optimizer, FusedOptimizer):
+        fused = FusedOptimizer.from_torch(optimizer, model, clip_norm) if next(model.parameters()).is_cuda else None
+        if fused is None:
+            raise TypeError("train_loop(graph=True) takes a FusedOptimizer, or a fresh torch.optim.Adam / SGD without "
+                            "weight decay or momentum over all of model.parameters()")
+        optimizer = fused
     history = []
     data.create_test_dataloader()
     eval_loop(model, data, k, epoch=None, num_epochs=None, epoch_loss=None)

@@ -263,6 +263,58 @@ def test_fused_optimizer_with_dense_adam_reproduces_reference_first_step():
     assert checked >= 6
 
 
+@pytest.mark.parametrize("fixture", MODEL_FIXTURES)
+def test_reference_optimizer_as_a_graph_replay_hits_the_golden_adam_steps(fixture):
+    """The reference's optimizer -- Adam(lr=1e-3) over all parameters behind clip_grad_norm_(1.0)
+    (recsys/pipelines/neuralcf/neumf.py:10, recsys/utils.py:101-103) -- through the graph path:
+    FusedOptimizer.from_torch(torch.optim.Adam(...)) gives kind="dense_adam", the step is recorded WITHOUT a
+    warm-up step (the device-side step count must start at zero and advance with the replays) and replayed
+    three times.  Weights after replay 1 and 3 are the golden adam1 / adam3 captures, and bit for bit those
+    of three eager steps of the same optimizer."""
+    from recsys_amd import ops
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.optim import FusedOptimizer
+    rec = load_golden(fixture)
+    name = fixture.split("_d")[0]
+    batch = to_torch(group(rec, "batch"), "cuda")
+    grads = group(rec, "grad")
+    gmax = max(float(np.abs(g).max()) for g in grads.values())
+
+    def make():
+        m = _build(rec, name).train()
+        o = FusedOptimizer.from_torch(torch.optim.Adam(m.parameters(), lr=1e-3), m, clip_norm=1.0)
+        assert o is not None and o.kind == "dense_adam" and not o.sparse and o.clip_norm == 1.0
+        return m, o
+
+    m, o = make()
+    eager = []
+    for s in (1, 2, 3):
+        o.zero_grad(); m.loss(batch).backward(); o.step()
+        if s == 1:
+            assert_close(o.last_total_norm.item(), rec["clip_total_norm"], what="clip norm")
+        eager.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert o.step_count == 3
+    _compare_state(m, group(rec, "adam3"), "adam", 3, grads, gmax)
+
+    m, o = make()
+    ops.set_index_check("deferred")
+    try:
+        gs = GraphedTrainStep(m, o, warmup=0)
+        slot = gs.add_batch({k: v.clone() for k, v in batch.items()})      # records, executes nothing
+        assert o.step_count == 0
+        for s in (1, 2, 3):
+            gs(slot)
+            if s == 1:
+                _compare_state(m, group(rec, "adam1"), "adam", 1, grads, gmax)
+            for k, v in m.state_dict().items():
+                if not k.endswith("num_batches_tracked"):      # (BatchNorm's counter is a host-side add in the recording)
+                    assert torch.equal(v, eager[s - 1][k]), (s, k)
+        ops.raise_if_index_error()
+    finally:
+        ops.set_index_check("sync")
+    assert o.step_count == 3
+
+
 @pytest.mark.parametrize("name", ["VanillaMF", "BiasMF", "SideFeaturesMF", "TemporalMF", "GMF"])
 @pytest.mark.parametrize("label_dtype", [torch.float64, torch.float32])
 def test_fused_forward_loss_of_the_mf_family_equals_the_two_launch_path(name, label_dtype, monkeypatch):

@@ -15,7 +15,7 @@ def _small_data():
     return ImplicitData(d, device="cuda", train_batch_size=256, test_batch_size=128)
 
 
-@pytest.mark.parametrize("fused", [False, True, "graph"])
+@pytest.mark.parametrize("fused", [False, True, "graph", "graph_torch_adam"])
 def test_train_loop_learns(fused, capsys):
     """recsys/utils.py:84-117 call pattern: eval before training, then epochs of train + eval."""
     from recsys_amd.models.neuralcf import NeuMF
@@ -24,11 +24,11 @@ def test_train_loop_learns(fused, capsys):
     torch.manual_seed(0)
     data = _small_data()
     model = load_model(NeuMF, "cuda", n_users=data.n_users, n_items=data.n_items, embedding_dim=16)
-    if fused:
+    if fused and fused != "graph_torch_adam":
         opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
-    else:
+    else:       # the reference pipelines' optimizer; with graph=True train_loop swaps in its fused equivalent
         opt = torch.optim.Adam(model.parameters(), lr=5e-3)
-    hist = train_loop(model, data, opt, num_epochs=4, clip_norm=1.0, k=10, graph=fused == "graph")
+    hist = train_loop(model, data, opt, num_epochs=4, clip_norm=1.0, k=10, graph=str(fused).startswith("graph"))
     out = capsys.readouterr().out
     assert out.count("metrics - ndcg@10") == 5 and "epoch [2/4], loss:" in out
     losses = [h[0] for h in hist]
@@ -418,6 +418,36 @@ def test_recording_with_three_concurrent_branches_is_refused(monkeypatch):
         ops.set_index_check("sync")
 
 
+def test_recording_refuses_a_live_autograd_graph_of_an_earlier_step():
+    """An eager step's loss kept in a variable keeps the parameters' gradient-accumulation nodes alive on the
+    default stream; a recording made then would run them there from inside the capture, which crashes the
+    host inside hipStreamEndCapture on this runtime (profiles/stale_autograd_probe.py).  The recorder must
+    say so instead, and record fine once the old graph is gone."""
+    from recsys_amd import graph, ops, synthetic
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    torch.manual_seed(5)
+    with torch.device("cuda"):
+        m = VanillaMF(d["n_users"], d["n_items"], 16)
+    m.train()
+    batches = [synthetic.ml1m_batch(256, seed=20 + i, device="cuda") for i in range(3)]
+    opt = FusedOptimizer(m, kind="dense_adam", lr=1e-2, clip_norm=1.0)
+    ops.set_index_check("deferred")
+    try:
+        opt.zero_grad(); kept = m.loss(batches[0]); kept.backward(); opt.step()
+        gs = graph.GraphedTrainStep(m, opt, warmup=0)
+        with pytest.raises(RuntimeError, match="autograd graph of an earlier step"):
+            gs.add_batch({k: v.clone() for k, v in batches[1].items()})
+        del kept
+        slot = gs.add_batch({k: v.clone() for k, v in batches[1].items()})
+        gs(slot); gs(slot)
+        assert gs.losses[slot].grad_fn is None          # what the recorder keeps is detached
+        ops.raise_if_index_error()
+    finally:
+        ops.set_index_check("sync")
+
+
 def test_sharded_fm_one_rank_through_rccl():
     """A one-rank process group on the nccl (RCCL) backend with the collectives forced on: the
     all-to-all calls, their split-size handling and dtypes run for real on the GPU, and the step
@@ -763,7 +793,7 @@ def test_device_loader_epochs_are_reproducible_from_the_seed():
 
 
 @pytest.mark.parametrize("feed", ["loader", "batches"])
-@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF", "NeuMF", "VanillaMF_without_prepare"])
+@pytest.mark.parametrize("name", ["VanillaMF", "TemporalMF", "NeuMF", "VanillaMF_without_prepare", "VanillaMF_adam", "NeuMF_adam"])
 def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
     """utils.LoopGraph: two epochs with the step replayed as a graph give the same weights and epoch
     losses, bit for bit, as the eager loop on the same seeded loader -- both when the recorded step
@@ -776,6 +806,7 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
     from recsys_amd.optim import FusedOptimizer
     from recsys_amd.utils import LoopGraph, train_epoch
     d = synthetic_ml1m_data(seed=3, n_users=400, n_items=300, n_occupations=7, n_train=12000, pool=60, n_test_codes=50)
+    opt_kind, name = ("dense_adam", name[:-5]) if name.endswith("_adam") else ("adagrad", name)   # _adam: the reference's Adam over dense gradients
     results = []
     for graphed in (False, True):
         data = ImplicitData(d, device="cuda", train_batch_size=500, seed=9)
@@ -793,7 +824,7 @@ def test_train_epoch_graph_replay_matches_eager_bitwise(name, feed):
             model = Unprepared(**kw).cuda().train()
         else:
             model = getattr(mf, name)(**kw).cuda().train()
-        opt = FusedOptimizer(model, kind="adagrad", lr=0.05, clip_norm=1.0)
+        opt = FusedOptimizer(model, kind=opt_kind, lr=0.05 if opt_kind == "adagrad" else 1e-3, clip_norm=1.0)
         step = LoopGraph(model, opt) if graphed else None
         ops.set_index_check("deferred")
         try:
