@@ -598,8 +598,18 @@ def extra_entry(name, device, clip, run):
         entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"],
                      role="the 1 B-row x 128 DeepFM as named, one rank's share (125 M rows, tower 3344-3344-1672-836-1)")
     if name == "fm_criteo_sharded":
-        # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series
-        entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series")
+        # what `--gpus N` runs for N > 1, here with one rank: the base of the weak-scaling series.  At N > 1 the
+        # step is launched eagerly (recorded collectives were never rehearsed on several GPUs), at one rank it
+        # replays a graph: the same one-rank step launched eagerly is timed too, so that the series has a base
+        # in its own launch mode
+        entry.update(rows=w2["desc"]["rows"], dim=w2["desc"]["dim"], role="one-rank base of the multi-GPU series",
+                     launch="one HIP graph per step")
+        del w2
+        torch.cuda.empty_cache()
+        w3, el3, _, _ = run(name, n2, wu2, use_graph=False)
+        entry["eager_launch"] = {"ms_per_step": 1e3 * el3 / n2, "samples_per_s": w3["B"] * n2 / el3,
+                                 "note": "the launch mode of --gpus N > 1: compare the N-GPU line with this figure"}
+        del w3
     fl = dense_flops_per_sample(name)
     if fl:  # whole-step rate of the tower / cross GEMM work (fwd + both gradients)
         entry["dense_tflops_per_s"] = fl * entry["samples_per_s"] / 1e12
@@ -837,7 +847,11 @@ def main():
         # one rank, which the --gpus 1 line reports under other_workloads (its main line is the unsharded
         # D = 16 configuration, another workload)
         out["scaling_base"] = {"workload": args.workload, "where": "other_workloads[workload == '%s'] of the --gpus 1 line" % args.workload,
-                               "note": "value / (n_gpus x that entry's samples_per_s); the --gpus 1 main line runs fm_criteo (D = 16, unsharded)"}
+                               "launch": "graph replay" if use_graph else "eager",
+                               "note": "value / (n_gpus x that entry's samples_per_s); this line was launched "
+                                       + ("as graph replays: compare with the entry's own figure" if use_graph else
+                                          "eagerly: compare with the entry's eager_launch figure")
+                                       + "; the --gpus 1 main line runs fm_criteo (D = 16, unsharded)"}
     cap_slots = getattr(w["model"], "capacity", None)
     if world > 1 and cap_slots:
         # third bound of the sharded step: bytes a rank puts on its xGMI links per step (slot ids out,

@@ -215,6 +215,9 @@ int rx_fm2_fwd(const rx_fm_args* a, float* d_logits, float* d_deep_out, float* d
  * >= dim + 1, a multiple of 4).  Two launches: the forward with per-block loss sums, and the
  * one-block sum of those.  ws: rx_fm2_fwd_bce_workspace_bytes bytes. */
 size_t rx_fm2_fwd_bce_workspace_bytes(int64_t B, int32_t dim);
+/* d_loss may be NULL: the final sum is then left to rx_fg_reduce (rx_fg_reduce_args.loss_parts = ws,
+ * n_loss_parts = rx_fm2_fwd_bce_partials(B, dim), loss_count = B), which must follow on the same stream. */
+int64_t rx_fm2_fwd_bce_partials(int64_t B, int32_t dim);
 int rx_fm2_fwd_bce(const rx_fm_args* a, const void* d_labels, int labels_f64, float* d_logits,
                    float* d_gt, int64_t ld_gt, double* d_loss, void* ws, size_t ws_bytes,
                    int32_t* err_flag, int device, void* stream);
@@ -440,6 +443,12 @@ typedef struct {
    * the rows back as they were (a second backward pass before the step must read the old rows), and the step
    * then applies such records with the final factor. */
   float* undo; float* undo2;
+  /* Deferred final sum of the BCE loss (may all be NULL / 0): rx_fm2_fwd_bce called with d_loss == NULL leaves
+   * its per-block fp64 partial sums in its workspace (rx_fm2_fwd_bce_partials(B, dim) of them) instead of
+   * launching the one-wavefront kernel that adds them; one wavefront of this launch then writes
+   * loss_out[0] = sum(loss_parts) / loss_count with the same order of additions, bit for bit the same loss.
+   * Takes a 5 us launch off the critical path between the forward pass and the reduce. */
+  const double* loss_parts; int32_t n_loss_parts; int32_t pad2_; int64_t loss_count; double* loss_out;
 } rx_fg_reduce_args;
 int64_t rx_fg_reduce_grid(int64_t n, int32_t dim);
 size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim);

@@ -50,7 +50,8 @@ class FGReduceArgs(C.Structure):
                 ("n_fields", i32), ("dim", i32), ("mode", i32), ("premultiplied", i32), ("srow", vp), ("sb", vp),
                 ("target", vp), ("state", vp), ("table", vp), ("target2", vp), ("state2", vp), ("n_rows", i64),
                 ("lr", f32), ("eps", f32), ("scale", vp), ("sq_part", vp), ("ld_w", i64), ("ld_w2", i64),
-                ("undo", vp), ("undo2", vp)]
+                ("undo", vp), ("undo2", vp),
+                ("loss_parts", vp), ("n_loss_parts", i32), ("pad2_", i32), ("loss_count", i64), ("loss_out", vp)]
 
 
 
@@ -118,6 +119,7 @@ PROTOTYPES = {
     "rx_fg_reduce_workspace_bytes": (sz, [i64, i32]),
     "rx_fg_reduce": (C.c_int, [C.POINTER(FGReduceArgs), vp, sz, C.c_int, vp]),
     "rx_fm2_fwd_bce_workspace_bytes": (sz, [i64, i32]),
+    "rx_fm2_fwd_bce_partials": (i64, [i64, i32]),
     "rx_fm2_fwd_bce": (C.c_int, [C.POINTER(FMArgs), vp, C.c_int, vp, vp, i64, vp, vp, sz, vp, C.c_int, vp]),
     "rx_fg_row_update": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, i64, C.c_int, vp]),
     "rx_fg_row_update_clip": (C.c_int, [vp, i32, vp, i64, C.c_int, vp, vp, vp, vp, vp, i64, f32, f32, vp, i64, f32, vp, vp,

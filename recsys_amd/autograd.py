@@ -420,6 +420,9 @@ class FM2(Function):
         return (None, None, None, None, gfeat, gbias) + none_tail
 
 
+DEFER_LOSS_FINAL = [False]     # see FMLoss.forward; switched on by graph.GraphedTrainStep._eager and utils.train_step
+
+
 class FMLoss(Function):
     """Forward + BCE loss of the one-item-per-sample FM as one launch (rx_fm2_fwd_bce), backward over
     the field-grouped occurrence list.  Used by FieldFM.loss when the batch qualifies for field
@@ -429,7 +432,12 @@ class FMLoss(Function):
     def forward(ctx, ex_idx, ex_base, item_idx, item_base, feat, bias_table, labels, presort, field_base):
         _before_table_read(feat)
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
-        loss, gt, _ = ops.fm2_fwd_bce(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, labels.contiguous())
+        # inside a train step (DEFER_LOSS_FINAL, set by the step drivers: a backward pass is certain to follow) the
+        # launch that adds the loss partials is left out and the backward's reduce writes the loss instead
+        defer = DEFER_LOSS_FINAL[0] and torch.is_grad_enabled() and ctx.needs_input_grad[4] and labels.dtype == torch.float64
+        out = ops.fm2_fwd_bce(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, labels.contiguous(), defer_final=defer)
+        loss, gt = out[0], out[1]
+        ctx.loss_final = out[3] if defer else None
         ctx.args = (ex_idx, ex_base, item_idx, item_base, feat, bias_table)
         ctx.gt, ctx.field_base = gt, field_base
         ctx.sort = presort
@@ -447,8 +455,13 @@ class FMLoss(Function):
             gt = gt * g.to(torch.float32)
         fg = ctx.sort.join()
         dim = feat.shape[1]
+        if ctx.loss_final is not None:
+            ops._loss_final_pending, ctx.loss_final = ctx.loss_final, None      # taken by the fg_reduce call below
         gfeat, gbias = table_backward_fm(feat, bias_table, fg, gt[:, :dim], gt[:, dim], ex_idx.shape[1], None,
                                          premultiplied=True)
+        if ops._loss_final_pending is not None:
+            ops._loss_final_pending = None
+            raise RuntimeError("FMLoss: the backward pass did not reach rx_fg_reduce; the deferred loss was not written")
         return (None, None, None, None, gfeat, gbias, None, None, None)
 
 

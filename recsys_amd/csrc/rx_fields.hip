@@ -641,6 +641,7 @@ struct FgRed {
   int64_t ldw, ldw2;   // row strides of the table (a.table, or a.target in the update modes) and of the companion table
   int line;            // the companion entry sits right behind its row in a line of 2 * dim floats: SGD writes whole lines
   float* undo;         // RX_SEG_SGD_SPEC: [positions][2 * dim] = gradient | the row before the step, at each run's last position
+  const double* loss_parts; int n_loss_parts; int64_t loss_count; double* loss_out;   // deferred final sum of the forward's loss partials
   int force;           // RX_SEG_SGD_SPEC update: redo the rows even for a clip factor of 1 (they were put back before)
   float* undo2;        // ... and [positions][2] = companion gradient | companion entry before the step (NULL in the line layout,
                        //     where the two ride in the row's own line behind the entry)
@@ -890,6 +891,14 @@ fg_reduce_kernel(FgRed a) {
       }
       if (lg == 0) a.tail_row[window] = tail;
     }
+  }
+  if (a.loss_out && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {
+    // the forward left its per-block fp64 loss partials (rx_fm2_fwd_bce with d_loss == NULL): one wavefront of
+    // the last block adds them exactly as bce_final_kernel does (lane l takes l, l + 64, ...; fixed xor tree)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.n_loss_parts; i += 64) s += a.loss_parts[i];
+    s = rx_wave_sum_f64(s);
+    if (threadIdx.x == 0) a.loss_out[0] = s / (double)a.loss_count;
   }
   if (a.sq_part) fg_block_sq_store(sq, a.sq_part, sq_lds);
 }
@@ -1145,6 +1154,7 @@ extern "C" size_t rx_fg_reduce_workspace_bytes(int64_t n, int32_t dim) {
     if (deep) hipLaunchKernelGGL((fg_reduce_kernel<GROUPV, 8, MODEV, true>), dim3(g1), dim3(RX_BLOCK), 0, st, a); \
     else hipLaunchKernelGGL((fg_reduce_kernel<GROUPV, 8, MODEV, false>), dim3(g1), dim3(RX_BLOCK), 0, st, a);  \
     a2 = a;                                                                                                    \
+    a2.loss_out = nullptr;                                                                                     \
     if (a2.sq_part) a2.sq_part += g1;                                                                          \
     hipLaunchKernelGGL((fg_combine_kernel<GROUPV, 8, MODEV>), dim3(g2), dim3(RX_BLOCK), 0, st, a2, n_windows); \
   } while (0)
@@ -1197,6 +1207,10 @@ extern "C" int rx_fg_reduce(const rx_fg_reduce_args* r, void* ws, size_t ws_byte
     RX_REQUIRE(!r->target2 || a.line || (r->undo2 && ((uintptr_t)r->undo2 & 7) == 0), "rx_fg_reduce: the speculative step needs undo2 [B * n_fields, 2] for a companion table outside the row's line");
     RX_REQUIRE(!a.line || dim >= 4, "rx_fg_reduce: line layout needs room for the undo pair");
     a.undo = r->undo; a.undo2 = a.line ? nullptr : r->undo2;
+  }
+  if (r->loss_out) {
+    RX_REQUIRE(r->loss_parts && r->n_loss_parts >= 1 && r->loss_count >= 1, "rx_fg_reduce: loss_out needs the forward's partial sums, their count and the number of logits");
+    a.loss_parts = r->loss_parts; a.n_loss_parts = r->n_loss_parts; a.loss_count = r->loss_count; a.loss_out = r->loss_out;
   }
   const size_t nw = (size_t)fg_windows(n, dim);
   char* w = (char*)ws;

@@ -738,7 +738,7 @@ extern "C" int rx_fm2_fwd_bce(const rx_fm_args* a, const void* d_labels, int lab
   if (fm_check(a, "rx_fm2_fwd_bce")) return 1;
   RX_REQUIRE(a->N == 1, "rx_fm2_fwd_bce: one item per sample only (N == 1)");
   RX_REQUIRE(a->B >= 1, "rx_fm2_fwd_bce: empty batch");
-  RX_REQUIRE(d_labels && d_gt && d_loss && ws, "rx_fm2_fwd_bce: null argument");
+  RX_REQUIRE(d_labels && d_gt && ws, "rx_fm2_fwd_bce: null argument");
   RX_REQUIRE(ws_bytes >= rx_fm2_fwd_bce_workspace_bytes(a->B, a->dim) && ((uintptr_t)ws & 15) == 0, "rx_fm2_fwd_bce: workspace too small or unaligned");
   RxRowShape sh;
   size_t lds;
@@ -756,9 +756,17 @@ extern "C" int rx_fm2_fwd_bce(const rx_fm_args* a, const void* d_labels, int lab
   else FWD_BCE(1, 4);
 #undef FWD_BCE
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B, d_loss);
-  RX_LAUNCH_CHECK();
+  if (d_loss) {   // NULL: the block partials stay in ws and rx_fg_reduce adds them up (rx_fg_reduce_args.loss_parts)
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B, d_loss);
+    RX_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" int64_t rx_fm2_fwd_bce_partials(int64_t B, int32_t dim) {
+  RxRowShape sh = rx_row_shape(dim > 0 ? dim : 1);
+  if (sh.chunks == 3) sh.chunks = 4;
+  return rx_cdiv(B > 0 ? B : 1, RX_BLOCK / sh.group);
 }
 
 extern "C" int rx_fm2_bwd(const rx_fm_args* a, const float* d_g, const float* d_deep, float* d_occ,

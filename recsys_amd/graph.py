@@ -154,8 +154,13 @@ class GraphedTrainStep:
             # (no version bump), so a sort memoised by an earlier step of the recording must not serve this one
             clear_capture_sort_cache()
         self.opt.zero_grad()
-        loss = self.model.loss(batch)
-        backward_from_loss(loss)
+        from . import autograd as rxa
+        rxa.DEFER_LOSS_FINAL[0] = True      # forward, backward and step follow one another: the reduce may write the loss
+        try:
+            loss = self.model.loss(batch)
+            backward_from_loss(loss)
+        finally:
+            rxa.DEFER_LOSS_FINAL[0] = False
         self.opt.step()
         return loss
 

@@ -687,7 +687,7 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
               state: Optional[Tensor] = None, target2: Optional[Tensor] = None, state2: Optional[Tensor] = None,
               lr: float = 0.0, eps: float = 0.0, scale: Optional[Tensor] = None, want_sq: bool = False,
               sq_out: Optional[Tensor] = None, deep: Optional[Tensor] = None, premultiplied: bool = False,
-              undo: Optional[Tensor] = None, undo2: Optional[Tensor] = None) -> Optional[Tensor]:
+              undo: Optional[Tensor] = None, undo2: Optional[Tensor] = None, loss_final=None) -> Optional[Tensor]:
     """rx_fg_reduce: the N == 1 FM backward over a field-grouped occurrence list (see FieldGroups).
     In RX_SEG_COMPACT mode ``target`` / ``target2`` have one row per POSITION (fg.n rows).
     RX_SEG_SGD_SPEC (the clipped SGD step taken at once with factor 1): ``undo`` [fg.n, 2 * dim] and, unless
@@ -741,6 +741,12 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
             if undo2.shape[0] < fg.n or undo2.shape[1] != 2:
                 raise ValueError("fg_reduce: undo2 must be [positions, 2]")
         a.undo, a.undo2 = undo.data_ptr(), (undo2.data_ptr() if undo2 is not None else 0)
+    global _loss_final_pending
+    if loss_final is None and _loss_final_pending is not None:
+        loss_final, _loss_final_pending = _loss_final_pending, None
+    if loss_final is not None:      # (partials, their count, number of logits, loss tensor) of fm2_fwd_bce(defer_final=True)
+        parts, n_parts, count, loss_out = loss_final
+        a.loss_parts, a.n_loss_parts, a.loss_count, a.loss_out = parts.data_ptr(), n_parts, count, loss_out.data_ptr()
     grad_mode = mode in (_lib.RX_SEG_COMPACT, _lib.RX_SEG_DENSE)
     a.ld_w, a.ld_w2 = _table_strides(table if grad_mode else target, None if grad_mode else target2, dim)
     ws = _ws(int(lib.rx_fg_reduce_workspace_bytes(fg.n, dim)), tsum.device)
@@ -748,10 +754,17 @@ def fg_reduce(tsum: Tensor, g: Tensor, fg: FieldGroups, mode: int, target: Tenso
     return sq
 
 
-def fm2_fwd_bce(feat, bias, ex_idx, ex_base, item_idx, item_base: int, labels: Tensor, want_logits: bool = False):
+# The final sum of a forward pass's loss partials, handed to the next fg_reduce call (see fm2_fwd_bce(defer_final=True)).
+_loss_final_pending = None
+
+
+def fm2_fwd_bce(feat, bias, ex_idx, ex_base, item_idx, item_base: int, labels: Tensor, want_logits: bool = False,
+                defer_final: bool = False):
     """rx_fm2_fwd_bce: logits, BCE loss and the per-sample backward record from one forward kernel (N == 1).
     Returns (loss fp64 scalar, gt [B, ld] fp32 with gt[:, :dim] = g_b * T_b and gt[:, dim] = g_b,
-    logits [B, 1] or None)."""
+    logits [B, 1] or None).  ``defer_final``: the one-wavefront launch that adds the block partials is left
+    out; the returned loss is written by the ``fg_reduce`` call of the backward pass instead, to which the
+    caller hands the fourth return value (``fg_reduce(..., loss_final=)``)."""
     a, B, F, N = _fm_args(feat, bias, ex_idx, ex_base, item_idx, item_base)
     if N != 1:
         raise ValueError("fm2_fwd_bce: one item per sample only")
@@ -767,9 +780,12 @@ def fm2_fwd_bce(feat, bias, ex_idx, ex_base, item_idx, item_base: int, labels: T
     loss = torch.empty((), dtype=torch.float64, device=dev)
     logits = torch.empty(B, 1, dtype=torch.float32, device=dev) if want_logits else None
     ws = _ws(int(lib.rx_fm2_fwd_bce_workspace_bytes(B, dim)), dev)
-    check(lib.rx_fm2_fwd_bce(C.byref(a), _p(labels), int(labels.dtype == torch.float64), _p(logits), _p(gt), ld, _p(loss),
-                             _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(feat), _stream(feat)), "rx_fm2_fwd_bce")
+    check(lib.rx_fm2_fwd_bce(C.byref(a), _p(labels), int(labels.dtype == torch.float64), _p(logits), _p(gt), ld,
+                             _p(None if defer_final else loss), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(feat), _stream(feat)),
+          "rx_fm2_fwd_bce")
     _after_index_op(dev)
+    if defer_final:
+        return loss, gt, logits, (ws, int(lib.rx_fm2_fwd_bce_partials(B, dim)), B, loss)
     return loss, gt, logits
 
 

@@ -70,8 +70,13 @@ def train_step(model, optimizer, inputs, clip_norm):
         # compact gradients + norm partials with one), so it has to be in place before the loss
         optimizer.clip_norm = clip_norm
     optimizer.zero_grad()
-    loss = model.loss(inputs)
-    backward_from_loss(loss)
+    from . import autograd as rxa
+    rxa.DEFER_LOSS_FINAL[0] = True          # the backward pass follows at once: its reduce may write the loss
+    try:
+        loss = model.loss(inputs)
+        backward_from_loss(loss)
+    finally:
+        rxa.DEFER_LOSS_FINAL[0] = False
     if clip_norm is not None and not isinstance(optimizer, FusedOptimizer):
         torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()

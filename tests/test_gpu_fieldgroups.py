@@ -419,6 +419,44 @@ def test_forward_between_backward_and_step_sees_the_rows_of_before_the_step(line
         assert all(torch.equal(p.detach(), q) for p, q in zip(m2.parameters(), w0))
 
 
+@pytest.mark.parametrize("kind,clip", [("sgd", 1.0), ("sgd", None), ("adagrad", 0.02)])
+def test_loss_written_by_the_reduce_equals_the_forward_launch_bitwise(kind, clip):
+    """Inside a train step (utils.train_step, graph.GraphedTrainStep) the FM forward leaves its loss partials
+    and the backward's reduce adds them up (one launch less between forward and reduce).  Same loss bits and
+    same weights as a step whose forward finishes the loss itself; a plain model.loss() outside a step is
+    complete as soon as it returns."""
+    from recsys_amd import autograd as rxa, synthetic
+    from recsys_amd.models import fields
+    from recsys_amd.optim import FusedOptimizer
+    from recsys_amd.utils import train_step
+    dims = [7, 1000, 13, 5000, 3, 211]
+    batches = [synthetic.criteo_batch(dims, 1100, seed=s, device="cuda") for s in (1, 2)]
+    out = []
+    for deferred in (False, True):
+        torch.manual_seed(0)
+        with torch.device("cuda"):
+            m = fields.FieldFM(dims, 16).train()
+        opt = FusedOptimizer(m, kind=kind, lr=0.1, clip_norm=clip)
+        losses = []
+        for b in batches:
+            if deferred:
+                losses.append(train_step(m, opt, b, clip).clone())
+            else:
+                opt.clip_norm = clip
+                opt.zero_grad()
+                loss = m.loss(b)
+                assert not rxa.DEFER_LOSS_FINAL[0]
+                first = loss.detach().clone()               # complete before any backward pass
+                loss.backward(); opt.step()
+                assert torch.equal(first, loss.detach())
+                losses.append(first)
+        out.append((losses, [p.detach().clone() for p in m.parameters()]))
+    (la, wa), (lb, wb) = out
+    assert all(torch.equal(x, y) for x, y in zip(la, lb)), (la, lb)
+    assert all(torch.equal(x, y) for x, y in zip(wa, wb))
+    assert all(0.0 < float(x) < 100.0 for x in lb)
+
+
 # ------------------------------------------------------------------ rows in whole cache lines
 def _line_model(dims, dim, line_rows, how):
     from recsys_amd.models import fields
