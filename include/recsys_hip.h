@@ -301,6 +301,14 @@ int rx_sort_dedup_fm(const rx_fm_args* a, int32_t* d_sorted_pos, int32_t* d_sort
  * reference gathers with the same indices, factorization_machine.py:40-51) can ride along:
  * d_occ2 [n] per-occurrence gradients, d_target2 / d_state2 its table (or dense / compact
  * gradient) and Adagrad state; all three NULL when absent.
+ *   RX_SEG_SGD_SPEC (rx_segreduce, rx_segreduce_fm, rx_row_update; not the _multi calls): the clipped SGD step
+ *                  in one pass when the clip does not bite -- the reduce takes the step with a factor of 1 and
+ *                  leaves undo records where a compact gradient would go: d_state [n, 2 * dim] = G_u | row
+ *                  before the step, d_state2 [n, 2] = companion gradient | entry before the step.
+ *                  rx_row_update(mode = RX_SEG_SGD_SPEC, d_compact = those records, d_compact2 = the
+ *                  companion's) ends at once for a factor of exactly 1 and otherwise redoes every row as
+ *                  old - lr * (factor * G_u), bit for bit what RX_SEG_COMPACT + rx_row_update(RX_SEG_SGD) leave;
+ *                  RX_SEG_SGD_SPEC_REDO redoes them whatever the factor (0 puts the rows back).
  * scale = *d_scale if d_scale != NULL else 1 (global-norm clip factor, recsys/utils.py:101).
  * d_sq_part (may be NULL) [rx_segreduce_grid(n, dim)] receives per-block sums of G_u^2.
  * ws: rx_segreduce_workspace_bytes(n, dim) bytes, 16-byte aligned (cross-piece partial sums). */

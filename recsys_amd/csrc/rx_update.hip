@@ -52,6 +52,12 @@ struct SegArgs {
   float* partials;    // [pieces][2][dim]
   float* partials2;   // [pieces][2]
   int32_t* tail_row;  // [pieces] slot of the run that leaves the piece to the right, or -1
+  // RX_SEG_SGD_SPEC (the clipped SGD step taken by the reduce with a factor of 1): `state` holds the undo
+  // records [n][2 * dim] = gradient | row before the step, `state2` [n][2] = companion gradient | entry before
+  // the step, both indexed like a compact gradient.  In rx_row_update: redo even for a factor of 1 (`force`),
+  // and the number of 256-thread blocks the list needs (the launch itself is a small grid that strides).
+  int force;
+  unsigned upd_blocks;
 };
 
 // Optimizer arithmetic for one scalar (companion table entry).  MODE is a template parameter:
@@ -65,6 +71,10 @@ __device__ __forceinline__ void apply_scalar(const SegArgs& a, float g, int64_t 
     a.target2[u] = g;
   } else if constexpr (MODE == RX_SEG_SGD) {
     a.target2[row] = a.target2[row] - a.lr * (g * scale);
+  } else if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    const float old = a.target2[row];
+    reinterpret_cast<float2*>(a.state2)[u] = make_float2(g, old);
+    a.target2[row] = old - a.lr * g;
   } else {  // Adagrad; row-wise Adagrad of a width-1 row is the same rule
     g *= scale;
     const float s = a.state2[row] + g * g;
@@ -89,8 +99,28 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, Acc
     }
     return;
   }
-  ACC_FOREACH(k, i) g.p[k].v[i] *= scale;
   float* w = a.target + row * (int64_t)dim;
+  if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    // the step with a clip factor of 1 (exact: the bits of the clipped step whenever the norm stays inside the
+    // bound), and the record from which rx_row_update redoes the row when it does not
+    float* ud = a.state + u * (int64_t)(2 * dim);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      if (c < dim) {
+        rx_store<VEC>(ud + c, g.p[k]);
+        rx_store<VEC>(ud + dim + c, x.p[k]);
+      }
+    }
+    ACC_FOREACH(k, i) x.p[k].v[i] = x.p[k].v[i] - a.lr * g.p[k].v[i];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      if (c < dim) rx_store<VEC>(w + c, x.p[k]);
+    }
+    return;
+  }
+  ACC_FOREACH(k, i) g.p[k].v[i] *= scale;
   if constexpr (MODE == RX_SEG_SGD) {
     ACC_FOREACH(k, i) x.p[k].v[i] = x.p[k].v[i] - a.lr * g.p[k].v[i];
   } else if constexpr (MODE == RX_SEG_ADAGRAD) {
@@ -642,6 +672,7 @@ extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
       case RX_SEG_COMPACT: SEG_DISPATCH_MF(RX_SEG_COMPACT, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
       case RX_SEG_SGD: SEG_DISPATCH_MF(RX_SEG_SGD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
       case RX_SEG_ADAGRAD: SEG_DISPATCH_MF(RX_SEG_ADAGRAD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
+      case RX_SEG_SGD_SPEC: SEG_DISPATCH_MF(RX_SEG_SGD_SPEC, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
       default: SEG_DISPATCH_MF(RX_SEG_ROWWISE_ADAGRAD, FMV, sh, KERNEL, grid, lds, st, __VA_ARGS__); break; \
     }                                                                                              \
   } while (0)
@@ -653,8 +684,9 @@ extern "C" size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim) {
   } while (0)
 
 static int mode_check(int mode, const float* state, const char* who, bool allow_grad_modes) {
-  RX_REQUIRE(mode >= (allow_grad_modes ? RX_SEG_DENSE : RX_SEG_SGD) && mode <= RX_SEG_ROWWISE_ADAGRAD, "%s: unknown mode %d", who, mode);
+  RX_REQUIRE(mode >= (allow_grad_modes ? RX_SEG_DENSE : RX_SEG_SGD) && mode <= RX_SEG_SGD_SPEC, "%s: unknown mode %d", who, mode);
   RX_REQUIRE(!(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || state, "%s: Adagrad needs a state buffer", who);
+  RX_REQUIRE(mode != RX_SEG_SGD_SPEC || state, "%s: the speculative step keeps its undo records in the state argument", who);
   return 0;
 }
 
@@ -665,12 +697,13 @@ static int seg_place(SegArgs& a, bool fm, const char* who, void* ws, size_t ws_b
   RX_REQUIRE(n >= 0 && dim >= 1 && dim <= RX_MAX_DIM && a.occ_ld >= dim, "%s: bad shape n=%lld dim=%d ld=%lld", who, (long long)n, dim, (long long)a.occ_ld);
   if (mode_check(a.mode, a.state, who, true)) return 1;
   RX_REQUIRE(fm || (a.occ2 == nullptr) == (a.target2 == nullptr), "%s: companion gradient and target come as a pair", who);
-  RX_REQUIRE(!a.target2 || !(a.mode == RX_SEG_ADAGRAD || a.mode == RX_SEG_ROWWISE_ADAGRAD) || a.state2, "%s: companion Adagrad state missing", who);
+  RX_REQUIRE(!a.target2 || !(a.mode == RX_SEG_ADAGRAD || a.mode == RX_SEG_ROWWISE_ADAGRAD || a.mode == RX_SEG_SGD_SPEC) || a.state2, "%s: companion Adagrad state / undo records missing", who);
+  RX_REQUIRE(a.mode != RX_SEG_SGD_SPEC || !a.state2 || ((uintptr_t)a.state2 & 7) == 0, "%s: companion undo records must be 8-byte aligned", who);
   if (n == 0) return 0;
   RX_REQUIRE(a.occ && a.sorted_pos && a.sorted_slot && a.uniq_rows && a.seg_off && a.n_uniq && a.target && ws, "%s: null argument", who);
   RX_REQUIRE(a.n_rows >= 1, "%s: n_rows must be positive", who);
   RX_REQUIRE(ws_bytes >= rx_segreduce_workspace_bytes(n, dim) && rx_aligned16(ws), "%s: workspace too small or unaligned", who);
-  if (seg_shape(dim, a.occ_ld, a.occ, a.target, a.mode == RX_SEG_ADAGRAD ? a.state : nullptr, shp, who)) return 1;
+  if (seg_shape(dim, a.occ_ld, a.occ, a.target, (a.mode == RX_SEG_ADAGRAD || a.mode == RX_SEG_SGD_SPEC) ? a.state : nullptr, shp, who)) return 1;
   RX_REQUIRE(!fm || shp->vec == 1 || !a.fm_table || rx_aligned16(a.fm_table), "%s: table must be 16-byte aligned", who);
   const size_t pieces = (size_t)seg_pieces(n);
   char* w = (char*)ws;
@@ -716,6 +749,7 @@ extern "C" int rx_segreduce_multi(const rx_seg_table* tables, int32_t count, int
                                   const float* d_scale, void* ws, size_t ws_bytes, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(count >= 0 && count <= SEG_MULTI_MAX && (tables || count == 0), "rx_segreduce_multi: 0..%d tables per call", SEG_MULTI_MAX);
+  RX_REQUIRE(mode != RX_SEG_SGD_SPEC, "rx_segreduce_multi: the speculative step goes through rx_segreduce / rx_segreduce_fm");
   static_assert(SEG_MULTI_MAX == RX_SEG_MULTI_MAX, "header and kernel disagree on the table limit");
   SegMulti m1{}, m2{};
   RxRowShape sh0{};
@@ -811,6 +845,27 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
   if (u >= a.n_uniq[0]) return;
   const int64_t row = a.uniq_rows[u];
   if (row < 0 || row >= a.n_rows) return;
+  if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    // redo the row from its record: old - lr * (factor * G), what RX_SEG_COMPACT + RX_SEG_SGD leave
+    const float scale = a.scale ? a.scale[0] : 1.f;
+    const float* ud = a.occ + u * (int64_t)(2 * dim);
+    float* w = a.target + row * (int64_t)dim;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      if (c < dim) {
+        RxPack<VEC> G = rx_load<VEC>(ud + c), x = rx_load<VEC>(ud + dim + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) x.v[i] = x.v[i] - a.lr * (G.v[i] * scale);
+        rx_store<VEC>(w + c, x);
+      }
+    }
+    if (a.target2 && lg == 0) {
+      const float2 t = reinterpret_cast<const float2*>(a.occ2)[u];
+      a.target2[row] = t.y - a.lr * (t.x * scale);
+    }
+    return;
+  }
   Acc<VEC, CH> g;
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
@@ -829,7 +884,15 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 row_update_kernel(SegArgs a) {
-  row_update_body<VEC, CH, MODE>(a, blockIdx.x);
+  if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    // the reduce already took the step with a factor of 1: nothing to do unless the clip bites.  A small grid
+    // strides over the list, so that the common case costs a few hundred blocks reading one float.
+    const float scale = a.scale ? a.scale[0] : 1.f;
+    if (scale == 1.f && !a.force) return;
+    for (unsigned b = blockIdx.x; b < a.upd_blocks; b += gridDim.x) row_update_body<VEC, CH, MODE>(a, b);
+  } else {
+    row_update_body<VEC, CH, MODE>(a, blockIdx.x);
+  }
 }
 
 template <int VEC, int CH, int MODE, bool FM>
@@ -846,6 +909,12 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
                              void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n_max >= 0 && dim >= 1 && dim <= RX_MAX_DIM, "rx_row_update: bad shape");
+  const bool force = mode == RX_SEG_SGD_SPEC_REDO;
+  if (force) mode = RX_SEG_SGD_SPEC;
+  if (mode == RX_SEG_SGD_SPEC) {      // d_compact / d_compact2 are the undo records; no optimizer state
+    RX_REQUIRE(d_scale, "rx_row_update: the speculative step needs the clip factor");
+    d_state = const_cast<float*>(d_compact);
+  }
   if (mode_check(mode, d_state, "rx_row_update", false)) return 1;
   RX_REQUIRE((d_compact2 == nullptr) == (d_w2 == nullptr), "rx_row_update: companion gradient and table come as a pair");
   RX_REQUIRE(!d_w2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || d_state2, "rx_row_update: companion Adagrad state missing");
@@ -858,7 +927,10 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   a.mode = mode; a.target = d_w; a.state = d_state; a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
   a.occ2 = d_compact2; a.target2 = d_w2; a.state2 = d_state2;
   a.group = sh.group;
-  const unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
+  unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
+  a.force = force ? 1 : 0;
+  a.upd_blocks = grid;
+  if (mode == RX_SEG_SGD_SPEC && grid > 2048u) grid = 2048u;
   SEG_DISPATCH_F(mode, false, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);
   RX_LAUNCH_CHECK();
   return 0;
@@ -868,6 +940,7 @@ extern "C" int rx_row_update_multi(const rx_seg_table* tables, int32_t count, in
                                    const float* d_scale, int device, void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(count >= 0 && count <= SEG_MULTI_MAX && (tables || count == 0), "rx_row_update_multi: 0..%d tables per call", SEG_MULTI_MAX);
+  RX_REQUIRE(mode != RX_SEG_SGD_SPEC, "rx_row_update_multi: the speculative step goes through rx_row_update");
   SegMulti m{};
   RxRowShape sh0{};
   unsigned blocks = 0;

@@ -814,8 +814,14 @@ def fg_row_update(compact: Tensor, fg: FieldGroups, mode: int, table: Tensor, *,
 
 def row_update(compact: Tensor, si: SortedIndex, mode: int, table: Tensor, *, state=None, lr=0.0, eps=0.0,
                scale=None, compact2=None, table2=None, state2=None) -> None:
-    """``compact2`` [n] / ``table2`` / ``state2``: the companion scalar table, updated in the same launch."""
+    """``compact2`` [n] / ``table2`` / ``state2``: the companion scalar table, updated in the same launch.
+    Modes RX_SEG_SGD_SPEC / _REDO: ``compact`` [n, 2 * dim] and ``compact2`` [n, 2] are the undo records the
+    reduce left (segreduce / segreduce_fm with ``state=`` / ``state2=`` in that mode)."""
     dim = compact.shape[1] if compact.dim() == 2 else 1
+    if mode in (_lib.RX_SEG_SGD_SPEC, _lib.RX_SEG_SGD_SPEC_REDO):
+        if compact.dim() != 2 or compact.shape[1] % 2 or scale is None:
+            raise ValueError("row_update: the speculative step takes [n, 2 * dim] undo records and a clip factor")
+        dim = compact.shape[1] // 2
     _req(table, torch.float32, "table")
     if table2 is not None:
         _req(table2, torch.float32, "companion table")

@@ -26,6 +26,11 @@ _SEPARATE_CLIP_LAUNCH = os.environ.get("RX_SEPARATE_CLIP") == "1"   # A/B timing
 _ONE_LAUNCH_PER_TABLE = os.environ.get("RX_NO_MULTI_TABLE") == "1"   # A/B timing of the multi-table launches
 
 _NO_SPECULATION = os.environ.get("RX_NO_SPECULATIVE_SGD") == "1"   # A/B: clipped SGD over field groups always in two phases
+# The same one-pass step on the general sorted path (rx_segreduce_fm): correct and tested, but OFF unless asked for.
+# Measured on fm_wide_d128 (125 M rows x 128, B = 65536): 0.748 ms per step against 0.629 in two phases -- a 512-byte
+# row's undo record is eight new 128-byte lines per distinct row, and first-touch line writes cost more than the
+# second pass they save.
+_SPECULATE_SORTED = os.environ.get("RX_SPECULATIVE_SGD_SORTED") == "1"
 
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
 
@@ -108,10 +113,24 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
         ops.segreduce_fm(tsum, g, n_fields_ex, si, self.mode, table, state=state, target2=table2, state2=state2,
                          lr=self.lr, eps=self.eps, deep=deep)
         return
-    compact = torch.empty(max(si.n, 1), tsum.shape[1], dtype=torch.float32, device=table.device)
+    dim = tsum.shape[1]
+    if self.owner._pending:
+        self.owner._restore_speculative()          # gradient accumulation: see the field-grouped branch above
+    elif (self.kind == "sgd" and _SPECULATE_SORTED and not _NO_SPECULATION and table.is_cuda and table.is_contiguous()
+          and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr))):
+        # the same one-pass clipped SGD step on the general sorted path (rows wider than the field groups take,
+        # N > 1, B > 65536): undo records go where the reduce's `state` arguments point
+        undo = torch.empty(max(si.n, 1), 2 * dim, dtype=torch.float32, device=table.device)
+        undo2 = torch.empty(max(si.n, 1), 2, dtype=torch.float32, device=table.device) if bias_table is not None else None
+        sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_SGD_SPEC, table, state=undo, target2=table2, state2=undo2,
+                              lr=self.lr, want_sq=True, sq_out=self.owner._sq_slice(si.n, dim, table.device), deep=deep)
+        self.owner._pending.append((self, feat, undo, si, sq, (rule2, bias_table, undo2) if bias_table is not None else None, "spec"))
+        self.owner._has_spec = True
+        return
+    compact = torch.empty(max(si.n, 1), dim, dtype=torch.float32, device=table.device)
     compact2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
     sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT, compact, table=table, target2=compact2,
-                          want_sq=True, sq_out=self.owner._sq_slice(si.n, tsum.shape[1], table.device), deep=deep)
+                          want_sq=True, sq_out=self.owner._sq_slice(si.n, dim, table.device), deep=deep)
     self.owner._pending.append((self, feat, compact, si, sq, (rule2, bias_table, compact2) if bias_table is not None else None, False))
 
 
@@ -177,6 +196,7 @@ class FusedOptimizer:
         self._pending = []
         self._has_spec = False                        # a pending entry whose rows the reduce already moved (speculative clipped SGD)
         self._zero = None
+        self._one = None
         self._deferred = []                            # reduces queued by the backward while a clip is set
         self._sq_buf: Optional[torch.Tensor] = None   # norm partials of all table reduces of a step, back to back
         self._sq_used = 0
@@ -229,8 +249,9 @@ class FusedOptimizer:
             if self._zero is None or self._zero.device != param.device:
                 self._zero = torch.zeros(1, dtype=torch.float32, device=param.device)
             rule2, param2, undo2 = comp if comp is not None else (None, None, None)
-            ops.fg_row_update(undo, si, _lib.RX_SEG_SGD_SPEC_REDO, param.data, lr=rule.lr, scale=self._zero, compact2=undo2,
-                              table2=param2.data if param2 is not None else None)
+            update = ops.fg_row_update if isinstance(si, ops.FieldGroups) else ops.row_update
+            update(undo, si, _lib.RX_SEG_SGD_SPEC_REDO, param.data, lr=rule.lr, scale=self._zero, compact2=undo2,
+                   table2=param2.data if param2 is not None else None)
             self._pending[k] = (rule, param, undo, si, sq, comp, "redo")
         self._has_spec = False
 
@@ -283,10 +304,23 @@ class FusedOptimizer:
                 if spec == "spec" and scale is None:
                     continue        # the clip was switched off after the backward pass: the rows already hold the plain step
                 mode = {"spec": _lib.RX_SEG_SGD_SPEC, "redo": _lib.RX_SEG_SGD_SPEC_REDO}.get(spec, rule.mode)
+                if spec and scale is None:      # rows put back earlier, clip switched off since: redo them unscaled
+                    if self._one is None or self._one.device != param.device:
+                        self._one = torch.ones(1, dtype=torch.float32, device=param.device)
                 ops.fg_row_update(compact, si, mode, param.data, state=rule._state_for(param), lr=rule.lr,
-                                  eps=rule.eps, scale=scale, compact2=compact2,
+                                  eps=rule.eps, scale=scale if (scale is not None or not spec) else self._one, compact2=compact2,
                                   table2=param2.data if param2 is not None else None,
                                   state2=rule2._state_for(param2) if rule2 is not None else None)
+            elif spec:
+                if spec == "spec" and scale is None:
+                    continue        # clip switched off after the backward pass: the rows already hold the plain step
+                rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+                if scale is None:
+                    if self._one is None or self._one.device != param.device:
+                        self._one = torch.ones(1, dtype=torch.float32, device=param.device)
+                ops.row_update(compact, si, _lib.RX_SEG_SGD_SPEC if spec == "spec" else _lib.RX_SEG_SGD_SPEC_REDO, param.data,
+                               lr=rule.lr, scale=scale if scale is not None else self._one, compact2=compact2,
+                               table2=param2.data if param2 is not None else None)
             else:
                 plain.append((rule, param, compact, si, comp))
         while plain:

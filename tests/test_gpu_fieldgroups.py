@@ -327,7 +327,7 @@ def test_clip_factor_formed_inside_the_row_update_equals_the_separate_launch_bit
     assert float(na[0]) > 0.02          # the clip was active
 
 
-@pytest.mark.parametrize("line_rows", [False, True])
+@pytest.mark.parametrize("line_rows", [False, True, "sorted_path", "sorted_path_d128"])
 @pytest.mark.parametrize("model", ["fm", "deepfm"])
 def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_rows, monkeypatch):
     """FusedOptimizer(kind="sgd", clip_norm=...) over field groups takes the step inside the reduce and only
@@ -337,8 +337,14 @@ def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_r
     DeepFM, whose tower gradients share the norm (clip factor from its own launch)."""
     from recsys_amd import optim, synthetic
     from recsys_amd.models import fields
-    if model == "deepfm" and line_rows:
+    if model == "deepfm" and line_rows is True:
         pytest.skip("the whole-line layout is an FM table option")
+    D = 16
+    if isinstance(line_rows, str):      # the general sort + run-walking reduce (rx_segreduce_fm) instead of field groups
+        monkeypatch.setenv("RX_NO_FIELD_GROUPS", "1")
+        monkeypatch.setattr(optim, "_SPECULATE_SORTED", True)     # off by default there (slower on wide rows)
+        D = 128 if line_rows.endswith("d128") else 16
+        line_rows = False
     dims = [7, 1000, 13, 5000, 3, 211, 40000]
     mk = (lambda s: synthetic.criteo_batch(dims, 3000, seed=s, device="cuda"))
     batches = [mk(s) for s in (1, 2, 3, 4)]
@@ -347,7 +353,10 @@ def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_r
         monkeypatch.setattr(optim, "_NO_SPECULATION", not speculate)
         torch.manual_seed(0)
         with torch.device("cuda"):
-            m = fields.FieldFM(dims, 16, line_rows=line_rows) if model == "fm" else fields.FieldDeepFM(dims, 16, n_dense=13, dropout=0.0)
+            m = fields.FieldFM(dims, D, line_rows=line_rows) if model == "fm" else fields.FieldDeepFM(dims, D, n_dense=13, dropout=0.0)
+            if D > 16:
+                with torch.no_grad():
+                    m.feature_embedding.weight.mul_(0.1)     # wide N(0, 1) rows saturate every logit
         m.train()
         opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip)
         losses, norms = [], []
@@ -370,14 +379,18 @@ def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_r
         assert all(torch.equal(x, y) for x, y in zip(wa, wb)), clip
 
 
-@pytest.mark.parametrize("line_rows", [False, True])
-def test_forward_between_backward_and_step_sees_the_rows_of_before_the_step(line_rows):
+@pytest.mark.parametrize("line_rows", [False, True, "sorted_path"])
+def test_forward_between_backward_and_step_sees_the_rows_of_before_the_step(line_rows, monkeypatch):
     """The speculative clipped SGD step moves rows during the backward pass.  A forward pass that comes
     before step() (an evaluation, or the next micro-batch of a gradient accumulation) must still see the old
     rows: it puts them back, and step() then applies the records with the final factor -- same weights as
     with the two-phase form, bit for bit.  zero_grad() without a step drops the update altogether."""
     from recsys_amd import optim, synthetic
     from recsys_amd.models import fields
+    if line_rows == "sorted_path":
+        monkeypatch.setenv("RX_NO_FIELD_GROUPS", "1")
+        monkeypatch.setattr(optim, "_SPECULATE_SORTED", True)
+        line_rows = False
     dims = [7, 1000, 13, 5000, 3, 211]
     batch = synthetic.criteo_batch(dims, 900, seed=3, device="cuda")
     other = synthetic.criteo_batch(dims, 900, seed=4, device="cuda")
