@@ -257,6 +257,45 @@ int rx_bce_fwd(const float* d_logits, const void* d_labels, int labels_f64, int6
 int rx_bce_fwd_noalloc(const float* d_logits, const void* d_labels, int labels_f64, int64_t M,
                        double* d_loss, float* d_dlogits, int device, void* stream);
 
+/* ------------------------------------------------------------------ NeuMF train step in one launch
+ * recsys/models/neuralcf/neumf.py:68-106 (list-wise forward: user / item rows of the GMF and MLP tables,
+ * GMF product -> linear_gmf, cat([user, item]) -> linear_mlp (Linear, ReLU, Dropout, Linear), cat([gmf, mlp])
+ * -> linear_final), its loss neumf.py:75-79 (mean BCE with logits over the B x N pairs, fp64) and what
+ * loss.backward() (recsys/utils.py:98) computes for it, for embedding_dim 64 and the default tower
+ * 2D -> D -> D/2: one kernel gathers, runs forward and backward of every pair on the matrix cores (exact
+ * fp32 products) and writes
+ *   du_gmf, du_mlp [B, 64]      gradient of each sample's user rows (summed over its N pairs, pair order)
+ *   di_gmf, di_mlp [B * N, 64]  gradient of each pair's item rows
+ *   wgrad [rx_neumf_step_weight_floats()]  gradients of linear_mlp.0.weight [64,128] | .bias [64] |
+ *                               linear_mlp.3.weight [32,64] | .bias [32] | linear_gmf.weight [32,64] | .bias [32] |
+ *                               linear_final.weight [64] | .bias [1], back to back
+ *   loss (fp64 mean), logits [B * N] (optional)
+ * The per-row embedding gradients then go through rx_sort_dedup + rx_segreduce like any other lookup.
+ * p_drop: the Dropout between the tower's layers (0 in eval mode); its keep mask is a counter-based draw
+ * keyed by (*seed, pair, unit), and the call advances *seed by one (seed may be NULL: stream 0, not advanced).
+ * Order of additions is fixed by (B, N): results are bitwise reproducible.  ws: rx_neumf_step_workspace_bytes,
+ * 256-byte aligned. */
+typedef struct {
+  const float* user_gmf; const float* item_gmf; const float* user_mlp; const float* item_mlp;   /* [n_users | n_items, 64] */
+  int64_t n_users, n_items;
+  const int64_t* users;    /* [B] */
+  const int64_t* items;    /* [B, N] */
+  const void* labels;      /* [B, N] f64 (labels_f64 != 0) or f32 */
+  int32_t labels_f64, N;
+  int64_t B;
+  int32_t dim, pad_;
+  const float* w1; const float* b1; const float* w2; const float* b2;     /* linear_mlp.0, linear_mlp.3 */
+  const float* wg; const float* bg; const float* wf; const float* bf;     /* linear_gmf, linear_final */
+  float p_drop; float pad2_;
+  const int64_t* seed;     /* device counter of the dropout stream, or NULL */
+  float* du_gmf; float* du_mlp; float* di_gmf; float* di_mlp;
+  float* wgrad; double* loss; float* logits;
+} rx_neumf_args;
+int rx_neumf_step_supported(int32_t dim, int32_t N);
+int64_t rx_neumf_step_weight_floats(void);
+size_t rx_neumf_step_workspace_bytes(int64_t B, int32_t N);
+int rx_neumf_step(const rx_neumf_args* a, void* ws, size_t ws_bytes, int32_t* err_flag, int device, void* stream);
+
 /* ------------------------------------------------------------------ index sort / dedup
  * First stage of the deterministic backward that replaces aten embedding_dense_backward /
  * index_put_(accumulate=True) (what autograd runs for every nn.Embedding and 1-D bias

@@ -56,6 +56,14 @@ class FGReduceArgs(C.Structure):
 
 
 
+class NeuMFArgs(C.Structure):
+    _fields_ = [("user_gmf", vp), ("item_gmf", vp), ("user_mlp", vp), ("item_mlp", vp), ("n_users", i64), ("n_items", i64),
+                ("users", vp), ("items", vp), ("labels", vp), ("labels_f64", i32), ("N", i32), ("B", i64), ("dim", i32),
+                ("pad_", i32), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("wg", vp), ("bg", vp), ("wf", vp), ("bf", vp),
+                ("p_drop", f32), ("pad2_", f32), ("seed", vp), ("du_gmf", vp), ("du_mlp", vp), ("di_gmf", vp), ("di_mlp", vp),
+                ("wgrad", vp), ("loss", vp), ("logits", vp)]
+
+
 RX_FM_NO_SECOND_ORDER = 1
 RX_MULTI_MAX = 24
 
@@ -104,6 +112,10 @@ PROTOTYPES = {
     "rx_bce_workspace_bytes": (sz, [i64]),
     "rx_bce_fwd": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, sz, C.c_int, vp]),
     "rx_bce_fwd_noalloc": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, C.c_int, vp]),
+    "rx_neumf_step_supported": (C.c_int, [i32, i32]),
+    "rx_neumf_step_weight_floats": (i64, []),
+    "rx_neumf_step_workspace_bytes": (sz, [i64, i32]),
+    "rx_neumf_step": (C.c_int, [C.POINTER(NeuMFArgs), vp, sz, vp, C.c_int, vp]),
     "rx_sort_dedup_workspace_bytes": (sz, [i64]),
     "rx_sort_dedup": (C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_sort_dedup_fm": (C.c_int, [C.POINTER(FMArgs), vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_int, vp]),

@@ -525,6 +525,48 @@ class GMFMul(Function):
         return None, None, gU, gV
 
 
+# ------------------------------------------------------------------ NeuMF: forward + loss + backward in one launch
+class NeuMFLoss(Function):
+    """List-wise NeuMF loss (embedding_dim 64, default tower) through rx_neumf_step: the forward launch already
+    computes every gradient -- a pair's dL/dlogit is known as soon as its logit is -- so the backward only hands
+    them on: the four tables' per-row gradients to the sort + segmented reduce (or the fused row update), the
+    eight weight gradients as views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, users, items, labels, p_drop, seed, ug, ig, um, im, w1, b1, w2, b2, wg, bg, wf, bf):
+        out = ops.neumf_step((ug, ig, um, im), users, items, labels.contiguous(), (w1, b1, w2, b2, wg, bg, wf, bf),
+                             p_drop=p_drop, seed=seed)
+        loss, ctx.du_g, ctx.du_m, ctx.di_g, ctx.di_m, ctx.wgrad, _ = out
+        ctx.idx = (users, items)
+        ctx.tables = (ug, ig, um, im)
+        ctx.shapes = [tuple(t.shape) for t in (w1, b1, w2, b2, wg, bg, wf, bf)]
+        return loss if labels.dtype == torch.float64 else loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        users, items = ctx.idx
+        ug, ig, um, im = ctx.tables
+        grads = [ctx.du_g, ctx.di_g, ctx.du_m, ctx.di_m, ctx.wgrad]
+        if not _UNIT_LOSS_GRAD:       # an upstream factor other than 1 (loss * c)
+            f = g.to(torch.float32)
+            grads = [t * f for t in grads]
+        du_g, di_g, du_m, di_m, wgrad = grads
+        su = sorted_index(users, ug.shape[0])
+        si = sorted_index(items, ig.shape[0])
+        gug = table_backward(ug, su, du_g)
+        gig = table_backward(ig, si, di_g)
+        gum = table_backward(um, su, du_m)
+        gim = table_backward(im, si, di_m)
+        outs, o = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            outs.append(wgrad[o:o + n].reshape(shp))
+            o += n
+        return (None, None, None, None, None, gug, gig, gum, gim) + tuple(outs)
+
+
 # ------------------------------------------------------------------ Linear (+ReLU) on the matrix cores
 class LinearAct(Function):
     """Linear (+ ReLU (+ Dropout)).  ``drop_p`` > 0: the Dropout behind a Linear + ReLU.  Its forward is
@@ -933,7 +975,7 @@ def backward_from_loss(loss: Tensor) -> None:
     one = _ONES.get(key)
     if one is None:
         one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
-    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward", "MFLossBackward")):
+    if not (loss.grad_fn is not None and type(loss.grad_fn).__name__ in ("BCEWithLogitsBackward", "FMLossBackward", "MFLossBackward", "NeuMFLossBackward")):
         loss.backward(gradient=one)
     else:
         _UNIT_LOSS_GRAD = True

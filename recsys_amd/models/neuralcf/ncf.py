@@ -160,6 +160,47 @@ class NeuMF(HotPathModule):
         return [(as_index(inputs["user_code"], "user_code"), self.n_users),
                 (as_index(inputs["item_code"], "item_code"), self.n_items)]
 
+    def _fused_step_ok(self, users, items, labels) -> bool:
+        """The one-launch train step (rx_neumf_step) serves the list-wise loss of the default architecture at
+        embedding_dim 64 on the GPU; anything else takes the per-layer path.  RX_NO_FUSED_NEUMF=1: A/B."""
+        from ... import ops
+        if os.environ.get("RX_NO_FUSED_NEUMF") == "1" or not torch.is_grad_enabled():
+            return False
+        mods = list(self.linear_mlp)
+        return (users.is_cuda and items.dim() == 2 and labels.is_cuda and labels.numel() == items.numel()
+                and labels.dtype in (torch.float32, torch.float64)
+                and tuple(self.mlp_dims) == (2 * self.embedding_dim, self.embedding_dim, self.embedding_dim // 2)
+                and len(mods) == 4 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.ReLU)
+                and isinstance(mods[2], nn.Dropout) and not mods[2].inplace and isinstance(mods[3], nn.Linear)
+                and all(m.bias is not None for m in (mods[0], mods[3], self.linear_gmf, self.linear_final))
+                and all(p.is_contiguous() for p in self.parameters())
+                and ops.neumf_step_supported(self.embedding_dim, items.shape[1]))
+
+    def loss(self, inputs, pointwise=False):
+        if not pointwise and inputs.get("item_code") is not None and "label" in inputs:
+            users = as_index(inputs["user_code"], "user_code")
+            items = as_index(inputs["item_code"], "item_code")
+            labels = inputs["label"]
+            if self._fused_step_ok(users, items, labels):
+                drop = self.linear_mlp[2]
+                p = float(drop.p) if (drop.training and drop.p > 0) else 0.0
+                seed = None
+                if p > 0.0:         # the dropout stream: a device counter the launch advances (graph replays draw anew)
+                    seed = getattr(self, "_drop_seed", None)
+                    if seed is None or seed.device != users.device:
+                        if torch.cuda.is_current_stream_capturing():
+                            raise RuntimeError("NeuMF: run one eager training step before recording (the dropout counter is made on first use)")
+                        # derived from torch's seed without drawing from its generator
+                        seed = self._drop_seed = torch.tensor([torch.initial_seed() % (2 ** 62)], dtype=torch.int64).to(users.device)
+                return rxa.NeuMFLoss.apply(users, items, labels, p, seed,
+                                           self.user_embedding_gmf.weight, self.item_embedding_gmf.weight,
+                                           self.user_embedding_mlp.weight, self.item_embedding_mlp.weight,
+                                           self.linear_mlp[0].weight, self.linear_mlp[0].bias,
+                                           self.linear_mlp[3].weight, self.linear_mlp[3].bias,
+                                           self.linear_gmf.weight, self.linear_gmf.bias,
+                                           self.linear_final.weight, self.linear_final.bias)
+        return super().loss(inputs, pointwise)
+
     def forward(self, inputs, pointwise=False):
         users = as_index(inputs["user_code"], "user_code")
         items = inputs["item_code"]

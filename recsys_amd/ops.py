@@ -597,6 +597,63 @@ def segreduce_fm(tsum: Tensor, g: Tensor, n_fields_ex: int, si: SortedIndex, mod
     return sq
 
 
+# ------------------------------------------------------------------ NeuMF train step in one launch
+def neumf_step_supported(dim: int, n_items_per_row: int) -> bool:
+    return bool(lib.rx_neumf_step_supported(int(dim), int(n_items_per_row)))
+
+
+def neumf_step(tables, users: Tensor, items: Tensor, labels: Tensor, weights, p_drop: float = 0.0,
+               seed: Optional[Tensor] = None, want_logits: bool = False):
+    """rx_neumf_step: forward, BCE loss and backward of the list-wise NeuMF (embedding_dim 64) in one launch.
+    ``tables`` = (user_gmf, item_gmf, user_mlp, item_mlp) weights, ``weights`` = (w1, b1, w2, b2, wg, bg, wf, bf)
+    of linear_mlp.0, linear_mlp.3, linear_gmf, linear_final.  Returns (loss fp64 scalar, du_gmf [B, 64],
+    du_mlp [B, 64], di_gmf [B * N, 64], di_mlp [B * N, 64], flat weight gradients, logits [B, N] or None)."""
+    ug, ig, um, im = (_table(t, "embedding table") for t in tables)
+    w1, b1, w2, b2, wg, bg, wf, bf = (_req(t, torch.float32, "tower weight") for t in weights)
+    D = ug.shape[1]
+    if not (ig.shape[1] == D and um.shape == ug.shape and im.shape == ig.shape):
+        raise ValueError("neumf_step: the GMF and MLP tables must have equal shapes")
+    if tuple(w1.shape) != (D, 2 * D) or tuple(w2.shape) != (D // 2, D) or tuple(wg.shape) != (D // 2, D) or wf.numel() != D \
+            or b1.numel() != D or b2.numel() != D // 2 or bg.numel() != D // 2 or bf.numel() != 1:
+        raise ValueError("neumf_step: tower shapes must be 2D -> D -> D/2, GMF D -> D/2, final D -> 1")
+    users, items = _idx(users, "user_code"), _idx(items, "item_code")
+    if users.dim() != 1 or items.dim() != 2 or items.shape[0] != users.shape[0]:
+        raise ValueError("neumf_step: user_code [B] and item_code [B, N]")
+    B, N = items.shape
+    if labels.dtype not in (torch.float64, torch.float32):
+        raise TypeError(f"label: expected float64 or float32, got {labels.dtype}")
+    _req(labels, labels.dtype, "label")
+    if labels.numel() != B * N:
+        raise ValueError(f"label: expected {B * N} elements")
+    _same_device(ug, ig, um, im, users, items, labels, w1, b1, w2, b2, wg, bg, wf, bf, seed)
+    dev = ug.device
+    _err_flag(dev)          # (first use of the device: library set-up)
+    if seed is not None:
+        _req(seed, torch.int64, "seed")
+    du_g = torch.empty(B, D, dtype=torch.float32, device=dev)
+    du_m = torch.empty(B, D, dtype=torch.float32, device=dev)
+    di_g = torch.empty(B * N, D, dtype=torch.float32, device=dev)
+    di_m = torch.empty(B * N, D, dtype=torch.float32, device=dev)
+    wgrad = torch.empty(int(lib.rx_neumf_step_weight_floats()), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float64, device=dev)
+    logits = torch.empty(B, N, dtype=torch.float32, device=dev) if want_logits else None
+    a = _lib.NeuMFArgs()
+    a.user_gmf, a.item_gmf, a.user_mlp, a.item_mlp = ug.data_ptr(), ig.data_ptr(), um.data_ptr(), im.data_ptr()
+    a.n_users, a.n_items = ug.shape[0], ig.shape[0]
+    a.users, a.items, a.labels = users.data_ptr(), items.data_ptr(), labels.data_ptr()
+    a.labels_f64, a.N, a.B, a.dim = int(labels.dtype == torch.float64), N, B, D
+    a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    a.wg, a.bg, a.wf, a.bf = wg.data_ptr(), bg.data_ptr(), wf.data_ptr(), bf.data_ptr()
+    a.p_drop = float(p_drop)
+    a.seed = seed.data_ptr() if seed is not None else 0
+    a.du_gmf, a.du_mlp, a.di_gmf, a.di_mlp = du_g.data_ptr(), du_m.data_ptr(), di_g.data_ptr(), di_m.data_ptr()
+    a.wgrad, a.loss, a.logits = wgrad.data_ptr(), loss.data_ptr(), (logits.data_ptr() if logits is not None else 0)
+    ws = _ws(int(lib.rx_neumf_step_workspace_bytes(B, N)), dev)
+    check(lib.rx_neumf_step(C.byref(a), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(ug), _stream(ug)), "rx_neumf_step")
+    _after_index_op(dev)
+    return loss, du_g, du_m, di_g, di_m, wgrad, logits
+
+
 # ------------------------------------------------------------------ field-grouped backward (N == 1 field models)
 @dataclass
 class FieldGroups:

@@ -315,6 +315,73 @@ def test_reference_optimizer_as_a_graph_replay_hits_the_golden_adam_steps(fixtur
     assert o.step_count == 3
 
 
+@pytest.mark.parametrize("B,N", [(8192, 5), (333, 5), (70, 1), (9, 64), (1, 7), (40, 13)])
+def test_neumf_one_launch_step_matches_the_per_layer_path(B, N, monkeypatch):
+    """rx_neumf_step (forward + loss + backward of the list-wise NeuMF in one launch, embedding_dim 64) against
+    the per-layer path (gathers, GMF product, MFMA Linear layers, rx_bce_fwd, their backward kernels): loss to
+    fp64 rounding, every gradient to 1e-5 of its tensor's magnitude; tiles of whole samples are exercised with
+    N that does and does not divide 64, a last partial tile, a single sample."""
+    from recsys_amd import synthetic
+    from recsys_amd.models.neuralcf import NeuMF
+    d = synthetic.ML1M
+    g = torch.Generator().manual_seed(B * 100 + N)
+    batch = {"user_code": torch.randint(0, d["n_users"], (B,), generator=g).cuda(),
+             "item_code": torch.randint(0, d["n_items"], (B, N), generator=g).cuda(),
+             "label": (torch.rand(B, N, generator=g) < 0.3).double().cuda()}
+    res = []
+    for fused in (False, True):
+        if fused:
+            monkeypatch.delenv("RX_NO_FUSED_NEUMF", raising=False)
+        else:
+            monkeypatch.setenv("RX_NO_FUSED_NEUMF", "1")
+        torch.manual_seed(3)
+        m = NeuMF(d["n_users"], d["n_items"], 64, dropout=0.0).cuda().train()
+        with torch.no_grad():        # N(0, 0.01) embeddings leave tiny gradients: make the tower see real signal
+            for e in (m.user_embedding_gmf, m.item_embedding_gmf, m.user_embedding_mlp, m.item_embedding_mlp):
+                e.weight.mul_(30.0)
+            for lin in (m.linear_mlp[0], m.linear_mlp[3], m.linear_gmf, m.linear_final):
+                lin.bias.normal_(0, 0.1)
+        loss = m.loss(batch)
+        assert (type(loss.grad_fn).__name__ == "NeuMFLossBackward") == fused
+        loss.backward()
+        res.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (la, ga), (lb, gb) = res
+    assert_close(lb, la, rtol=1e-6, what="loss")
+    for k in ga:
+        assert_close(gb[k].cpu().numpy(), ga[k].cpu().numpy(), what=f"grad {k}", atol=1e-9)
+
+
+def test_neumf_one_launch_step_dropout_stream():
+    """The Dropout between the tower's layers inside rx_neumf_step: a counter-based draw keyed by the model's
+    device counter.  The same counter value reproduces the step bit for bit, the launch advances it, the next
+    call draws anew, and with p = 0.1 about a tenth of the first layer's units are off (seen through the
+    gradient of its bias: a dropped unit passes no gradient)."""
+    from recsys_amd import synthetic
+    from recsys_amd.models.neuralcf import NeuMF
+    d = synthetic.ML1M
+    batch = synthetic.ml1m_batch(2048, seed=1, device="cuda")
+    torch.manual_seed(0)
+    m = NeuMF(d["n_users"], d["n_items"], 64, dropout=0.1).cuda().train()
+
+    def step():
+        m.zero_grad()
+        loss = m.loss(batch)
+        loss.backward()
+        return loss.item(), m.linear_mlp[0].weight.grad.clone()
+
+    l1, g1 = step()
+    assert int(m._drop_seed.item()) == torch.initial_seed() % (2 ** 62) + 1
+    l2, g2 = step()
+    assert l1 != l2 and not torch.equal(g1, g2)
+    m._drop_seed.sub_(2)
+    l3, g3 = step()
+    assert l3 == l1 and torch.equal(g3, g1)
+    m.eval()
+    with torch.no_grad():
+        ev = m(batch)
+    assert torch.isfinite(ev).all()
+
+
 @pytest.mark.parametrize("name", ["VanillaMF", "BiasMF", "SideFeaturesMF", "TemporalMF", "GMF"])
 @pytest.mark.parametrize("label_dtype", [torch.float64, torch.float32])
 def test_fused_forward_loss_of_the_mf_family_equals_the_two_launch_path(name, label_dtype, monkeypatch):
