@@ -9,21 +9,31 @@
 //   logit = wf . [gm | h2] + bf                                      linear_final on cat([gmf, mlp])
 // and its loss the mean BCE over all B x N pairs (neumf.py:75-79), so dL/dlogit = (sigmoid(logit) - y) / (B N)
 // is known as soon as the pair's logit is: nothing in the backward pass of one pair waits for another pair.
-// The only sums across pairs are the weight gradients, the gradient of a user's rows over that user's N items,
-// and the loss.  A workgroup therefore takes a tile of whole samples (64 / N samples, at most 64 pairs), keeps
-// every activation of the tile in LDS, runs all nine matrix products of forward and backward on
-// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation), keeps its share of the weight gradients in
-// accumulator registers across its tiles, and leaves
+//
+// Nothing non-linear stands between linear_mlp.3 / linear_gmf and linear_final (neumf.py:44 removes the last
+// ReLU and Dropout), so with  t2 = W2^T wf[D/2:],  tg = Wg^T wf[:D/2],  c0 = bf + wf[:D/2].bg + wf[D/2:].b2
+//   logit = c0 + tg . zg + t2 . h1           zg = user_gmf[u] * item_gmf[i]
+//   dh1 = dl t2,   dzg = dl tg               dl = dL/dlogit of the pair
+//   dW2 = wf[D/2:] (x) v,   db2 = wf[D/2:] sum(dl),   v  = sum_pairs dl h1
+//   dWg = wf[:D/2] (x) vg,  dbg = wf[:D/2] sum(dl),   vg = sum_pairs dl zg
+//   dwf = [Wg vg + bg sum(dl) | W2 v + b2 sum(dl)],   dbf = sum(dl)
+// which leaves three matrix products per pair tile -- the first tower layer forward, and its two gradients
+// (dW1 += dz1^T x, dx = dz1 W1) -- on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  The
+// only sums across pairs are those weight-gradient terms, the gradient of a user's rows over that user's N
+// items, and the loss.  A workgroup takes tiles of whole samples (64 / N samples, at most 64 pairs), keeps the
+// tile's activations in LDS, keeps dW1 in accumulator registers across its tiles, fetches the rows of its next
+// tile while the gradient products of the current one run, and leaves
 //   du_g, du_m [B, D]      gradient of the user's GMF / MLP row, summed over the sample's N pairs (pair order)
 //   di_g, di_m [B N, D]    gradient of every pair's item rows
-//   wpart [grid][WP]       per-workgroup weight-gradient partials, added in workgroup order by the finish kernel
+//   raw [grid][NM_RAW]     per-workgroup [dW1 | db1 | v | vg | sum(dl)], added in workgroup order by the finish
+//                          kernel, which also expands v, vg, sum(dl) into the gradients of W2, b2, Wg, bg, wf, bf
 //   loss partials          fp64, one per workgroup
 // The embedding gradients then take the usual deterministic path (sort + segmented reduce, fused row update).
-// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 151 KB of LDS per workgroup.
+// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 101 KB of LDS per workgroup.
 //
 // LDS operands are read in the two patterns an MFMA lane needs -- (index = lane % 32, k = lane / 32) and
 // (k = lane / 32, index = lane % 32) -- from the same arrays; every array has an ODD row pitch, so both
-// patterns spread a wavefront's reads over all banks and each weight matrix is kept once (W1 as [in][out]).
+// patterns spread a wavefront's reads over all banks and W1 is kept once (as [in][out]).
 #include "rx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,26 +41,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NM_D 64
 #define NM_P 64       // pair rows of a tile (two MFMA row tiles)
 #define NM_LDX 129    // pitch of the tower input / its gradient [pair][2 D]
-#define NM_LD 65      // pitch of the 64-wide activation arrays
-#define NM_LDW 33     // pitch of the [in = 64][out = 32] weight arrays
-#define NM_WP (64 * 128 + 64 + 32 * 64 + 32 + 32 * 64 + 32 + 64 + 1)   // floats of one weight-gradient partial
+#define NM_LD 65      // pitch of the 64-wide arrays
+#define NM_WP (64 * 128 + 64 + 32 * 64 + 32 + 32 * 64 + 32 + 64 + 1)   // floats of the weight gradient [W1|b1|W2|b2|Wg|bg|wf|bf]
+#define NM_RAW (64 * 128 + 64 + 64 + 64 + 1)                            // floats of one workgroup's partial [dW1|db1|v|vg|sum dl]
+#define NM_RAW_V (64 * 128 + 64)
+#define NM_RAW_VG (NM_RAW_V + 64)
+#define NM_RAW_SDL (NM_RAW_VG + 64)
 #define NM_MAX_GRID 256
 
 // LDS map (floats)
 #define NM_OFF_X 0
-#define NM_OFF_ZG (NM_OFF_X + NM_P * NM_LDX)
-#define NM_OFF_H1 (NM_OFF_ZG + NM_P * NM_LD)
-#define NM_OFF_HG (NM_OFF_H1 + NM_P * NM_LD)
-#define NM_OFF_DHG (NM_OFF_HG + NM_P * NM_LD)
-#define NM_OFF_W1T (NM_OFF_DHG + NM_P * NM_LD)
-#define NM_OFF_W2T (NM_OFF_W1T + 128 * NM_LD)
-#define NM_OFF_WGT (NM_OFF_W2T + 64 * NM_LDW)
-#define NM_OFF_B1 (NM_OFF_WGT + 64 * NM_LDW)
-#define NM_OFF_B2 (NM_OFF_B1 + 64)
-#define NM_OFF_BG (NM_OFF_B2 + 32)
-#define NM_OFF_WF (NM_OFF_BG + 32)
-#define NM_OFF_DL (NM_OFF_WF + 64)
-#define NM_LDS_FLOATS (NM_OFF_DL + 64)
+#define NM_OFF_H1 (NM_OFF_X + NM_P * NM_LDX)
+#define NM_OFF_GU (NM_OFF_H1 + NM_P * NM_LD)
+#define NM_OFF_W1T (NM_OFF_GU + NM_P * NM_LD)
+#define NM_OFF_B1 (NM_OFF_W1T + 128 * NM_LD)
+#define NM_OFF_T2 (NM_OFF_B1 + 64)
+#define NM_OFF_TG (NM_OFF_T2 + 64)
+#define NM_OFF_DL (NM_OFF_TG + 64)
+#define NM_OFF_ZD (NM_OFF_DL + 64)
+#define NM_OFF_C0 (NM_OFF_ZD + 64)
+#define NM_LDS_FLOATS (NM_OFF_C0 + 4)
 
 struct NmArgs {
   const float *Ug, *Ig, *Um, *Im;
@@ -64,7 +74,7 @@ struct NmArgs {
   float p_drop;
   const int64_t* seed;    // device counter: the dropout stream of this call (NULL: 0)
   float *du_g, *du_m, *di_g, *di_m;
-  float* wpart;
+  float* raw;
   double* loss_part;
   float* logits;          // optional [B * N]
   int32_t* err_flag;
@@ -80,82 +90,215 @@ __device__ __forceinline__ uint64_t nm_mix(uint64_t seed, uint64_t counter) {
 
 #define NM_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))   // row of accumulator register r inside a 32 x 32 tile
 
+// Row-chunk mapping of the gathers and the per-pair outputs: thread -> columns qc .. qc + 3 of the pairs
+// qp, qp + 16, qp + 32, qp + 48 of a tile (a float4 of each of the pair's four rows).
+struct NmIdx {
+  int64_t u[4], it[4];
+  unsigned have;          // bit k: the tile has a pair qp + 16 k
+};
+
+__device__ __forceinline__ void nm_load_idx(const NmArgs& a, int64_t tile, int64_t tiles, int S, int N, int qp, NmIdx& x) {
+  x.have = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x.u[k] = 0; x.it[k] = 0; }
+  if (tile >= tiles) return;
+  const int64_t s0 = tile * S;
+  const int ns = (int)((a.B - s0 < S) ? a.B - s0 : S);
+  const int PT = ns * N;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = qp + 16 * k;
+    if (p < PT) {
+      x.u[k] = a.users[s0 + p / N];
+      x.it[k] = a.items[s0 * N + p];
+      x.have |= 1u << k;
+    }
+  }
+}
+
+// Row offsets of the fetch: a missing pair or an index outside its table reads row 0 (and is masked at use).
+// Returns the bits of the pairs whose rows count.
+__device__ __forceinline__ unsigned nm_row_offsets(const NmArgs& a, const NmIdx& x, int64_t (&ou)[4], int64_t (&oi)[4], bool& bad) {
+  unsigned ok = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t u = x.u[k], it = x.it[k];
+    const bool in = u >= 0 && u < a.n_users && it >= 0 && it < a.n_items;
+    const bool have = (x.have >> k) & 1u;
+    bad |= have && !in;
+    ok |= (have && in) ? 1u << k : 0u;
+    ou[k] = (in ? u : 0) * NM_D;
+    oi[k] = (in ? it : 0) * NM_D;
+  }
+  return ok;
+}
+
+// Issues the four row loads of every pair of the mapping and returns at once.  The loads are unconditional so
+// that nothing but the loads defines the registers: the wait for them then sits at their first use, a whole
+// phase of matrix products later, where nm_mask_rows() zeroes what was not a pair.
+__device__ __forceinline__ void nm_load_rows(const NmArgs& a, const int64_t (&ou)[4], const int64_t (&oi)[4], int qc, float4 (&um)[4], float4 (&im)[4],
+                                             float4 (&ug)[4], float4 (&ig)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    um[k] = *reinterpret_cast<const float4*>(a.Um + ou[k] + qc);
+    im[k] = *reinterpret_cast<const float4*>(a.Im + oi[k] + qc);
+    ug[k] = *reinterpret_cast<const float4*>(a.Ug + ou[k] + qc);
+    ig[k] = *reinterpret_cast<const float4*>(a.Ig + oi[k] + qc);
+  }
+}
+
+__device__ __forceinline__ void nm_mask_rows(unsigned ok, float4 (&um)[4], float4 (&im)[4], float4 (&ug)[4], float4 (&ig)[4]) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (!((ok >> k) & 1u)) { um[k] = z; im[k] = z; ug[k] = z; ig[k] = z; }
+}
+
+// acc += A B over k = 0 .. 2 STEPS - 1 on v_mfma_f32_32x32x2_f32, operands in LDS: this lane's A element of step t
+// at ap[2 t SA], its B element at bp[2 t SB] (both pointers already at the lane's index and k half).  The
+// operands of the next eight steps are read while the eight products of the current ones run: with one
+// wavefront per SIMD nothing else hides the LDS latency, and the scheduler left alone reads two operands,
+// waits, and multiplies twice.
+template <int STEPS, int SA, int SB>
+__device__ __forceinline__ void nm_mm(f32x16& acc, const float* ap, const float* bp) {
+  float av[2][8], bv[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; }
+#pragma unroll
+  for (int b = 0; b < STEPS / 8; ++b) {
+    if (b + 1 < STEPS / 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        av[(b + 1) & 1][j] = ap[2 * (8 * (b + 1) + j) * SA];
+        bv[(b + 1) & 1][j] = bp[2 * (8 * (b + 1) + j) * SB];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// two products with one A operand: acc1 += A B, acc2 += A B' with B' = B + BOFF floats
+template <int STEPS, int SA, int SB, int BOFF>
+__device__ __forceinline__ void nm_mm2(f32x16& acc1, f32x16& acc2, const float* ap, const float* bp) {
+  float av[2][4], bv[2][4], cv[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; cv[0][j] = bp[2 * j * SB + BOFF]; }
+#pragma unroll
+  for (int b = 0; b < STEPS / 4; ++b) {
+    if (b + 1 < STEPS / 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[(b + 1) & 1][j] = ap[2 * (4 * (b + 1) + j) * SA];
+        bv[(b + 1) & 1][j] = bp[2 * (4 * (b + 1) + j) * SB];
+        cv[(b + 1) & 1][j] = bp[2 * (4 * (b + 1) + j) * SB + BOFF];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], cv[b & 1][j], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <bool F64>
 __global__ void __launch_bounds__(RX_BLOCK)
 neumf_step_kernel(NmArgs a) {
   extern __shared__ float lds[];
-  float* X = lds + NM_OFF_X;
-  float* ZG = lds + NM_OFF_ZG;
-  float* H1 = lds + NM_OFF_H1;
-  float* HG = lds + NM_OFF_HG;
-  float* DHG = lds + NM_OFF_DHG;
-  float* W1T = lds + NM_OFF_W1T;
-  float* W2T = lds + NM_OFF_W2T;
-  float* WGT = lds + NM_OFF_WGT;
+  float* X = lds + NM_OFF_X;       // tower input [pair][2 D]; its gradient once the products that read it are done
+  float* H1 = lds + NM_OFF_H1;     // h1 [pair][D]; dz1 once the logit is known
+  float* GU = lds + NM_OFF_GU;     // the pair's share of the user's GMF-row gradient
+  float* W1T = lds + NM_OFF_W1T;   // W1 as [in][out]
   float* B1 = lds + NM_OFF_B1;
-  float* B2 = lds + NM_OFF_B2;
-  float* BG = lds + NM_OFF_BG;
-  float* WF = lds + NM_OFF_WF;
+  float* T2 = lds + NM_OFF_T2;
+  float* TG = lds + NM_OFF_TG;
   float* DL = lds + NM_OFF_DL;
+  float* ZD = lds + NM_OFF_ZD;     // tg . zg of the pair
+  float* C0 = lds + NM_OFF_C0;
   __shared__ double lsum_w[RX_BLOCK / 64];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
+  const int qc = (tid & 15) * 4, qp = tid >> 4;
   const int N = a.N;
   const int S = NM_P / N;                       // whole samples per tile
   const int64_t tiles = (a.B + S - 1) / S;
   const double inv_m = 1.0 / ((double)a.B * (double)N);
 
-  // weights: W1 [64][128] -> W1T[c][h]; W2, Wg [32][64] -> [c][o]
+  // the first tile's rows are on their way while the weights are laid out
+  NmIdx ix;
+  float4 rum[4], rim[4], rug[4], rig[4];
+  nm_load_idx(a, blockIdx.x, tiles, S, N, qp, ix);
+  int64_t ou[4], oi[4];
+  bool bad = false;
+  unsigned rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
+  nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
+
   for (int i = tid; i < 64 * 128; i += RX_BLOCK) W1T[(i & 127) * NM_LD + (i >> 7)] = a.W1[i];
-  for (int i = tid; i < 32 * 64; i += RX_BLOCK) {
-    W2T[(i & 63) * NM_LDW + (i >> 6)] = a.W2[i];
-    WGT[(i & 63) * NM_LDW + (i >> 6)] = a.Wg[i];
+  if (tid < 64) {
+    float s = 0.f;
+    for (int o = 0; o < 32; ++o) s += a.wf[32 + o] * a.W2[o * 64 + tid];
+    T2[tid] = s;
+    B1[tid] = a.b1[tid];
+  } else if (tid < 128) {
+    float s = 0.f;
+    for (int o = 0; o < 32; ++o) s += a.wf[o] * a.Wg[o * 64 + (tid - 64)];
+    TG[tid - 64] = s;
+  } else if (tid == 128) {
+    float s = a.bf[0];
+    for (int o = 0; o < 32; ++o) s += a.wf[o] * a.bg[o];
+    for (int o = 0; o < 32; ++o) s += a.wf[32 + o] * a.b2[o];
+    C0[0] = s;
   }
-  if (tid < 64) { B1[tid] = a.b1[tid]; WF[tid] = a.wf[tid]; }
-  if (tid < 32) { B2[tid] = a.b2[tid]; BG[tid] = a.bg[tid]; }
-  const float bf = a.bf[0];
   const uint64_t seed = a.seed ? (uint64_t)a.seed[0] : 0ull;
   const bool drop = a.p_drop > 0.f;
   const uint32_t thr = drop ? (uint32_t)((double)a.p_drop * 4294967296.0) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.p_drop) : 1.f;
 
-  f32x16 dW1a[2], dWs;
+  f32x16 dW1a[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dW1a[0][r] = 0.f; dW1a[1][r] = 0.f; dWs[r] = 0.f; }
-  float bsum = 0.f;       // this thread's bias-type gradient: dwf[tid] | dbf | db2 | dbg | db1 by thread range
+  for (int r = 0; r < 16; ++r) { dW1a[0][r] = 0.f; dW1a[1][r] = 0.f; }
+  float va = 0.f, db1a = 0.f;       // column (tid % 64) of v and db1 over the pairs 16 wave .. 16 wave + 15 of every tile
+  float vga[4] = {0.f, 0.f, 0.f, 0.f};   // columns qc .. qc + 3 of vg over this thread's pairs
+  float sdl = 0.f;                  // sum of dl over the pair tid / 4 of every tile (threads with tid % 4 == 0)
   double lsum = 0.0;
-  bool bad = false;
   __syncthreads();
+  const float t2c = T2[tid & 63];
+  const float4 tg4 = make_float4(TG[qc], TG[qc + 1], TG[qc + 2], TG[qc + 3]);
+  const float c0 = C0[0];
 
+#ifdef NM_PHASE_TIMES
+  long long stamp[9] = {};
+#define NM_STAMP(i) if (tile == blockIdx.x + gridDim.x) stamp[i] = wall_clock64()
+#else
+#define NM_STAMP(i)
+#endif
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    NM_STAMP(0);
     const int64_t s0 = tile * S;
     const int ns = (int)((a.B - s0 < S) ? a.B - s0 : S);
     const int PT = ns * N;
     const int64_t p0 = s0 * N;                  // first pair of the tile (pairs of a tile are contiguous)
-    // ---- 1. gather: tower input and GMF product
-    for (int q = tid; q < NM_P * 16; q += RX_BLOCK) {
-      const int p = q >> 4, c = (q & 15) * 4;
-      float4 um = make_float4(0.f, 0.f, 0.f, 0.f), im = um, ug = um, ig = um;
-      if (p < PT) {
-        const int64_t u = a.users[s0 + p / N], it = a.items[p0 + p];
-        const bool ok = u >= 0 && u < a.n_users && it >= 0 && it < a.n_items;
-        if (ok) {
-          um = *reinterpret_cast<const float4*>(a.Um + u * NM_D + c);
-          im = *reinterpret_cast<const float4*>(a.Im + it * NM_D + c);
-          ug = *reinterpret_cast<const float4*>(a.Ug + u * NM_D + c);
-          ig = *reinterpret_cast<const float4*>(a.Ig + it * NM_D + c);
-        } else {
-          bad = true;
-        }
-      }
-      float* xr = X + p * NM_LDX + c;
-      xr[0] = um.x; xr[1] = um.y; xr[2] = um.z; xr[3] = um.w;
-      xr[64] = im.x; xr[65] = im.y; xr[66] = im.z; xr[67] = im.w;
-      float* zr = ZG + p * NM_LD + c;
-      zr[0] = ug.x * ig.x; zr[1] = ug.y * ig.y; zr[2] = ug.z * ig.z; zr[3] = ug.w * ig.w;
+    nm_load_idx(a, tile + gridDim.x, tiles, S, N, qp, ix);   // the next tile's indices: used after the logits
+    // ---- 1. the fetched rows: tower input into LDS, tg . zg of every pair
+    nm_mask_rows(rows_ok, rum, rim, rug, rig);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = qp + 16 * k;
+      float* xr = X + p * NM_LDX + qc;
+      xr[0] = rum[k].x; xr[1] = rum[k].y; xr[2] = rum[k].z; xr[3] = rum[k].w;
+      xr[64] = rim[k].x; xr[65] = rim[k].y; xr[66] = rim[k].z; xr[67] = rim[k].w;
+      float zd = (rug[k].x * rig[k].x) * tg4.x + (rug[k].y * rig[k].y) * tg4.y + (rug[k].z * rig[k].z) * tg4.z + (rug[k].w * rig[k].w) * tg4.w;
+      zd = rx_group_sum(zd, 16);
+      if ((tid & 15) == 0) ZD[p] = zd;
     }
     __syncthreads();
+    NM_STAMP(1);
     // ---- 2. h1 = dropout(relu(x W1^T + b1)): wave -> 32 x 32 tile (rt, ct) of [64 pairs, 64 units]
     {
       const int rt = wave >> 1, ct = wave & 1;
@@ -164,8 +307,7 @@ neumf_step_kernel(NmArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* ap = X + (rt * 32 + l31) * NM_LDX + hh;
       const float* bp = W1T + hh * NM_LD + ct * 32 + l31;
-#pragma unroll 8
-      for (int kk = 0; kk < 128; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * NM_LD], acc, 0, 0, 0);
+      nm_mm<64, 1, NM_LD>(acc, ap, bp);
       const int col = ct * 32 + l31;
       const float bv = B1[col];
 #pragma unroll
@@ -181,125 +323,80 @@ neumf_step_kernel(NmArgs a) {
       }
     }
     __syncthreads();
-    // ---- 3. h2 = h1 W2^T + b2 (waves 0, 1) and gm = zg Wg^T + bg (waves 2, 3): 32 rows each, 32 units
+    NM_STAMP(2);
+    // ---- 3. logit = c0 + tg . zg + t2 . h1 (four threads per pair), BCE term (fp64), dL/dlogit
+    // The next tile's row offsets are taken here, pinned in registers: the indices arrived two phases ago, and
+    // a wait placed behind the label loads and gradient stores below would wait for those as well.
+    rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ou[k]), "+v"(oi[k]));
     {
-      const int rt = wave & 1;
-      const bool mlp = wave < 2;
-      f32x16 acc;
+      const int p = tid >> 2, part = (tid & 3) * 16;
+      const float* hp = H1 + p * NM_LD + part;
+      float x = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* ap = (mlp ? H1 : ZG) + (rt * 32 + l31) * NM_LD + hh;
-      const float* bp = (mlp ? W2T : WGT) + hh * NM_LDW + l31;
-#pragma unroll 8
-      for (int kk = 0; kk < 64; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * NM_LDW], acc, 0, 0, 0);
-      const float bv = mlp ? B2[l31] : BG[l31];
-      const int col = (mlp ? 32 : 0) + l31;         // linear_final reads [gmf | mlp]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + NM_ROW(r, hh);
-        HG[row * NM_LD + col] = row < PT ? acc[r] + bv : 0.f;
+      for (int j = 0; j < 16; ++j) x += hp[j] * T2[part + j];
+      x = rx_group_sum(x, 4);
+      if ((tid & 3) == 0) {
+        float dl = 0.f;
+        if (p < PT) {
+          x += c0 + ZD[p];
+          if (a.logits) a.logits[p0 + p] = x;
+          const double xd = (double)x;
+          const double y = F64 ? reinterpret_cast<const double*>(a.labels)[p0 + p] : (double)reinterpret_cast<const float*>(a.labels)[p0 + p];
+          const double e = exp(-fabs(xd));
+          lsum += fmax(xd, 0.0) - xd * y + log1p(e);
+          const double sig = xd >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+          dl = (float)((sig - y) * inv_m);
+        }
+        DL[p] = dl;
+        sdl += dl;
       }
     }
     __syncthreads();
-    // ---- 4. logit, BCE term (fp64), dL/dlogit: one thread per pair
-    if (tid < NM_P) {
-      float dl = 0.f;
-      if (tid < PT) {
-        float x = bf;
-        const float* hp = HG + tid * NM_LD;
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) x += hp[j] * WF[j];
-        if (a.logits) a.logits[p0 + tid] = x;
-        const double xd = (double)x;
-        const double y = F64 ? reinterpret_cast<const double*>(a.labels)[p0 + tid] : (double)reinterpret_cast<const float*>(a.labels)[p0 + tid];
-        const double e = exp(-fabs(xd));
-        lsum += fmax(xd, 0.0) - xd * y + log1p(e);
-        const double sig = xd >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
-        dl = (float)((sig - y) * inv_m);
-      }
-      DL[tid] = dl;
-    }
-    __syncthreads();
-    // ---- 5. d[gm | h2] = dl * wf; gradients of wf and bf
-    for (int q = tid; q < NM_P * 64; q += RX_BLOCK) DHG[(q >> 6) * NM_LD + (q & 63)] = DL[q >> 6] * WF[q & 63];
-    if (tid < 64) {
-      float t = 0.f;
-      for (int p = 0; p < NM_P; ++p) t += DL[p] * HG[p * NM_LD + tid];
-      bsum += t;
-    } else if (tid == 64) {
-      float t = 0.f;
-      for (int p = 0; p < NM_P; ++p) t += DL[p];
-      bsum += t;
-    }
-    __syncthreads();
-    // ---- 6. dW2 += dh2^T h1, dWg += dgm^T zg (one 32 x 32 tile per wave, k = pairs); dh1 = dh2 W2, dzg = dgm Wg
-    f32x16 acc1, acc2;
+    NM_STAMP(3);
+    // ---- 4. v += dl h1, dz1 = dl t2 through the dropout scale and the ReLU (in place), db1 += dz1;
+    //         vg += dl zg, item GMF gradients out, the pair's share of the user's GMF gradient into LDS
     {
-      const bool mlp = wave < 2;
-      const int ct = wave & 1;
-      const float* ap = DHG + hh * NM_LD + (mlp ? 32 : 0) + l31;         // A[i = unit][k = pair]
-      const float* bp = (mlp ? H1 : ZG) + hh * NM_LD + ct * 32 + l31;    // B[k = pair][j = input]
-#pragma unroll 8
-      for (int kk = 0; kk < NM_P; kk += 2) dWs = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * NM_LD], bp[kk * NM_LD], dWs, 0, 0, 0);
-      const int rt = wave >> 1, c2 = wave & 1;
+      const int c = tid & 63;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
-      const float* a1 = DHG + (rt * 32 + l31) * NM_LD + 32 + hh;         // A[i = pair][k = unit of h2]
-      const float* b1p = W2T + (c2 * 32 + l31) * NM_LDW + hh;            // B[k = unit][j = input] = W2[unit][input]
-      const float* a2 = DHG + (rt * 32 + l31) * NM_LD + hh;
-      const float* b2p = WGT + (c2 * 32 + l31) * NM_LDW + hh;
-#pragma unroll 8
-      for (int kk = 0; kk < 32; kk += 2) {
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1p[kk], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], b2p[kk], acc2, 0, 0, 0);
-      }
-      if (tid >= 65 && tid < 129) {      // db2[o] (65..96), dbg[o] (97..128): column sums of d[gm | h2]
-        const int col = tid < 97 ? 32 + (tid - 65) : tid - 97;
-        float t = 0.f;
-        for (int p = 0; p < NM_P; ++p) t += DHG[p * NM_LD + col];
-        bsum += t;
+      for (int p = wave * 16; p < wave * 16 + 16; ++p) {
+        const float h = H1[p * NM_LD + c], dl = DL[p];
+        va += dl * h;
+        const float dz = h > 0.f ? (dl * t2c) * inv_keep : 0.f;
+        db1a += dz;
+        H1[p * NM_LD + c] = dz;
       }
     }
-    __syncthreads();      // every read of h1 and zg is done: they now take the gradients
-    {
-      const int rt = wave >> 1, c2 = wave & 1;
-      const int col = c2 * 32 + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + NM_ROW(r, hh);
-        const float h = H1[row * NM_LD + col];
-        H1[row * NM_LD + col] = h > 0.f ? acc1[r] * inv_keep : 0.f;     // through the dropout scale and the ReLU
-        ZG[row * NM_LD + col] = acc2[r];
-      }
+    for (int k = 0; k < 4; ++k) {
+      const int p = qp + 16 * k;
+      const float dl = DL[p];
+      vga[0] += dl * (rug[k].x * rig[k].x); vga[1] += dl * (rug[k].y * rig[k].y);
+      vga[2] += dl * (rug[k].z * rig[k].z); vga[3] += dl * (rug[k].w * rig[k].w);
+      const float4 dz = make_float4(dl * tg4.x, dl * tg4.y, dl * tg4.z, dl * tg4.w);
+      if (p < PT) *reinterpret_cast<float4*>(a.di_g + (p0 + p) * NM_D + qc) = make_float4(dz.x * rug[k].x, dz.y * rug[k].y, dz.z * rug[k].z, dz.w * rug[k].w);
+      float* gr = GU + p * NM_LD + qc;
+      gr[0] = dz.x * rig[k].x; gr[1] = dz.y * rig[k].y; gr[2] = dz.z * rig[k].z; gr[3] = dz.w * rig[k].w;
     }
+    // the next tile's rows travel while the gradient products below run
+    nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
     __syncthreads();
-    // ---- 7. dW1 += dz1^T x (two tiles per wave); dx = dz1 W1 (two tiles per wave); db1
+    NM_STAMP(4);
+    // ---- 5. dW1 += dz1^T x (two tiles per wave); dx = dz1 W1 (two tiles per wave)
     {
+      f32x16 acc1, acc2;
       const int ht = wave & 1, cp = wave >> 1;
       const float* ap = H1 + hh * NM_LD + ht * 32 + l31;                 // A[i = unit][k = pair]
       const float* bp = X + hh * NM_LDX + cp * 64 + l31;                 // B[k = pair][j = input]
-#pragma unroll 4
-      for (int kk = 0; kk < NM_P; kk += 2) {
-        const float av = ap[kk * NM_LD];
-        dW1a[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[kk * NM_LDX], dW1a[0], 0, 0, 0);
-        dW1a[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[kk * NM_LDX + 32], dW1a[1], 0, 0, 0);
-      }
+      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[1], ap, bp);
       const int rt = wave & 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
       const float* a1 = H1 + (rt * 32 + l31) * NM_LD + hh;               // A[i = pair][k = unit]
       const float* b1p = W1T + (cp * 64 + l31) * NM_LD + hh;             // B[k = unit][j = input] = W1[unit][input]
-#pragma unroll 4
-      for (int kk = 0; kk < 64; kk += 2) {
-        const float av = a1[kk];
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1p[kk], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1p[32 * NM_LD + kk], acc2, 0, 0, 0);
-      }
-      if (tid >= 129 && tid < 193) {     // db1[h]
-        float t = 0.f;
-        for (int p = 0; p < NM_P; ++p) t += H1[p * NM_LD + (tid - 129)];
-        bsum += t;
-      }
+      nm_mm2<32, 1, 1, 32 * NM_LD>(acc1, acc2, a1, b1p);
+      NM_STAMP(5);
       __syncthreads();    // every read of x is done: it now takes dx
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -309,39 +406,41 @@ neumf_step_kernel(NmArgs a) {
       }
     }
     __syncthreads();
-    // ---- 8. embedding gradients out: items per pair, users summed over the sample's pairs in pair order
-    for (int q = tid; q < PT * 16; q += RX_BLOCK) {
-      const int p = q >> 4, c = (q & 15) * 4;
-      const int64_t u = a.users[s0 + p / N];
-      const bool ok = u >= 0 && u < a.n_users;
-      const float4 ug = ok ? *reinterpret_cast<const float4*>(a.Ug + u * NM_D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* xr = X + p * NM_LDX + 64 + c;
-      const float* zr = ZG + p * NM_LD + c;
-      *reinterpret_cast<float4*>(a.di_m + (p0 + p) * NM_D + c) = make_float4(xr[0], xr[1], xr[2], xr[3]);
-      *reinterpret_cast<float4*>(a.di_g + (p0 + p) * NM_D + c) = make_float4(zr[0] * ug.x, zr[1] * ug.y, zr[2] * ug.z, zr[3] * ug.w);
+    NM_STAMP(6);
+    // ---- 6. embedding gradients out: item MLP rows per pair, user rows summed over the sample's pairs in pair order
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = qp + 16 * k;
+      if (p < PT) {
+        const float* xr = X + p * NM_LDX + 64 + qc;
+        *reinterpret_cast<float4*>(a.di_m + (p0 + p) * NM_D + qc) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+      }
     }
     for (int q = tid; q < ns * 16; q += RX_BLOCK) {
       const int s = q >> 4, c = (q & 15) * 4;
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), g = m;
       for (int n = 0; n < N; ++n) {
-        const int p = s * N + n;
-        const int64_t it = a.items[p0 + p];
-        const bool ok = it >= 0 && it < a.n_items;
-        const float4 ig = ok ? *reinterpret_cast<const float4*>(a.Ig + it * NM_D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* xr = X + p * NM_LDX + c;
-        const float* zr = ZG + p * NM_LD + c;
+        const float* xr = X + (s * N + n) * NM_LDX + c;
+        const float* gr = GU + (s * N + n) * NM_LD + c;
         m.x += xr[0]; m.y += xr[1]; m.z += xr[2]; m.w += xr[3];
-        g.x += zr[0] * ig.x; g.y += zr[1] * ig.y; g.z += zr[2] * ig.z; g.w += zr[3] * ig.w;
+        g.x += gr[0]; g.y += gr[1]; g.z += gr[2]; g.w += gr[3];
       }
       *reinterpret_cast<float4*>(a.du_m + (s0 + s) * NM_D + c) = m;
       *reinterpret_cast<float4*>(a.du_g + (s0 + s) * NM_D + c) = g;
     }
     __syncthreads();
+    NM_STAMP(7);
   }
+#ifdef NM_PHASE_TIMES
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+    printf("block %d phases (10 ns ticks): stage %lld  h1 %lld  logit %lld  dz %lld  mfma %lld  dx %lld  out %lld  | tile %lld\n", (int)blockIdx.x,
+           stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5],
+           stamp[7] - stamp[6], stamp[7] - stamp[0]);
+#endif
 
   if (bad && a.err_flag) atomicOr(a.err_flag, RX_ERR_INDEX);
-  // ---- this workgroup's weight-gradient partial: [W1 | b1 | W2 | b2 | Wg | bg | wf | bf]
-  float* wp = a.wpart + (size_t)blockIdx.x * NM_WP;
+  // ---- this workgroup's partial: [dW1 | db1 | v | vg | sum dl]; the thread-level pieces meet in LDS, fixed order
+  float* wp = a.raw + (size_t)blockIdx.x * NM_RAW;
   {
     const int ht = wave & 1, cp = wave >> 1;
 #pragma unroll
@@ -350,44 +449,124 @@ neumf_step_kernel(NmArgs a) {
       wp[h * 128 + cp * 64 + l31] = dW1a[0][r];
       wp[h * 128 + cp * 64 + 32 + l31] = dW1a[1][r];
     }
-    float* w2 = wp + 64 * 128 + 64 + (wave < 2 ? 0 : 32 * 64 + 32);
-    const int ct = wave & 1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w2[NM_ROW(r, hh) * 64 + ct * 32 + l31] = dWs[r];
   }
-  float* pb1 = wp + 64 * 128;
-  float* pb2 = pb1 + 64 + 32 * 64;
-  float* pbg = pb2 + 32 + 32 * 64;
-  float* pwf = pbg + 32;
-  if (tid < 64) pwf[tid] = bsum;
-  else if (tid == 64) pwf[64] = bsum;
-  else if (tid < 97) pb2[tid - 65] = bsum;
-  else if (tid < 129) pbg[tid - 97] = bsum;
-  else if (tid < 193) pb1[tid - 129] = bsum;
+  float* red = X;
+  red[wave * 64 + lane] = db1a;
+  red[256 + wave * 64 + lane] = va;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[512 + qp * 64 + qc + e] = vga[e];
+  if ((tid & 3) == 0) red[1536 + (tid >> 2)] = sdl;
   lsum = rx_wave_sum_f64(lsum);
   if (lane == 0) lsum_w[wave] = lsum;
   __syncthreads();
+  if (tid < 64) {
+    wp[64 * 128 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    wp[NM_RAW_V + tid] = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+  } else if (tid < 128) {
+    float s = 0.f;
+    for (int g = 0; g < 16; ++g) s += red[512 + g * 64 + (tid - 64)];
+    wp[NM_RAW_VG + (tid - 64)] = s;
+  } else if (tid < 192) {
+    const float s = rx_wave_sum(red[1536 + (tid - 128)]);
+    if (tid == 128) wp[NM_RAW_SDL] = s;
+  }
   if (tid == 0) a.loss_part[blockIdx.x] = (lsum_w[0] + lsum_w[1]) + (lsum_w[2] + lsum_w[3]);
 }
 
-// Adds the workgroups' partials in workgroup order (fixed tree: bitwise reproducible), finishes the loss and
-// advances the dropout counter.
-__global__ void __launch_bounds__(RX_BLOCK)
-neumf_finish_kernel(const float* __restrict__ wpart, int n_parts, float* __restrict__ wgrad, const double* __restrict__ loss_part,
-                    double count, double* __restrict__ loss, int64_t* seed) {
-  const int i = blockIdx.x * RX_BLOCK + threadIdx.x;
-  if (i < NM_WP) {
-    float s = 0.f;
-    for (int b = 0; b < n_parts; ++b) s += wpart[(size_t)b * NM_WP + i];
-    wgrad[i] = s;
+// Adds the workgroups' partials in a fixed order (bitwise reproducible), expands v, vg and sum(dl) into the
+// gradients of the layers behind the first tower layer, finishes the loss and advances the dropout counter.
+struct NmFin {
+  const float* raw;
+  int n_parts;
+  float* wgrad;           // [W1 | b1 | W2 | b2 | Wg | bg | wf | bf]
+  const float *W2, *b2, *Wg, *bg, *wf;
+  const double* loss_part;
+  double count;
+  double* loss;
+  int64_t* seed;
+};
+
+#define NM_FB 1024
+#define NM_FIN_W1_BLOCKS ((64 * 128 + 64) / 64)     // 129 blocks of 64 columns: dW1 and db1 keep their places
+#define NM_FIN_BLOCKS (NM_FIN_W1_BLOCKS + 2 + 2 + 1)
+#define NM_WG_W2 (64 * 128 + 64)
+#define NM_WG_B2 (NM_WG_W2 + 32 * 64)
+#define NM_WG_WG (NM_WG_B2 + 32)
+#define NM_WG_BG (NM_WG_WG + 32 * 64)
+#define NM_WG_WF (NM_WG_BG + 32)
+#define NM_WG_BF (NM_WG_WF + 64)
+
+// columns col0 .. col0 + 63 of the partials: 16 thread groups take n_parts / 16 partials each, then meet in order
+__device__ __forceinline__ void nm_reduce64(const float* __restrict__ raw, int n_parts, int col0, float* part, float* out) {
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int chunk = (n_parts + 15) >> 4;        // at most NM_MAX_GRID / 16 = 16 partials: all loads in flight at once
+  const int b0 = g * chunk;
+  float v[NM_MAX_GRID / 16];
+#pragma unroll
+  for (int k = 0; k < NM_MAX_GRID / 16; ++k) {
+    const int b = b0 + k;
+    v[k] = (k < chunk && b < n_parts) ? raw[(size_t)b * NM_RAW + col0 + c] : 0.f;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < n_parts; b += 64) s += loss_part[b];
-    s = rx_wave_sum_f64(s);
-    if (threadIdx.x == 0) {
-      loss[0] = s / count;
-      if (seed) seed[0] = seed[0] + 1;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NM_MAX_GRID / 16; ++k) s += v[k];
+  part[g * 64 + c] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k * 64 + c];
+    out[c] = t;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(NM_FB)
+neumf_finish_kernel(NmFin f) {
+  __shared__ float part[16 * 64];
+  __shared__ float outv[64], outg[64], sd[1];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (b < NM_FIN_W1_BLOCKS) {
+    nm_reduce64(f.raw, f.n_parts, b * 64, part, outv);
+    if (tid < 64) f.wgrad[b * 64 + tid] = outv[tid];
+  } else if (b < NM_FIN_W1_BLOCKS + 2) {           // dW2[o][c] = wf[D/2 + o] v[c]
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_V, part, outv);
+    const int idx = (b - NM_FIN_W1_BLOCKS) * NM_FB + tid;
+    f.wgrad[NM_WG_W2 + idx] = f.wf[32 + (idx >> 6)] * outv[idx & 63];
+  } else if (b < NM_FIN_W1_BLOCKS + 4) {           // dWg[o][c] = wf[o] vg[c]
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_VG, part, outv);
+    const int idx = (b - NM_FIN_W1_BLOCKS - 2) * NM_FB + tid;
+    f.wgrad[NM_WG_WG + idx] = f.wf[idx >> 6] * outv[idx & 63];
+  } else {
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_V, part, outv);
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_VG, part, outg);
+    if (tid < 64) {
+      float s = 0.f;
+      for (int k = tid; k < f.n_parts; k += 64) s += f.raw[(size_t)k * NM_RAW + NM_RAW_SDL];
+      s = rx_wave_sum(s);
+      if (tid == 0) sd[0] = s;
+      double l = 0.0;
+      for (int k = tid; k < f.n_parts; k += 64) l += f.loss_part[k];
+      l = rx_wave_sum_f64(l);
+      if (tid == 0) {
+        f.loss[0] = l / f.count;
+        if (f.seed) f.seed[0] = f.seed[0] + 1;
+      }
+    }
+    __syncthreads();
+    const float sdl = sd[0];
+    if (tid < 32) {
+      f.wgrad[NM_WG_B2 + tid] = f.wf[32 + tid] * sdl;
+      f.wgrad[NM_WG_BG + tid] = f.wf[tid] * sdl;
+    } else if (tid >= 64 && tid < 128) {
+      const int j = tid - 64, o = j & 31;
+      const float* w = (j < 32 ? f.Wg : f.W2) + o * 64;
+      const float* x = j < 32 ? outg : outv;
+      float s = 0.f;
+      for (int c = 0; c < 64; ++c) s += w[c] * x[c];
+      f.wgrad[NM_WG_WF + j] = s + (j < 32 ? f.bg[o] : f.b2[o]) * sdl;
+    } else if (tid == 128) {
+      f.wgrad[NM_WG_BF] = sdl;
     }
   }
 }
@@ -395,7 +574,10 @@ neumf_finish_kernel(const float* __restrict__ wpart, int n_parts, float* __restr
 static int nm_grid(int64_t B, int N) {
   const int S = NM_P / N;
   const int64_t tiles = (B + S - 1) / S;
-  return (int)(tiles < NM_MAX_GRID ? tiles : NM_MAX_GRID);
+  // every workgroup takes the same number of tiles: the launch is as long as its busiest compute unit either
+  // way, and the units it leaves free run whatever else is in flight (the index preparation of the next step)
+  const int64_t rounds = (tiles + NM_MAX_GRID - 1) / NM_MAX_GRID;
+  return (int)((tiles + rounds - 1) / rounds);
 }
 
 extern "C" int rx_neumf_step_supported(int32_t dim, int32_t N) { return dim == NM_D && N >= 1 && N <= NM_P; }
@@ -405,7 +587,7 @@ extern "C" int64_t rx_neumf_step_weight_floats(void) { return NM_WP; }
 extern "C" size_t rx_neumf_step_workspace_bytes(int64_t B, int32_t N) {
   if (B < 1 || N < 1 || N > NM_P) return 256;
   const int g = nm_grid(B, N);
-  return rx_align_up((size_t)g * NM_WP * sizeof(float), 256) + rx_align_up((size_t)g * sizeof(double), 256);
+  return rx_align_up((size_t)g * NM_RAW * sizeof(float), 256) + rx_align_up((size_t)g * sizeof(double), 256);
 }
 
 extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, int32_t* err_flag, int device, void* stream) {
@@ -431,8 +613,8 @@ extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, 
   a.W1 = r->w1; a.b1 = r->b1; a.W2 = r->w2; a.b2 = r->b2; a.Wg = r->wg; a.bg = r->bg; a.wf = r->wf; a.bf = r->bf;
   a.p_drop = r->p_drop; a.seed = r->seed;
   a.du_g = r->du_gmf; a.du_m = r->du_mlp; a.di_g = r->di_gmf; a.di_m = r->di_mlp;
-  a.wpart = (float*)ws;
-  a.loss_part = (double*)((char*)ws + rx_align_up((size_t)grid * NM_WP * sizeof(float), 256));
+  a.raw = (float*)ws;
+  a.loss_part = (double*)((char*)ws + rx_align_up((size_t)grid * NM_RAW * sizeof(float), 256));
   a.logits = r->logits; a.err_flag = err_flag;
   const size_t lds = NM_LDS_FLOATS * sizeof(float);
   static bool attr_set[64] = {};
@@ -445,8 +627,11 @@ extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, 
   if (r->labels_f64) hipLaunchKernelGGL(neumf_step_kernel<true>, dim3(grid), dim3(RX_BLOCK), lds, st, a);
   else hipLaunchKernelGGL(neumf_step_kernel<false>, dim3(grid), dim3(RX_BLOCK), lds, st, a);
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(neumf_finish_kernel, dim3((unsigned)rx_cdiv(NM_WP, RX_BLOCK)), dim3(RX_BLOCK), 0, st, (const float*)a.wpart, grid,
-                     r->wgrad, (const double*)a.loss_part, (double)r->B * (double)r->N, r->loss, const_cast<int64_t*>(r->seed));
+  NmFin f{};
+  f.raw = a.raw; f.n_parts = grid; f.wgrad = r->wgrad;
+  f.W2 = r->w2; f.b2 = r->b2; f.Wg = r->wg; f.bg = r->bg; f.wf = r->wf;
+  f.loss_part = a.loss_part; f.count = (double)r->B * (double)r->N; f.loss = r->loss; f.seed = const_cast<int64_t*>(r->seed);
+  hipLaunchKernelGGL(neumf_finish_kernel, dim3(NM_FIN_BLOCKS), dim3(NM_FB), 0, st, f);
   RX_LAUNCH_CHECK();
   return 0;
 }

@@ -687,6 +687,175 @@ static int sort_dedup_small(const RawSrc& raw, int raw_mode, int64_t n, int64_t 
   return 0;
 }
 
+// ---------------------------------------------------------------- few distinct rows: one launch, a workgroup per row range
+// When the table is small (the user and item tables of a MovieLens-sized model) the sort by row is a grouping
+// into few buckets, and the workgroups can split the ROWS instead of the positions: workgroup j owns the rows
+// [64 j, 64 j + 64), reads the whole list, and places the positions of its rows.  Everything it needs from the
+// rest of the list -- how many positions hold a lower row, how many distinct lower rows occur -- it counts
+// itself on the way, so no workgroup waits for another and one launch does what the general path does in
+// eight.  Order inside a row is position order: every wavefront walks a contiguous share of the list once and
+// queues the positions of the range (at most 65536 positions in all: the queues live in LDS); it then ranks the
+// queued positions, 64 a step, by a 6-ballot match on the row, keeps wavefront-private counters, and the counters
+// are prefixed over the wavefronts; a last walk over the queue repeats the ranking and writes.  Outputs are those of the other
+// two paths, bit for bit.
+#define KR_THREADS 1024
+#define KR_WAVES (KR_THREADS / 64)
+#define KR_KEYS 64
+#define KR_MAX_ROWS 16384
+#define KR_MAX_READS (4ll << 20)      // positions read over all workgroups: beyond this the general path is cheaper
+
+__device__ __forceinline__ unsigned long long kr_match(bool in, uint32_t d) {
+  unsigned long long p = __ballot(in);
+#pragma unroll
+  for (int bit = 0; bit < 6; ++bit) {
+    const bool b = (d >> bit) & 1u;
+    const unsigned long long m = __ballot(b);
+    p &= b ? m : ~m;
+  }
+  return in ? p : 0ull;
+}
+
+#define KR_MAX_N 65536
+
+// Dynamic LDS: per wavefront the queue of its positions whose row lies in the range (16-bit offsets into the
+// wavefront's share, in position order: at worst the whole share), and one byte per row below the range (plain
+// stores: which lower rows occur).  The list itself is read once; the few queued positions are read again (two
+// more times) for their rows, which costs less than a place to keep them.
+template <int RAW>
+__global__ void __launch_bounds__(KR_THREADS)
+sort_dedup_keyrange_kernel(RawSrc src, int n, int64_t n_rows, int32_t* __restrict__ sorted_pos, int32_t* __restrict__ sorted_slot,
+                           int64_t* __restrict__ uniq_rows, int32_t* __restrict__ seg_off, int32_t* __restrict__ n_uniq,
+                           int32_t* __restrict__ inverse, int32_t* err_flag) {
+  extern __shared__ uint32_t kr_dyn[];
+  __shared__ uint32_t cnt[KR_WAVES][KR_KEYS];    // positions of each row per wavefront; then the exclusive prefix over the wavefronts
+  __shared__ uint32_t run[KR_WAVES][KR_KEYS];    // the last walk's running counts
+  __shared__ uint32_t below_w[KR_WAVES], dist_w[KR_WAVES];
+  __shared__ uint32_t kstart[KR_KEYS], kslot[KR_KEYS];
+  __shared__ uint32_t below_all;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t lo = blockIdx.x * KR_KEYS;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int per_wave = (((n + KR_WAVES - 1) / KR_WAVES + 63) >> 6) << 6;
+  uint16_t* queue = reinterpret_cast<uint16_t*>(kr_dyn) + wave * per_wave;
+  uint32_t* seen_w = kr_dyn + ((per_wave * KR_WAVES) >> 1);
+  uint8_t* seen = reinterpret_cast<uint8_t*>(seen_w);
+  const int seen_words = (int)(lo >> 2);
+  for (int i = tid; i < KR_WAVES * KR_KEYS; i += KR_THREADS) { (&cnt[0][0])[i] = 0; (&run[0][0])[i] = 0; }
+  for (int i = tid; i < seen_words; i += KR_THREADS) seen_w[i] = 0;
+  __syncthreads();
+  const int w0 = wave * per_wave;
+  const int steps = per_wave >> 6;
+  uint32_t below = 0, qn = 0;      // (wavefront-uniform)
+  bool any_bad = false;
+  for (int s0 = 0; s0 < steps; s0 += 16) {       // sixteen loads in flight, then their sixteen steps
+    uint32_t kk[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = w0 + (s0 + e) * 64 + lane;
+      bool bad;
+      kk[e] = raw_key<RAW>(src, i < n ? i : n - 1, n_rows, &bad);
+      any_bad |= i < n && bad;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int s = s0 + e;
+      const bool live = s < steps && w0 + s * 64 + lane < n;
+      const uint32_t k = kk[e];
+      const bool under = live && k < lo;
+      if (under) seen[k] = 1;
+      below += (uint32_t)__popcll(__ballot(under));
+      const bool in = live && (k - lo) < KR_KEYS;
+      const unsigned long long b = __ballot(in);
+      if (in) queue[qn + (uint32_t)__popcll(b & lt_mask)] = (uint16_t)(s * 64 + lane);
+      qn += (uint32_t)__popcll(b);
+    }
+  }
+  if (any_bad && err_flag) atomicOr(err_flag, RX_ERR_INDEX);
+  if (lane == 0) below_w[wave] = below;
+  for (uint32_t e0 = 0; e0 < qn; e0 += 64) {
+    const uint32_t e = e0 + lane;
+    const bool has = e < qn;
+    bool bad;
+    const uint32_t k = raw_key<RAW>(src, w0 + (int)queue[has ? e : 0], n_rows, &bad);
+    const uint32_t d = k - lo;
+    const unsigned long long peers = kr_match(has, d);
+    if (has && lane == __ffsll((long long)peers) - 1) cnt[wave][d] += (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    uint32_t dist = 0;
+    for (int i = tid; i < seen_words; i += KR_THREADS) dist += (uint32_t)__popc(seen_w[i] & 0x01010101u);
+    for (int m = 32; m > 0; m >>= 1) dist += __shfl_xor(dist, m, 64);
+    if (lane == 0) dist_w[wave] = dist;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < KR_WAVES; ++w) {
+      const uint32_t c = cnt[w][tid];
+      cnt[w][tid] = total;
+      total += c;
+    }
+    uint32_t inc = total;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    uint32_t ball = 0, dist = 0;
+#pragma unroll
+    for (int w = 0; w < KR_WAVES; ++w) { ball += below_w[w]; dist += dist_w[w]; }
+    const bool present = total > 0;
+    const unsigned long long pm = __ballot(present);
+    const uint32_t slot = dist + (uint32_t)__popcll(pm & lt_mask);
+    kstart[tid] = inc - total;
+    kslot[tid] = slot;
+    if (present) {
+      uniq_rows[slot] = (int64_t)(lo + tid);
+      seg_off[slot] = (int32_t)(ball + inc - total);
+    }
+    if (tid == 0) {
+      below_all = ball;
+      if (blockIdx.x == gridDim.x - 1) {
+        const uint32_t nu = dist + (uint32_t)__popcll(pm);
+        n_uniq[0] = (int32_t)nu;
+        seg_off[nu] = n;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ball = below_all;
+  for (uint32_t e0 = 0; e0 < qn; e0 += 64) {
+    const uint32_t e = e0 + lane;
+    const bool has = e < qn;
+    const int i = w0 + (int)queue[has ? e : 0];
+    bool bad;
+    const uint32_t k = raw_key<RAW>(src, i, n_rows, &bad);
+    const uint32_t d = k - lo;
+    const unsigned long long peers = kr_match(has, d);
+    uint32_t base = 0;
+    if (has) base = run[wave][d];
+    if (has && lane == __ffsll((long long)peers) - 1) run[wave][d] = base + (uint32_t)__popcll(peers);
+    if (has) {
+      const uint32_t r = ball + kstart[d] + cnt[wave][d] + base + (uint32_t)__popcll(peers & lt_mask);
+      const int32_t slot = (int32_t)kslot[d];
+      sorted_pos[r] = i;
+      if (sorted_slot) sorted_slot[r] = slot;
+      if (inverse) inverse[i] = slot;
+    }
+  }
+}
+
+static size_t sort_keyrange_lds(int64_t n, int64_t n_rows) {
+  const int64_t per_wave = (((n + KR_WAVES - 1) / KR_WAVES + 63) >> 6) << 6;
+  return (size_t)(per_wave * KR_WAVES * 2 + rx_cdiv(n_rows, KR_KEYS) * KR_KEYS + 16);
+}
+
+static bool sort_keyrange_fits(int raw_mode, int64_t n, int64_t n_rows) {
+  if (raw_mode != 1 || n < 1 || n > KR_MAX_N || n_rows > KR_MAX_ROWS) return false;
+  return rx_cdiv(n_rows, KR_KEYS) * n <= KR_MAX_READS;
+}
+
 // Digit width: the fewest passes with digits of at most SORT_MAX_BITS bits, spread evenly.
 static void sort_plan(int64_t n_rows, int* passes, int* bits_per_pass) {
   int bits = 1;
@@ -763,11 +932,30 @@ static int sort_pass(const SortWs& w, const RawSrc& raw, int raw_mode, int64_t n
 // test that compares the two paths)
 static const bool rx_sort_force_general = [] { const char* e = getenv("RX_SORT_GENERAL"); return e && e[0] == '1'; }();
 
+// RX_SORT_NO_KEYRANGE=1 keeps small tables off the workgroup-per-row-range path (A/B timing)
+static const bool rx_sort_no_keyrange = [] { const char* e = getenv("RX_SORT_NO_KEYRANGE"); return e && e[0] == '1'; }();
+
 // rows given by `raw` (mode 1 or 2) -> sorted positions, distinct rows, run offsets
 static int sort_dedup_run(const RawSrc& raw, int raw_mode, int64_t n, int64_t n_rows, int32_t* d_sorted_pos,
                           int32_t* d_sorted_slot, int64_t* d_uniq_rows, int32_t* d_seg_off, int32_t* d_n_uniq,
                           int32_t* d_inverse, void* ws, int32_t* err_flag, hipStream_t st) {
   RX_REQUIRE(((uintptr_t)ws & 15) == 0, "sort workspace must be 16-byte aligned");
+  if (sort_keyrange_fits(raw_mode, n, n_rows) && !rx_sort_force_general && !rx_sort_no_keyrange) {
+    const unsigned grid = (unsigned)rx_cdiv(n_rows, KR_KEYS);
+    const size_t lds = sort_keyrange_lds(n, n_rows);
+    static bool attr_set[64] = {};      // LDS beyond 64 KiB per block has to be asked for, per device
+    int device = 0;
+    RX_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64 || !attr_set[device]) {
+      RX_HIP(hipFuncSetAttribute((const void*)sort_dedup_keyrange_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)sort_keyrange_lds(KR_MAX_N, KR_MAX_ROWS)));
+      if (device >= 0 && device < 64) attr_set[device] = true;
+    }
+    hipLaunchKernelGGL(sort_dedup_keyrange_kernel<1>, dim3(grid), dim3(KR_THREADS), lds, st, raw, (int)n, n_rows,
+                       d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, err_flag);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   if (n <= SMALL_MAX && !rx_sort_force_general)
     return sort_dedup_small(raw, raw_mode, n, n_rows, d_sorted_pos, d_sorted_slot, d_uniq_rows, d_seg_off, d_n_uniq, d_inverse, err_flag, st);
   SortWs w = sort_ws_layout(ws, n);

@@ -120,7 +120,11 @@ def test_empty_batch(ops):
                                       # around the limit of the one-launch path (8192 positions), with one,
                                       # two, three and four 8-bit passes
                                       (63, 200), (65, 256), (511, 257), (513, 70000), (5120, 3706), (8191, 6040),
-                                      (8192, 2**24), (8192, 2**32), (8193, 6040), (7000, 2**32)])
+                                      (8192, 2**24), (8192, 2**32), (8193, 6040), (7000, 2**32),
+                                      # small tables: one launch, a workgroup per range of 64 rows (up to 16384 rows
+                                      # and 4 Mi positions read over all workgroups), and just past its limits
+                                      (8192, 6040), (49152, 3706), (16, 16384), (255, 16384), (256, 16385), (65536, 4096),
+                                      (65537, 4096), (1025, 64), (1023, 65), (100000, 63)])
 def test_sort_dedup_bit_exact(ops, n, n_rows):
     g = _gen(n)
     if n_rows > 2**31:
