@@ -324,12 +324,25 @@ ALL_OPS = ["fm2_fwd", "fm2_fwd_bce", "fm2_bwd", "fm2_flat_indices", "sort_dedup"
 
 # kernels behind each timed op (names as rocprofv3 prints them), for the roofline line and the PMC lookup
 OP_KERNELS = {
-    "fg_reduce": ["fg_reduce_kernel<4, 8, 1, false>", "fg_combine_kernel<4, 8, 1>"],
-    "fg_row_update": [("fg_row_update_kernel<4, 2, true>", "fg_row_update_kernel<4, 2>")],   # with / without the clip factor formed inside
+    # (alternatives in a tuple: the one that ran.  Mode 5 = clipped SGD taken speculatively inside the reduce, mode 1 = plain
+    # reduce followed by the clipped update of fg_row_update)
+    "fg_reduce": [("fg_reduce_kernel<4, 8, 5, false>", "fg_reduce_kernel<4, 8, 1, false>"), ("fg_combine_kernel<4, 8, 5>", "fg_combine_kernel<4, 8, 1>")],
+    "fg_row_update": [("fg_row_update_kernel<4, 5, true>", "fg_row_update_kernel<4, 2, true>", "fg_row_update_kernel<4, 2>")],
     "segreduce_fm": ["segreduce_chunk_kernel<4, 1, 1, true>", "segreduce_combine_kernel<4, 1, 1, true>"],
     "fm2_fwd": ["fm2_fwd_kernel<4, 1>"],
     "row_update": ["row_update_kernel<4, 1, 2, false>"],
 }
+
+
+def kernels_that_run(op, opt=None):
+    """Names of the kernels behind ``op`` in this run: of alternatives, the speculative clipped-SGD variants when the
+    optimizer takes that form (a clip bound, plain SGD, speculation not switched off), else the next one listed."""
+    from recsys_amd import optim
+    ks = OP_KERNELS.get(op)
+    if ks is None:
+        return None
+    spec = opt is not None and getattr(opt, "kind", None) == "sgd" and getattr(opt, "clip_norm", None) and not optim._NO_SPECULATION
+    return [(k[0] if spec or len(k) == 1 else k[1]) if isinstance(k, tuple) else k for k in ks]
 
 
 def unique_fraction(batches, dims, want_round=False):
@@ -808,7 +821,7 @@ def main():
         if ab:
             ach = ab / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dominant,
-                    "kernels": OP_KERNELS.get(dominant) if w["desc"].get("dim") == 16 else None, "achieved": ach,
+                    "kernels": kernels_that_run(dominant, w.get("opt")) if w["desc"].get("dim") == 16 else None, "achieved": ach,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": measured_traffic(dominant) if args.workload == "fm_criteo" else None, "avg_us": ms * 1e3, "launches_timed": cnt,
                     "algorithmic_bytes_per_launch": ab, "distinct_row_fraction": rho}
