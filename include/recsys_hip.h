@@ -20,8 +20,13 @@
  *  - Embedding tables are row-major fp32 [rows, dim]; indices are int64 (the dtype the
  *    reference's batches carry, recsys/dataset.py:255-262).
  *  - `err_flag` (device int32*, may be NULL): kernels never dereference an out-of-range
- *    row; they skip it and OR a bit into *err_flag (RX_ERR_INDEX).  The host side checks
- *    the word and raises IndexError, as torch does for nn.Embedding.
+ *    row and OR a bit into *err_flag (RX_ERR_INDEX) when they meet one.  The host side checks
+ *    the word and raises IndexError, as torch does for nn.Embedding.  What happens to the
+ *    occurrence itself: gathers and forward kernels leave it out (zeros); the index
+ *    preparation (rx_sort_dedup*, rx_fg_group) clamps it into the table / into its field, so a
+ *    backward pass run on a flagged batch adds that occurrence's gradient to the clamped row.
+ *    Nothing is ever written outside the rows the batch names plus such clamped rows; beyond
+ *    that the tables of a flagged step are unspecified, and the step should be treated as failed.
  */
 #ifndef RECSYS_HIP_H
 #define RECSYS_HIP_H

@@ -515,21 +515,85 @@ segreduce_chunk_deep_kernel(SegArgs a) {
   segreduce_chunk_body<VEC, CH, MODE, true, true>(a, blockIdx.x);
 }
 
+// Partials of the run that starts in `piece` and spans np pieces, pieces q0, q0 + stride, ... (piece 0 of a run
+// holds its sum on side 1, the others on side 0).  While whole rounds of U pieces remain, U partials are
+// fetched together (independent loads in flight) and then added in the order of the walk; the rest goes one
+// piece at a time.
+template <int VEC, int CH>
+__device__ __forceinline__ void seg_sum_partials(const SegArgs& a, int64_t piece, int np, int q0, int stride, int lg, bool keep2,
+                                                 Acc<VEC, CH>& g, float& g2) {
+  const int group = a.group, dim = a.dim;
+  constexpr int U = CH == 1 ? 8 : (CH == 2 ? 4 : 2);
+  int q = q0;
+  for (; q + (U - 1) * stride < np; q += stride * U) {
+    RxPack<VEC> v[U][CH];
+    float p2[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int qj = q + j * stride;
+      const int64_t e = (piece + qj) * 2 + (qj == 0 ? 1 : 0);
+      const float* src = a.partials + e * (int64_t)dim;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        v[j][k] = c < dim ? rx_load<VEC>(src + c) : rx_zero<VEC>();
+      }
+      p2[j] = (keep2 && lg == 0) ? a.partials2[e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v[j][k].v[i];
+      g2 += p2[j];
+    }
+  }
+  for (; q < np; q += stride) {
+    const int64_t e = (piece + q) * 2 + (q == 0 ? 1 : 0);
+    const float* src = a.partials + e * (int64_t)dim;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      if (c < dim) {
+        RxPack<VEC> v = rx_load<VEC>(src + c);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v.v[i];
+      }
+    }
+    if (keep2 && lg == 0) g2 += a.partials2[e];
+  }
+}
+
+#define SEG_LONG_RUN 64        // pieces: a run beyond this is added by the whole block, not by one wavefront
+#define SEG_LONG_MAX_DIM 256   // widest row the block-wide path stages in LDS
+
 template <int VEC, int CH, int MODE, bool FM>
 __device__ __forceinline__ void segreduce_combine_body(const SegArgs& a, const int64_t n_pieces, const unsigned blk) {
   // A wavefront looks after 64/group consecutive pieces.  Each lane group first fetches what its
   // own piece's tail run needs (length, row, the row's current value), all groups at once; the
   // wavefront then takes the tails one by one, all lane slots adding that run's partials.
+  // A hot row's run spans hundreds of pieces; walked by one wavefront it is one chain of dependent rounds
+  // that sets the duration of the whole launch.  Such runs are set aside and added by all four wavefronts of
+  // the block (every wavefront a quarter of the pieces, joined through LDS in wavefront order), after the
+  // short ones.
   __shared__ float sq_lds[RX_BLOCK / 64];
+  __shared__ int long_n;
+  __shared__ int long_np[RX_BLOCK / 4], long_owner[RX_BLOCK / 4];
+  __shared__ int64_t long_piece[RX_BLOCK / 4];
+  __shared__ float long_part[RX_BLOCK / 64][SEG_LONG_MAX_DIM], long_part2[RX_BLOCK / 64];
   const int group = a.group, dim = a.dim;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slots = 64 / group;
   const int s = lane / group, lg = lane % group;
-  const int64_t base = ((int64_t)blk * (RX_BLOCK / 64) + (threadIdx.x >> 6)) * slots;
+  const int64_t base = ((int64_t)blk * (RX_BLOCK / 64) + wave) * slots;
   const int64_t mine = base + s;
   const bool has2 = a.target2 != nullptr;
   const bool keep2 = FM || has2;
   const float scale = a.scale ? a.scale[0] : 1.f;
+  const bool wide_ok = dim <= SEG_LONG_MAX_DIM;
+  if (threadIdx.x == 0) long_n = 0;
+  __syncthreads();
   const int u = mine < n_pieces ? a.tail_row[mine] : -1;
   int n_parts = 0;
   int64_t row = -1;
@@ -549,58 +613,64 @@ __device__ __forceinline__ void segreduce_combine_body(const SegArgs& a, const i
     const int owner = leader / group;
     const int np = __shfl(n_parts, leader, 64);
     const int64_t piece = base + owner;
+    if (np > SEG_LONG_RUN && wide_ok) {
+      if (lane == leader) {
+        const int e = atomicAdd(&long_n, 1);      // (the order of the list does not enter any sum)
+        long_np[e] = np; long_owner[e] = (int)threadIdx.x; long_piece[e] = piece;
+      }
+      continue;
+    }
     Acc<VEC, CH> g;
     ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
     float g2 = 0.f;
-    // A hot row's run spans hundreds of pieces and one wavefront walks them all: while whole rounds
-    // of U pieces per lane slot remain, U partials are fetched together (independent loads in
-    // flight) and then added in the order of the walk; the rest goes one piece at a time.
-    constexpr int U = CH == 1 ? 8 : (CH == 2 ? 4 : 2);
-    int q = s;
-    for (int round = np / (slots * U); round > 0; --round, q += slots * U) {
-      RxPack<VEC> v[U][CH];
-      float p2[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const int qj = q + j * slots;
-        const int64_t e = (piece + qj) * 2 + (qj == 0 ? 1 : 0);
-        const float* src = a.partials + e * (int64_t)dim;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-          const int c = (lg + k * group) * VEC;
-          v[j][k] = c < dim ? rx_load<VEC>(src + c) : rx_zero<VEC>();
-        }
-        p2[j] = (keep2 && lg == 0) ? a.partials2[e] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-#pragma unroll
-        for (int k = 0; k < CH; ++k)
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v[j][k].v[i];
-        g2 += p2[j];
-      }
-    }
-    for (; q < np; q += slots) {
-      const int64_t e = (piece + q) * 2 + (q == 0 ? 1 : 0);
-      const float* src = a.partials + e * (int64_t)dim;
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int c = (lg + k * group) * VEC;
-        if (c < dim) {
-          RxPack<VEC> v = rx_load<VEC>(src + c);
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) g.p[k].v[i] += v.v[i];
-        }
-      }
-      if (keep2 && lg == 0) g2 += a.partials2[e];
-    }
+    seg_sum_partials<VEC, CH>(a, piece, np, s, slots, lg, keep2, g, g2);
     for (int m = group; m < 64; m <<= 1) {
       ACC_FOREACH(k, i) g.p[k].v[i] += __shfl_xor(g.p[k].v[i], m, 64);
       g2 += __shfl_xor(g2, m, 64);
     }
     if (FM) g2 = __shfl(g2, lane - lg, 64);  // every lane of a group needs the scalar sum
     if (s == owner && row_ok) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, scale, has2);
+  }
+  __syncthreads();
+  const int nl = long_n;
+  for (int e = 0; e < nl; ++e) {
+    const int np = long_np[e], owner_tid = long_owner[e];
+    const int64_t piece = long_piece[e];
+    Acc<VEC, CH> g;
+    ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
+    float g2 = 0.f;
+    seg_sum_partials<VEC, CH>(a, piece, np, wave * slots + s, (RX_BLOCK / 64) * slots, lg, keep2, g, g2);
+    for (int m = group; m < 64; m <<= 1) {
+      ACC_FOREACH(k, i) g.p[k].v[i] += __shfl_xor(g.p[k].v[i], m, 64);
+      g2 += __shfl_xor(g2, m, 64);
+    }
+    if (s == 0) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        if (c < dim) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) long_part[wave][c + i] = g.p[k].v[i];
+        }
+      }
+      if (lg == 0) long_part2[wave] = g2;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x - lg == owner_tid) {       // the lane group that holds the run's row and old value
+      ACC_FOREACH(k, i) g.p[k].v[i] = 0.f;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        if (c < dim) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i)
+            g.p[k].v[i] = (long_part[0][c + i] + long_part[1][c + i]) + (long_part[2][c + i] + long_part[3][c + i]);
+        }
+      }
+      g2 = (long_part2[0] + long_part2[1]) + (long_part2[2] + long_part2[3]);
+      if (row_ok) sq += finish_run<VEC, CH, MODE, FM>(a, g, g2, x, st, row, u, lg, scale, has2);
+    }
+    __syncthreads();
   }
   if (a.sq_part) block_sq_store(sq, a.sq_part, sq_lds, blk);
 }
@@ -1279,8 +1349,17 @@ clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double
                         float* __restrict__ total_norm) {
   __shared__ double wsum[RX_BLOCK / 64];
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += RX_BLOCK) s += (double)parts[i];
-  for (int64_t i = threadIdx.x; i < n64; i += RX_BLOCK) s += parts64[i];
+  // eight loads in flight, added in index order: the sum is the one of the plain loop, bit for bit
+  int64_t i = threadIdx.x;
+  for (; i + 7 * RX_BLOCK < n; i += 8 * RX_BLOCK) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = parts[i + k * RX_BLOCK];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (double)v[k];
+  }
+  for (; i < n; i += RX_BLOCK) s += (double)parts[i];
+  for (int64_t j = threadIdx.x; j < n64; j += RX_BLOCK) s += parts64[j];
   s = rx_wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();

@@ -128,6 +128,41 @@ def test_grouping_flags_an_index_outside_its_field():
         ops.set_index_check("sync")
 
 
+def test_a_flagged_step_writes_only_rows_of_the_batch_or_the_clamped_row():
+    """An index outside its field is flagged (IndexError when the flag is read).  The forward leaves the
+    occurrence out; the index preparation clamps it into its field, so the backward adds that occurrence's
+    gradient to the field's nearest row.  What the contract promises about the tables after such a step:
+    nothing is written outside the rows the batch names plus that clamped row."""
+    from recsys_amd import ops, optim
+    from recsys_amd.models import fields
+    dims = [10, 300, 40]
+    base = _bases(dims)
+    sparse = torch.tensor([[1, 5, 0], [12, 7, 39], [3, 299, 8], [-2, 0, 8]], device="cuda")   # 12 and -2 are outside field 0
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        m = fields.FieldFM(dims, 16).train()
+    w0, b0 = m.feature_embedding.weight.detach().clone(), m.bias_embedding.weight.detach().clone()
+    opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=1.0)
+    ops.set_index_check("deferred")
+    try:
+        opt.zero_grad()
+        m.loss({"sparse": sparse, "label": torch.tensor([1., 0., 1., 0.], device="cuda", dtype=torch.float64)}).backward()
+        opt.step()
+        with pytest.raises(IndexError):
+            ops.raise_if_index_error()
+    finally:
+        ops.set_index_check("sync")
+    allowed = torch.zeros(sum(dims), dtype=torch.bool, device="cuda")
+    valid = (sparse >= 0) & (sparse < torch.tensor(dims, device="cuda")[None, :])
+    rows = sparse + torch.tensor(base[:-1], device="cuda")[None, :]
+    allowed[rows[valid]] = True
+    allowed[base[0]] = True             # -2 clamps to the field's first row
+    allowed[base[1] - 1] = True         # 12 clamps to its last
+    w1, b1 = m.feature_embedding.weight.detach(), m.bias_embedding.weight.detach()
+    assert torch.equal(w1[~allowed], w0[~allowed]) and torch.equal(b1[~allowed], b0[~allowed])
+    assert torch.isfinite(w1).all() and torch.isfinite(b1).all()
+
+
 def _reference_grads(table, bias, sparse, dims, T, g, deep, dim):
     """fp64: G_r = sum_b g_b (T_b - e_r) + tower slices; bias gradient sum_b g_b."""
     B, nf = sparse.shape
