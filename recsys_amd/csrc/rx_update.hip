@@ -906,16 +906,19 @@ extern "C" int rx_segreduce_fm(const float* d_T, int64_t ld_T, const float* d_g,
 }
 
 // ---------------------------------------------------------------- update from a compact gradient
+template <int CH> __host__ __device__ constexpr int upd_rows() { return CH == 1 ? 4 : (CH == 2 ? 2 : 1); }
+static inline int upd_rows_of(int chunks, int mode) { return mode == RX_SEG_SGD_SPEC ? 1 : (chunks == 1 ? 4 : (chunks == 2 ? 2 : 1)); }
+
 template <int VEC, int CH, int MODE>
 __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned blk) {
   const int group = a.group, dim = a.dim;
   const int64_t gid = (int64_t)blk * blockDim.x + threadIdx.x;
-  const int64_t u = gid / group;
   const int lg = (int)(gid % group);
+  const int64_t u = (gid / group) * (MODE == RX_SEG_SGD_SPEC ? 1 : upd_rows<CH>());
   if (u >= a.n_uniq[0]) return;
-  const int64_t row = a.uniq_rows[u];
-  if (row < 0 || row >= a.n_rows) return;
   if constexpr (MODE == RX_SEG_SGD_SPEC) {
+    const int64_t row = a.uniq_rows[u];
+    if (row < 0 || row >= a.n_rows) return;
     // redo the row from its record: old - lr * (factor * G), what RX_SEG_COMPACT + RX_SEG_SGD leave
     const float scale = a.scale ? a.scale[0] : 1.f;
     const float* ud = a.occ + u * (int64_t)(2 * dim);
@@ -936,19 +939,40 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
     }
     return;
   }
-  Acc<VEC, CH> g;
+  // UPD_ROWS rows per lane group, every load of all of them issued before the first use: a row costs three
+  // dependent round trips (count, row id, row), and one row per group left the launch bound by that latency
+  // (4.0 TB/s on 512-byte rows) rather than by the bytes.
+  constexpr int R = upd_rows<CH>();
+  const int64_t nu = a.n_uniq[0];
+  int64_t rows[R];
+  bool ok[R];
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const int c = (lg + k * group) * VEC;
-    g.p[k] = (c < dim) ? rx_load<VEC>(a.occ + u * (int64_t)dim + c) : rx_zero<VEC>();
+  for (int r = 0; r < R; ++r) {
+    const int64_t ur = u + r;
+    ok[r] = ur < nu;
+    rows[r] = a.uniq_rows[ok[r] ? ur : 0];
+    ok[r] = ok[r] && rows[r] >= 0 && rows[r] < a.n_rows;
   }
-  Acc<VEC, CH> x, st;
-  ACC_FOREACH(k, i) { x.p[k].v[i] = 0.f; st.p[k].v[i] = 0.f; }
-  load_old<VEC, CH, MODE, false>(a, row, lg, x, st);
+  Acc<VEC, CH> g[R], x[R], st[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t ur = ok[r] ? u + r : 0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int c = (lg + k * group) * VEC;
+      g[r].p[k] = (c < dim) ? rx_load<VEC>(a.occ + ur * (int64_t)dim + c) : rx_zero<VEC>();
+    }
+    ACC_FOREACH(k, i) { x[r].p[k].v[i] = 0.f; st[r].p[k].v[i] = 0.f; }
+    load_old<VEC, CH, MODE, false>(a, ok[r] ? rows[r] : 0, lg, x[r], st[r]);
+  }
   const float scale = a.scale ? a.scale[0] : 1.f;
-  apply_row<VEC, CH, MODE>(a, g, x, st, row, u, lg, scale);
-  // companion scalar table addressed by the same rows
-  if (a.target2 && lg == 0) apply_scalar<MODE>(a, a.occ2[u], row, u, scale);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!ok[r]) continue;
+    apply_row<VEC, CH, MODE>(a, g[r], x[r], st[r], rows[r], u + r, lg, scale);
+    // companion scalar table addressed by the same rows
+    if (a.target2 && lg == 0) apply_scalar<MODE>(a, a.occ2[u + r], rows[r], u + r, scale);
+  }
 }
 
 template <int VEC, int CH, int MODE, bool FM>
@@ -997,7 +1021,7 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   a.mode = mode; a.target = d_w; a.state = d_state; a.n_rows = n_rows; a.lr = lr; a.eps = eps; a.scale = d_scale;
   a.occ2 = d_compact2; a.target2 = d_w2; a.state2 = d_state2;
   a.group = sh.group;
-  unsigned grid = (unsigned)rx_cdiv(n_max * sh.group, RX_BLOCK);
+  unsigned grid = (unsigned)rx_cdiv(rx_cdiv(n_max, upd_rows_of(sh.chunks, mode)) * sh.group, RX_BLOCK);
   a.force = force ? 1 : 0;
   a.upd_blocks = grid;
   if (mode == RX_SEG_SGD_SPEC && grid > 2048u) grid = 2048u;
@@ -1033,7 +1057,7 @@ extern "C" int rx_row_update_multi(const rx_seg_table* tables, int32_t count, in
     seg_from_table(t, mode, lr, eps, d_scale, &a);
     a.occ_ld = t.dim; a.group = sh.group; a.sq_part = nullptr;
     m.t[k] = a; m.first[k] = blocks;
-    blocks += (unsigned)rx_cdiv(t.n * sh.group, RX_BLOCK);
+    blocks += (unsigned)rx_cdiv(rx_cdiv(t.n, upd_rows_of(sh.chunks, mode)) * sh.group, RX_BLOCK);
     ++k;
   }
   if (k == 0) return 0;
