@@ -363,10 +363,14 @@ __device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a, const uns
 #pragma unroll
           for (int k = 0; k < CH; ++k) t.deep[j].p[k] = rx_load<VEC>(dsrc + col[k]);
         }
-        // the row's current value (and state) ride along, so that the end of a run has them at hand
+        // the row's current value (and state) ride along, so that the end of a run has them at hand.  Only
+        // the last position of a run uses them: every other position reads row 0 instead (one line the
+        // whole launch shares), which keeps the load unconditional without moving the row through the
+        // caches once per occurrence.
         const uint32_t r = myrow[b0 + j];
         t.rid[j] = r;
-        const int64_t r_safe = r < a.n_rows ? (int64_t)r : 0;
+        const bool ends = mine[b0 + j + 1].x != m.x;
+        const int64_t r_safe = (ends && r < a.n_rows) ? (int64_t)r : 0;
         load_old<VEC, CH, MODE, FM>(a, r_safe, lg, t.oldx[j], t.oldst[j]);
         t.old2[j] = OLD2 ? old2_src[has2 ? r_safe : 0] : 0.f;
       }
