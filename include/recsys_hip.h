@@ -588,6 +588,20 @@ size_t rx_multi_sumsq_partials(int32_t count);
 int rx_multi_sumsq(const rx_tensor_list* list, double* d_partial, int device, void* stream);
 int rx_multi_dense_update(const rx_tensor_list* list, int mode, float lr, float eps,
                           const float* d_scale, int device, void* stream);
+/* torch.optim.Adam over every parameter of a model -- what the reference's pipelines build
+ * (recsys/pipelines/neuralcf/neumf.py:10, matrix_factorization/vanilla_mf.py:10) -- as ONE launch for up to
+ * RX_MULTI_MAX tensors: rx_dense_adam / rx_dense_adam_dstep element by element (d_step != NULL: the step count
+ * is read from device memory), the same bits as one call per tensor. */
+typedef struct rx_adam_list {
+  float* w[RX_MULTI_MAX];
+  const float* g[RX_MULTI_MAX];
+  float* m[RX_MULTI_MAX];
+  float* v[RX_MULTI_MAX];
+  int64_t n[RX_MULTI_MAX];
+  int32_t count;
+} rx_adam_list;
+int rx_multi_dense_adam(const rx_adam_list* list, float lr, float beta1, float beta2, float eps, int32_t step,
+                        const int32_t* d_step, const float* d_scale, int device, void* stream);
 /* out[0] = sum(x) (fp64 accumulate, fixed order): gradient of a scalar bias that is added to
  * every logit (bias_mf.py:12,17; the Linear(D,1) bias of gmf.py:20). Same workspace size. */
 int rx_reduce_sum(const float* d_x, int64_t n, float* d_out, void* ws, size_t ws_bytes, int device,

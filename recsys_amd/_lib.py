@@ -73,6 +73,11 @@ class TensorList(C.Structure):
                 ("n", i64 * RX_MULTI_MAX), ("count", i32)]
 
 
+class AdamList(C.Structure):
+    _fields_ = [("w", vp * RX_MULTI_MAX), ("g", vp * RX_MULTI_MAX), ("m", vp * RX_MULTI_MAX), ("v", vp * RX_MULTI_MAX),
+                ("n", i64 * RX_MULTI_MAX), ("count", i32)]
+
+
 RX_SEG_MULTI_MAX = 8
 RX_BATCH_MAX_TENSORS = 8
 
@@ -169,6 +174,7 @@ PROTOTYPES = {
     "rx_multi_sumsq_partials": (C.c_size_t, [i32]),
     "rx_multi_sumsq": (C.c_int, [C.POINTER(TensorList), vp, C.c_int, vp]),
     "rx_multi_dense_update": (C.c_int, [C.POINTER(TensorList), C.c_int, f32, f32, vp, C.c_int, vp]),
+    "rx_multi_dense_adam": (C.c_int, [C.POINTER(AdamList), f32, f32, f32, f32, i32, vp, vp, C.c_int, vp]),
     "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),
     "rx_linear_bwd_x": (C.c_int, [vp, i64, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

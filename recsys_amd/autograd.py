@@ -129,6 +129,26 @@ def table_backward(param: Optional[Tensor], si: SortedIndex, occ: Tensor, dim: O
     return grad if param2 is None else (grad, grad2)
 
 
+def tables_backward(params: Sequence[Tensor], sis: Sequence[SortedIndex], occs: Sequence[Tensor]):
+    """``table_backward`` for several tables at once.  Tables without a fused sparse rule, all of one width on
+    one GPU, get their dense gradients from ONE zeroed buffer and ONE pair of reduce launches
+    (rx_segreduce_multi in DENSE mode: the same bits as one reduce per table); anything else goes table by
+    table."""
+    same = (len(params) > 1 and all(p is not None and p.is_cuda and getattr(p, "_rx_sparse", None) is None and p.dim() == 2
+                                    and p.shape[1] == params[0].shape[1] and p.dtype == torch.float32 for p in params)
+            and len(params) <= _lib.RX_SEG_MULTI_MAX and os.environ.get("RX_NO_MULTI_TABLE") != "1")
+    if not same:
+        return [table_backward(p, si, occ) for p, si, occ in zip(params, sis, occs)]
+    sizes = [(p.numel() + 63) // 64 * 64 for p in params]         # every gradient starts on a 256-byte boundary
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=params[0].device)
+    grads, o = [], 0
+    for p, n in zip(params, sizes):
+        grads.append(flat[o:o + p.numel()].view(p.shape))
+        o += n
+    ops.segreduce_multi([ops.TableReduce(occ, si, g, p.shape[1]) for p, si, occ, g in zip(params, sis, occs, grads)], _lib.RX_SEG_DENSE)
+    return grads
+
+
 # ------------------------------------------------------------------ MF-family score
 class MFScore(Function):
     """logits[B,N] of the matrix-factorization family / GMF (rx_mf_score_fwd / _bwd)."""
@@ -154,8 +174,7 @@ def _mf_backward(ctx, g):
         user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, **kw)
         su = sorted_index(users, U.shape[0])
         si = sorted_index(items, V.shape[0])
-        gU = table_backward(U, su, user_occ)
-        gV = table_backward(V, si, item_occ)
+        gU, gV = tables_backward((U, V), (su, si), (user_occ, item_occ))
         gO = gUT = gT = gub = gib = gb = glw = glb = None
         if kw["O"] is not None:
             gO = table_backward(kw["O"], sorted_index(kw["occs"], kw["O"].shape[0]), user_occ)
@@ -520,8 +539,7 @@ class GMFMul(Function):
     def backward(ctx, dout):
         users, items, U, V = ctx.args
         user_occ, item_occ = ops.gmf_mul_bwd(dout.contiguous(), U, V, users, items)
-        gU = table_backward(U, sorted_index(users, U.shape[0]), user_occ)
-        gV = table_backward(V, sorted_index(items, V.shape[0]), item_occ)
+        gU, gV = tables_backward((U, V), (sorted_index(users, U.shape[0]), sorted_index(items, V.shape[0])), (user_occ, item_occ))
         return None, None, gU, gV
 
 
@@ -553,10 +571,7 @@ class NeuMFLoss(Function):
         du_g, di_g, du_m, di_m, wgrad = grads
         su = sorted_index(users, ug.shape[0])
         si = sorted_index(items, ig.shape[0])
-        gug = table_backward(ug, su, du_g)
-        gig = table_backward(ig, si, di_g)
-        gum = table_backward(um, su, du_m)
-        gim = table_backward(im, si, di_m)
+        gug, gig, gum, gim = tables_backward((ug, ig, um, im), (su, si, su, si), (du_g, di_g, du_m, di_m))
         outs, o = [], 0
         for shp in ctx.shapes:
             n = 1

@@ -1339,6 +1339,68 @@ multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __
   }
 }
 
+// Adam on up to RX_MULTI_MAX tensors in one launch (blockIdx.y selects the tensor): the arithmetic of
+// dense_adam_kernel element by element, so the weights equal those of one launch per tensor bit for bit.
+#define RX_MULTI_ADAM_BLOCKS 64
+__global__ void __launch_bounds__(RX_BLOCK)
+multi_dense_adam_kernel(rx_adam_list t, float lr, float beta1, float beta2, float eps, int32_t step,
+                        const int32_t* __restrict__ d_step, const float* __restrict__ scale) {
+  const int k = blockIdx.y;
+  float* __restrict__ w = t.w[k];
+  const float* __restrict__ g = t.g[k];
+  float* __restrict__ m = t.m[k];
+  float* __restrict__ v = t.v[k];
+  const int64_t n = t.n[k];
+  const float sc = scale ? scale[0] : 1.f;
+  const int32_t tt = d_step ? d_step[0] : step;
+  if (tt < 1) return;
+  const double bc1 = 1.0 - pow((double)beta1, (double)tt);
+  const double bc2 = 1.0 - pow((double)beta2, (double)tt);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  auto one = [&](float& wi, float gi_, float& mi_, float& vi_) {
+    const float gi = gi_ * sc;
+    const float mi = mi_ + (gi - mi_) * (1.f - beta1);
+    const float vi = vi_ * beta2 + (1.f - beta2) * gi * gi;
+    mi_ = mi;
+    vi_ = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    wi = wi - step_size * (mi / denom);
+  };
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = (((uintptr_t)w | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  float4* __restrict__ w4 = reinterpret_cast<float4*>(w);
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+  float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = tid; i < n4; i += stride) {
+    float4 wv = w4[i], mv = m4[i], vv = v4[i];
+    const float4 gv = g4[i];
+    one(wv.x, gv.x, mv.x, vv.x); one(wv.y, gv.y, mv.y, vv.y); one(wv.z, gv.z, mv.z, vv.z); one(wv.w, gv.w, mv.w, vv.w);
+    w4[i] = wv; m4[i] = mv; v4[i] = vv;
+  }
+  for (int64_t j = n4 * 4 + tid; j < n; j += stride) {
+    float wj = w[j], mj = m[j], vj = v[j];
+    one(wj, g[j], mj, vj);
+    w[j] = wj; m[j] = mj; v[j] = vj;
+  }
+}
+
+extern "C" int rx_multi_dense_adam(const rx_adam_list* list, float lr, float beta1, float beta2, float eps, int32_t step,
+                                   const int32_t* d_step, const float* d_scale, int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(list && list->count >= 0 && list->count <= RX_MULTI_MAX, "rx_multi_dense_adam: bad tensor list");
+  RX_REQUIRE(d_step || step >= 1, "rx_multi_dense_adam: step count must be at least 1 (or live on the device)");
+  if (list->count == 0) return 0;
+  for (int k = 0; k < list->count; ++k)
+    RX_REQUIRE(list->n[k] >= 0 && ((list->w[k] && list->g[k] && list->m[k] && list->v[k]) || list->n[k] == 0), "rx_multi_dense_adam: bad tensor %d", k);
+  hipLaunchKernelGGL(multi_dense_adam_kernel, dim3(RX_MULTI_ADAM_BLOCKS, list->count), dim3(RX_BLOCK), 0, (hipStream_t)stream, *list, lr,
+                     beta1, beta2, eps, step, d_step, d_scale);
+  RX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t rx_multi_sumsq_partials(int32_t count) {
   return (size_t)(count > 0 ? count : 0) * RX_MULTI_BLOCKS;
 }

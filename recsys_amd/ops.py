@@ -1037,6 +1037,27 @@ def multi_dense_update(ws, gs, mode: int, lr: float, eps: float = 0.0, scale=Non
           "rx_multi_dense_update")
 
 
+def multi_dense_adam(ws, gs, ms, vs, lr: float, beta1: float, beta2: float, eps: float, step, scale=None) -> None:
+    """Adam step of up to 24 dense tensors in one launch (rx_multi_dense_adam); ``step`` as for ``dense_adam``."""
+    if not 1 <= len(ws) <= _lib.RX_MULTI_MAX or not (len(gs) == len(ms) == len(vs) == len(ws)):
+        raise ValueError(f"1..{_lib.RX_MULTI_MAX} tensors with a gradient and two moments each")
+    t = _lib.AdamList()
+    for k, (w, g, m, v) in enumerate(zip(ws, gs, ms, vs)):
+        for x, name in ((w, "parameter"), (g, "gradient"), (m, "first moment"), (v, "second moment")):
+            _req(x, torch.float32, name)
+            if x.numel() != w.numel():
+                raise ValueError(f"{name}: expected {w.numel()} elements")
+        _same_device(w, g, m, v)
+        t.w[k], t.g[k], t.m[k], t.v[k], t.n[k] = w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel()
+    t.count = len(ws)
+    d_step = None
+    if isinstance(step, Tensor):
+        _req(step, torch.int32, "step")
+        d_step, step = step, 0
+    check(lib.rx_multi_dense_adam(C.byref(t), lr, beta1, beta2, eps, int(step), _p(d_step), _p(scale), _dev(ws[0]), _stream(ws[0])),
+          "rx_multi_dense_adam")
+
+
 def reduce_sum(x: Tensor) -> Tensor:
     _req(x, torch.float32, "x")
     out = torch.empty(1, dtype=torch.float32, device=x.device)

@@ -388,13 +388,21 @@ class FusedOptimizer:
                            self._step_dev if self._step_dev is not None else self._step, scale)
 
     def _dense_step_all(self, scale):
-        """All dense parameters: SGD / Adagrad in launches of up to 24 tensors; Adam per tensor."""
+        """All dense parameters in launches of up to 24 tensors (same bits as one launch per tensor)."""
         live = [(p, p.grad.contiguous()) for p in self.dense if p.grad is not None]
         if not live:
             return
-        if self.dense_kind == "adam" or any(not p.data.is_contiguous() for p, _ in live):
+        if any(not p.data.is_contiguous() for p, _ in live) or not live[0][0].is_cuda:
             for p, _ in live:
                 self._dense_update(p, scale)
+            return
+        if self.dense_kind == "adam":
+            step = self._step_dev if self._step_dev is not None else self._step
+            for i in range(0, len(live), _lib.RX_MULTI_MAX):
+                chunk = live[i:i + _lib.RX_MULTI_MAX]
+                st = [self._dense_state_for(p) for p, _ in chunk]
+                ops.multi_dense_adam([p.data for p, _ in chunk], [g for _, g in chunk], [x[0] for x in st], [x[1] for x in st],
+                                     self.lr, self.betas[0], self.betas[1], self.adam_eps, step, scale)
             return
         mode = _lib.RX_SEG_SGD if self.dense_kind == "sgd" else _lib.RX_SEG_ADAGRAD
         for i in range(0, len(live), _lib.RX_MULTI_MAX):

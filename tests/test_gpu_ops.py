@@ -945,3 +945,57 @@ def test_index_glue_kernels_equal_their_torch_formulas(ops):
         ops.compose_slots(src_of, inverse, out=(out[0][:10], out[1]))
     with pytest.raises(ValueError):
         ops.fm_flat_rows(sparse, offs[:3])
+
+
+def test_multi_dense_adam_equals_one_launch_per_tensor_bitwise(ops):
+    """rx_multi_dense_adam: torch.optim.Adam's step over many tensors in one launch; bit for bit what
+    rx_dense_adam / rx_dense_adam_dstep leave tensor by tensor, with the step count by value or on the device."""
+    g0 = _gen(77)
+    shapes = [(6040, 64), (3706, 64), (64, 128), (64,), (1,), (33, 7), (32, 64)]
+    scale = torch.tensor([0.37], device="cuda")
+    for dstep in (False, True):
+        ws = [torch.randn(s, generator=g0).cuda() for s in shapes]
+        gs = [torch.randn(s, generator=g0).cuda() for s in shapes]
+        ms = [torch.randn(s, generator=g0).cuda() * 0.1 for s in shapes]
+        vs = [torch.rand(s, generator=g0).cuda() * 0.01 for s in shapes]
+        ref = [[t.clone() for t in ts] for ts in (ws, ms, vs)]
+        step = torch.tensor([3], dtype=torch.int32, device="cuda") if dstep else 3
+        for w, g, m, v in zip(ref[0], gs, ref[1], ref[2]):
+            ops.dense_adam(w, g, m, v, 1e-3, 0.9, 0.999, 1e-8, step, scale)
+        ops.multi_dense_adam(ws, gs, ms, vs, 1e-3, 0.9, 0.999, 1e-8, step, scale)
+        for a, b in zip(ws + ms + vs, ref[0] + ref[1] + ref[2]):
+            assert torch.equal(a, b)
+        # and against torch's own formula for one of them (fp32 tolerance)
+        w0 = torch.randn(shapes[2], generator=g0).cuda()
+        p = torch.nn.Parameter(w0.clone())
+        opt = torch.optim.Adam([p], lr=1e-3)
+        m0, v0 = torch.zeros_like(w0), torch.zeros_like(w0)
+        for t in (1, 2):
+            g = torch.randn(shapes[2], generator=g0).cuda()
+            p.grad = g.clone()
+            opt.step()
+            ops.multi_dense_adam([w0], [g], [m0], [v0], 1e-3, 0.9, 0.999, 1e-8,
+                                 torch.tensor([t], dtype=torch.int32, device="cuda") if dstep else t)
+        assert_close(w0.cpu(), p.detach().cpu(), 1e-5, "multi adam vs torch.optim.Adam")
+
+
+def test_dense_gradients_of_several_tables_in_one_reduce_equal_one_reduce_per_table(ops):
+    """autograd.tables_backward: four dense table gradients out of one zeroed buffer and one pair of reduce
+    launches; the same bits as table_backward table by table (and as index_add in fp64, to tolerance)."""
+    from recsys_amd import autograd as rxa
+    g0 = _gen(5)
+    U, I, D, B, N = 600, 371, 64, 900, 6
+    tabs = [torch.nn.Parameter(torch.randn(n, D, generator=g0).cuda()) for n in (U, I, U, I)]
+    users = torch.randint(0, U, (B,), generator=g0).cuda()
+    items = torch.randint(0, I, (B, N), generator=g0).cuda()
+    su, si = rxa.sorted_index(users, U), rxa.sorted_index(items, I)
+    occs = [torch.randn(B, D, generator=g0).cuda(), torch.randn(B * N, D, generator=g0).cuda(),
+            torch.randn(B, D, generator=g0).cuda(), torch.randn(B * N, D, generator=g0).cuda()]
+    sis = (su, si, su, si)
+    together = rxa.tables_backward(tabs, sis, occs)
+    for p, s, occ, g in zip(tabs, sis, occs, together):
+        alone = rxa.table_backward(p, s, occ)
+        assert g.shape == p.shape and torch.equal(g, alone)
+        idx = users if occ.shape[0] == B else items.reshape(-1)
+        exp = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, idx, occ.double())
+        assert_close(g.cpu(), exp.float().cpu(), 1e-5, "dense table gradient")
