@@ -524,7 +524,7 @@ __device__ __forceinline__ void nm_reduce64(const float* __restrict__ raw, int n
 __global__ void __launch_bounds__(NM_FB)
 neumf_finish_kernel(NmFin f) {
   __shared__ float part[16 * 64];
-  __shared__ float outv[64], outg[64], sd[1];
+  __shared__ float outv[64], outg[64];
   const int tid = threadIdx.x, b = blockIdx.x;
   if (b < NM_FIN_W1_BLOCKS) {
     nm_reduce64(f.raw, f.n_parts, b * 64, part, outv);
@@ -538,35 +538,36 @@ neumf_finish_kernel(NmFin f) {
     const int idx = (b - NM_FIN_W1_BLOCKS - 2) * NM_FB + tid;
     f.wgrad[NM_WG_WG + idx] = f.wf[idx >> 6] * outv[idx & 63];
   } else {
-    nm_reduce64(f.raw, f.n_parts, NM_RAW_V, part, outv);
-    nm_reduce64(f.raw, f.n_parts, NM_RAW_VG, part, outg);
-    if (tid < 64) {
-      float s = 0.f;
-      for (int k = tid; k < f.n_parts; k += 64) s += f.raw[(size_t)k * NM_RAW + NM_RAW_SDL];
-      s = rx_wave_sum(s);
-      if (tid == 0) sd[0] = s;
-      double l = 0.0;
-      for (int k = tid; k < f.n_parts; k += 64) l += f.loss_part[k];
-      l = rx_wave_sum_f64(l);
-      if (tid == 0) {
-        f.loss[0] = l / f.count;
-        if (f.seed) f.seed[0] = f.seed[0] + 1;
-      }
+    // the last block: sum(dl) and the loss over the partials (one load per thread, fixed trees), v and vg, then
+    // db2, dbg, dbf and dwf = [Wg vg + bg sum(dl) | W2 v + b2 sum(dl)] (16 lanes per output, 16-byte loads)
+    __shared__ float sdl_w[4];
+    __shared__ double loss_w[4];
+    if (tid < 256) {
+      const float x = tid < f.n_parts ? f.raw[(size_t)tid * NM_RAW + NM_RAW_SDL] : 0.f;
+      const double l = tid < f.n_parts ? f.loss_part[tid] : 0.0;
+      const float xs = rx_wave_sum(x);
+      const double ls = rx_wave_sum_f64(l);
+      if ((tid & 63) == 0) { sdl_w[tid >> 6] = xs; loss_w[tid >> 6] = ls; }
     }
-    __syncthreads();
-    const float sdl = sd[0];
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_V, part, outv);      // (its barriers also publish sdl_w / loss_w)
+    nm_reduce64(f.raw, f.n_parts, NM_RAW_VG, part, outg);
+    const float sdl = (sdl_w[0] + sdl_w[1]) + (sdl_w[2] + sdl_w[3]);
+    if (tid == 0) {
+      f.loss[0] = ((loss_w[0] + loss_w[1]) + (loss_w[2] + loss_w[3])) / f.count;
+      if (f.seed) f.seed[0] = f.seed[0] + 1;
+      f.wgrad[NM_WG_BF] = sdl;
+    }
     if (tid < 32) {
       f.wgrad[NM_WG_B2 + tid] = f.wf[32 + tid] * sdl;
       f.wgrad[NM_WG_BG + tid] = f.wf[tid] * sdl;
-    } else if (tid >= 64 && tid < 128) {
-      const int j = tid - 64, o = j & 31;
-      const float* w = (j < 32 ? f.Wg : f.W2) + o * 64;
-      const float* x = j < 32 ? outg : outv;
-      float s = 0.f;
-      for (int c = 0; c < 64; ++c) s += w[c] * x[c];
-      f.wgrad[NM_WG_WF + j] = s + (j < 32 ? f.bg[o] : f.b2[o]) * sdl;
-    } else if (tid == 128) {
-      f.wgrad[NM_WG_BF] = sdl;
+    }
+    {
+      const int j = tid >> 4, q = (tid & 15) * 4, o = j & 31;
+      const float4 w = *reinterpret_cast<const float4*>((j < 32 ? f.Wg : f.W2) + o * 64 + q);
+      const float* x = (j < 32 ? outg : outv) + q;
+      float s = ((w.x * x[0] + w.y * x[1]) + w.z * x[2]) + w.w * x[3];
+      s = rx_group_sum(s, 16);
+      if ((tid & 15) == 0) f.wgrad[NM_WG_WF + j] = s + (j < 32 ? f.bg[o] : f.b2[o]) * sdl;
     }
   }
 }
@@ -602,6 +603,7 @@ extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, 
   RX_REQUIRE(rx_aligned16(r->user_gmf) && rx_aligned16(r->item_gmf) && rx_aligned16(r->user_mlp) && rx_aligned16(r->item_mlp) &&
              rx_aligned16(r->du_gmf) && rx_aligned16(r->du_mlp) && rx_aligned16(r->di_gmf) && rx_aligned16(r->di_mlp),
              "rx_neumf_step: tables and gradient buffers must be 16-byte aligned");
+  RX_REQUIRE(rx_aligned16(r->w2) && rx_aligned16(r->wg), "rx_neumf_step: linear_mlp.3 / linear_gmf weights must be 16-byte aligned");
   RX_REQUIRE(r->n_users >= 1 && r->n_items >= 1, "rx_neumf_step: empty table");
   RX_REQUIRE(r->p_drop >= 0.f && r->p_drop < 1.f, "rx_neumf_step: dropout probability outside [0, 1)");
   RX_REQUIRE(ws_bytes >= rx_neumf_step_workspace_bytes(r->B, r->N) && ((uintptr_t)ws & 255) == 0, "rx_neumf_step: workspace too small or not 256-byte aligned");
