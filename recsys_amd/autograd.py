@@ -737,7 +737,7 @@ def cross_stack(x0: Tensor, layers, bf16: bool = False) -> Tensor:
 
 def h16_shapes_ok(x: Tensor, weights) -> bool:
     """Shapes the bf16-activation kernels take: fp32 GPU input with 16-byte addressable rows, every
-    layer width a multiple of 4 (the last layer may have one output column, up to 512 inputs)."""
+    layer width a multiple of 4 (the last layer may have one output column, up to 4096 inputs)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1 and x.shape[1] % 4 == 0
             and x.shape[1] >= 8 and x.stride(1) == 1 and x.stride(0) % 4 == 0):
         return False
@@ -746,7 +746,7 @@ def h16_shapes_ok(x: Tensor, weights) -> bool:
         n, k = w.shape
         if k % 4 != 0 or k < 8:
             return False
-        if n % 4 != 0 and not (i == len(ws) - 1 and n == 1 and k <= 512):
+        if n % 4 != 0 and not (i == len(ws) - 1 and n == 1 and k <= 4096):
             return False
     return True
 

@@ -1900,12 +1900,91 @@ gemv16_bwd_w_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const uint16_t
   }
 }
 
+#define GEMV16_MAX_K 4096
 static inline int gemv16_lpr(int K) {
   int l = 1;
   while (l * 8 < K) l <<= 1;
   return l;
 }
-static inline bool gemv16_ok(int32_t N, int32_t K) { return N == 1 && K % 4 == 0 && K >= 8 && K <= 512; }
+static inline bool gemv16_ok(int32_t N, int32_t K) { return N == 1 && K % 4 == 0 && K >= 8 && K <= GEMV16_MAX_K; }
+static inline bool gemv16_wide(int32_t K) { return K > 512; }   // beyond one 16-byte piece per lane of a wavefront
+
+// The same three products for rows of more than 512 inputs (up to GEMV16_MAX_K): a wavefront per row, CH 16-byte
+// pieces per lane (forward); a thread per piece column walking the slab's rows (weight gradient).
+template <int CH>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv16_fwd_wide_kernel(const uint16_t* __restrict__ X, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                       float* __restrict__ Y, int64_t ldy, int64_t M, int K, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[CH][8];
+  bool ok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int k0 = (c * 64 + lane) * 8;
+    ok[c] = k0 < K;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[c][e] = (k0 + e < K) ? round_bf16(w[k0 + e]) : 0.f;   // rows are zero padded to 8
+  }
+  const float bv = b ? b[0] : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * (RX_BLOCK / 64) + wave; r < M; r += (int64_t)gridDim.x * (RX_BLOCK / 64)) {
+    uint4 x[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) x[c] = ok[c] ? *reinterpret_cast<const uint4*>(X + r * ldx + (c * 64 + lane) * 8) : make_uint4(0u, 0u, 0u, 0u);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const uint32_t xs[4] = {x[c].x, x[c].y, x[c].z, x[c].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += bf16_bits_to_f32(xs[e] & 0xffffu) * wv[c][2 * e] + bf16_bits_to_f32(xs[e] >> 16) * wv[c][2 * e + 1];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) {
+      float v = s + bv;
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      Y[r * ldy] = v;
+    }
+  }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(RX_BLOCK)
+gemv16_bwd_w_wide_kernel(const uint16_t* __restrict__ dY, int64_t ldd, const uint16_t* __restrict__ X, int64_t ldx, int64_t M, int K,
+                         int64_t rows_per_slab, float* __restrict__ part_w, float* __restrict__ part_b) {
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t hi = (lo + rows_per_slab < M) ? lo + rows_per_slab : M;
+  float s[CH][8];
+  bool ok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    ok[c] = (c * RX_BLOCK + (int)threadIdx.x) * 8 < K;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[c][e] = 0.f;
+  }
+  float sb = 0.f;
+  for (int64_t r = lo; r < hi; ++r) {
+    const float gy = bf16_bits_to_f32(dY[r * ldd]);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const uint4 x = ok[c] ? *reinterpret_cast<const uint4*>(X + r * ldx + (c * RX_BLOCK + threadIdx.x) * 8) : make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[c][2 * e] += gy * bf16_bits_to_f32(xs[e] & 0xffffu);
+        s[c][2 * e + 1] += gy * bf16_bits_to_f32(xs[e] >> 16);
+      }
+    }
+    sb += gy;
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = (c * RX_BLOCK + threadIdx.x) * 8 + e;
+      if (k < K) part_w[(int64_t)blockIdx.x * K + k] = s[c][e];
+    }
+  if (threadIdx.x == 0 && part_b) part_b[blockIdx.x] = sb;
+}
 
 // ---- column sums of a bf16 matrix: partial[z][j]; a block covers 128 columns with 16 row lanes of 16-byte loads
 template <int DUMMY>
@@ -1949,6 +2028,42 @@ colsum16_slab_kernel(const uint16_t* __restrict__ dY, int64_t ldd, int64_t M, in
   }
 }
 
+// ---- wide plain products go to the library (rx_blaslt.hip); 0 done, 1 error, -1 not taken
+int rx_lt_matmul(int device, hipStream_t st, int transA, int transB, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda,
+                 const void* B, int64_t ldb, void* D, int64_t ldd, int out_bf16, const float* bias, int relu, int beta1, void* call_ws,
+                 size_t call_ws_bytes);
+
+// [rows, n_out] = [rows, n_red] x [n_red, n_out]: where the library's kernels are the faster ones (measured at
+// rows = 65536, profiles/gemm16_vs_library.py: 1024 x 432, 512 x 1024, 256 x 512 and everything wider go to the
+// library; 432 x 432, 216 x 432, 108 x 216 stay here)
+static const bool lt_gated_too = [] { const char* e = getenv("RX_LT_NO_GATED"); return !(e && e[0] == '1'); }();   // A/B: gated input gradients
+static const bool lt_bwd_w_too = [] { const char* e = getenv("RX_LT_NO_BWD_W"); return !(e && e[0] == '1'); }();   // A/B: weight gradients
+static bool lt_shape(int64_t rows, int64_t n_out, int64_t n_red) {
+  const int64_t lo = n_out < n_red ? n_out : n_red, hi = n_out < n_red ? n_red : n_out;
+  return rows >= 4096 && lo >= 256 && hi >= 512 && n_out % 4 == 0 && n_red % 4 == 0;
+}
+
+// dX16 = gate > 0 ? dX16 : 0 in place: the ReLU backward of the layer in front, for input gradients that came from
+// the library (gemm_h16_kernel applies the gate in its epilogue)
+__global__ void __launch_bounds__(RX_BLOCK)
+relu_gate16_kernel(uint16_t* __restrict__ dx, int64_t ldx, const uint16_t* __restrict__ gate, int64_t ldg, int64_t rows, int c8) {
+  const int64_t n = rows * c8;
+  const bool small = n < (1ll << 31);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rx_row_of(i, c8, small);
+    const int c = (int)(i - r * c8) * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(dx + r * ldx + c);
+    const uint4 g = *reinterpret_cast<const uint4*>(gate + r * ldg + c);
+    auto keep = [](uint32_t x, uint32_t gg) {   // a bf16 gate passes when it is positive: not zero, sign clear
+      const uint32_t glo = gg & 0xffffu, ghi = gg >> 16;
+      const uint32_t mlo = (glo == 0 || (glo & 0x8000u)) ? 0u : 0xffffu, mhi = (ghi == 0 || (ghi & 0x8000u)) ? 0u : 0xffff0000u;
+      return x & (mlo | mhi);
+    };
+    v.x = keep(v.x, g.x); v.y = keep(v.y, g.y); v.z = keep(v.z, g.z); v.w = keep(v.w, g.w);
+    *reinterpret_cast<uint4*>(dx + r * ldx + c) = v;
+  }
+}
+
 extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t* W16, const float* W, const float* b,
                                void* Y, int64_t ldy, int64_t M, int32_t N, int32_t K, int act, int out_bf16, int device,
                                void* stream) {
@@ -1960,6 +2075,16 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
   hipStream_t st = (hipStream_t)stream;
   if (gemv16_ok(N, K) && !out_bf16) {
     RX_REQUIRE(W, "rx_linear16_fwd: the one-column layer reads the fp32 weights");
+    if (gemv16_wide(K)) {
+      int64_t wg = rx_cdiv(M, RX_BLOCK / 64);
+      if (wg > 8192) wg = 8192;
+      const int ch = (int)rx_cdiv(rx_cdiv(K, 8), 64);
+      if (ch <= 2) hipLaunchKernelGGL(gemv16_fwd_wide_kernel<2>, dim3((unsigned)wg), dim3(RX_BLOCK), 0, st, X16, ldx, W, b, (float*)Y, ldy, M, (int)K, act);
+      else if (ch <= 4) hipLaunchKernelGGL(gemv16_fwd_wide_kernel<4>, dim3((unsigned)wg), dim3(RX_BLOCK), 0, st, X16, ldx, W, b, (float*)Y, ldy, M, (int)K, act);
+      else hipLaunchKernelGGL(gemv16_fwd_wide_kernel<8>, dim3((unsigned)wg), dim3(RX_BLOCK), 0, st, X16, ldx, W, b, (float*)Y, ldy, M, (int)K, act);
+      RX_LAUNCH_CHECK();
+      return 0;
+    }
     const int lpr = gemv16_lpr(K);
     int64_t grid = rx_cdiv(M, RX_BLOCK / lpr);
     if (grid > 4096) grid = 4096;
@@ -1970,6 +2095,10 @@ extern "C" int rx_linear16_fwd(const uint16_t* X16, int64_t ldx, const uint16_t*
   RX_REQUIRE(W16 && rx_aligned16(W16), "rx_linear16_fwd: null or unaligned bf16 weights");
   RX_REQUIRE(N % 4 == 0 && (out_bf16 ? h16_ok(Y, ldy) : f4_ok(Y, ldy)),
              "rx_linear16_fwd: N must be a multiple of 4 and output rows 16-byte addressable");
+  if (lt_shape(M, N, K)) {   // Y^T (N x M, column-major) = W16^T X16^T: A = W16 as K x N, transposed; B = X16 as K x M
+    const int rc = rx_lt_matmul(device, st, 1, 0, N, M, K, W16, rx_cdiv(K, 8) * 8, X16, ldx, Y, ldy, out_bf16, b, act, 0, nullptr, 0);
+    if (rc >= 0) return rc;
+  }
   Gemm16Args g{};
   g.A = X16; g.lda = ldx; g.B = W16; g.ldb = rx_cdiv(K, 8) * 8; g.C = Y; g.ldc = ldy; g.bias = b;
   g.M = M; g.N = N; g.K = K; g.act = act; g.k_per_slab = K;
@@ -2016,6 +2145,20 @@ extern "C" int rx_linear16_bwd_x(const uint16_t* dY16, int64_t ldd, const uint16
   RX_REQUIRE(N % 4 == 0 && h16_ok(dY16, ldd) && W16T && rx_aligned16(W16T), "rx_linear16_bwd_x: N must be a multiple of 4, operands 16-byte aligned");
   RX_REQUIRE(K % 4 == 0 && (out_bf16 ? (h16_ok(dX, ldx) && (!gate16 || h16_ok(gate16, ldg))) : f4_ok(dX, ldx)),
              "rx_linear16_bwd_x: K must be a multiple of 4 and output (and gate) rows 16-byte addressable");
+  if (lt_shape(M, K, N) && (!gate16 || (K % 8 == 0 && lt_gated_too))) {   // (the gate pass works on whole 16-byte pieces)
+    // dX^T (K x M, column-major) = W^T dY^T: A = W16T as N x K, transposed; B = dY16 as N x M; the gate in a pass of its own
+    const int rc = rx_lt_matmul(device, st, 1, 0, K, M, N, W16T, rx_cdiv(N, 8) * 8, dY16, ldd, dX, ldx, out_bf16, nullptr, 0, accumulate, nullptr, 0);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      if (gate16) {
+        int64_t grid = rx_cdiv(M * (K / 8), RX_BLOCK);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(relu_gate16_kernel, dim3((unsigned)grid), dim3(RX_BLOCK), 0, st, (uint16_t*)dX, ldx, gate16, ldg, M, (int)(K / 8));
+        RX_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   Gemm16Args g{};
   g.A = dY16; g.lda = ldd; g.B = W16T; g.ldb = rx_cdiv(N, 8) * 8; g.C = dX; g.ldc = ldx; g.bias = nullptr; g.gate = gate16; g.ldg = ldg;
   g.M = M; g.N = K; g.K = N; g.act = 0; g.k_per_slab = N;
@@ -2056,6 +2199,16 @@ extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16
   float* slabs = (float*)ws;
   float* bpart = (float*)((char*)ws + rx_align_up((size_t)s * N * K * sizeof(float), 256));
   const int64_t nk = (int64_t)N * K;
+  if (gemv16_ok(N, K) && gemv16_wide(K)) {
+    const int ch = (int)rx_cdiv(rx_cdiv(K, 8), RX_BLOCK);
+    if (ch <= 1) hipLaunchKernelGGL(gemv16_bwd_w_wide_kernel<1>, dim3((unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY16, ldd, X16, ldx, M, (int)K, rows_per_slab, slabs, db ? bpart : (float*)nullptr);
+    else hipLaunchKernelGGL(gemv16_bwd_w_wide_kernel<2>, dim3((unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY16, ldd, X16, ldx, M, (int)K, rows_per_slab, slabs, db ? bpart : (float*)nullptr);
+    RX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)(rx_cdiv((int64_t)K, 64) + (db ? 1 : 0))), dim3(RX_BLOCK), 0, st, slabs,
+                       (int64_t)K, n_slabs, dW, (const float*)bpart, (int64_t)(db ? 1 : 0), n_slabs, db);
+    RX_LAUNCH_CHECK();
+    return 0;
+  }
   if (gemv16_ok(N, K)) {
     const int lpr = gemv16_lpr(K);
     RX_GEMV_DISPATCH(gemv16_bwd_w_kernel, lpr, dim3((unsigned)n_slabs), dim3(RX_BLOCK), 0, st, dY16, ldd, X16, ldx, M, (int)K, rows_per_slab,
@@ -2067,6 +2220,28 @@ extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16
     return 0;
   }
   RX_REQUIRE(N % 4 == 0 && h16_ok(dY16, ldd), "rx_linear16_bwd_w: N must be a multiple of 4 and dY 16-byte aligned");
+  if (lt_bwd_w_too && lt_shape(M, N, K) && (int64_t)N * K >= (1 << 20)) {
+    // dW^T (K x N, column-major, ld K) = X16^T dY16: A = X16 as K x M; B = dY16 as N x M, transposed.  Output tiles alone
+    // fill the card at these widths, so the library needs no split over the batch; the bias gradient takes the
+    // column-sum pass
+    // (the slab area of the caller's workspace is free on this path: lent to the library)
+    const int rc = rx_lt_matmul(device, st, 0, 1, K, N, M, X16, ldx, dY16, ldd, dW, K, 0, nullptr, 0, 0, slabs,
+                                rx_align_up((size_t)s * N * K * sizeof(float), 256));
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      if (db) {
+        int64_t cs_rows = rx_cdiv(M, COLSUM16_SLABS);
+        cs_rows = rx_cdiv(cs_rows, 16) * 16;
+        const int cs = (int)rx_cdiv(M, cs_rows);
+        hipLaunchKernelGGL(colsum16_slab_kernel<0>, dim3((unsigned)rx_cdiv(N, 128), 1, (unsigned)cs), dim3(RX_BLOCK), 0, st, dY16, ldd, M, (int)N, cs_rows, bpart);
+        RX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rx_cdiv(N, 64)), dim3(RX_BLOCK), 0, st, (const float*)bpart, (int64_t)N, cs, db,
+                           (const float*)nullptr, (int64_t)0, 0, (float*)nullptr);
+        RX_LAUNCH_CHECK();
+      }
+      return 0;
+    }
+  }
   Gemm16Args g{};
   g.A = dY16; g.lda = ldd; g.B = X16; g.ldb = ldx; g.C = slabs; g.ldc = K; g.bias = nullptr;
   g.M = N; g.N = K; g.K = M; g.act = 0; g.k_per_slab = rows_per_slab; g.c_slab_stride = nk;

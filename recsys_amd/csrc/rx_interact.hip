@@ -889,8 +889,11 @@ static int bce_scratch_resolve(int device) {
   return 0;
 }
 
+int rx_lt_init(int device);   // rx_blaslt.hip: the device's hipBLASLt handle
+
 extern "C" int rx_init(int device) {
   RX_ENTER(device);
+  rx_lt_init(device);
   return bce_scratch_resolve(device);
 }
 

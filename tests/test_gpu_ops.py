@@ -999,3 +999,25 @@ def test_dense_gradients_of_several_tables_in_one_reduce_equal_one_reduce_per_ta
         idx = users if occ.shape[0] == B else items.reshape(-1)
         exp = torch.zeros(p.shape, dtype=torch.float64, device="cuda").index_add_(0, idx, occ.double())
         assert_close(g.cpu(), exp.float().cpu(), 1e-5, "dense table gradient")
+
+
+@pytest.mark.parametrize("K", [520, 836, 2048, 4096])
+def test_linear16_one_column_layer_beyond_512_inputs(ops, K):
+    """The tower's last layer (one output column) on bf16 activations with rows of more than 512 inputs (the
+    836-wide last layer of the 1 B-row DeepFM's tower): forward, input gradient and weight / bias gradient against
+    fp64 products of the same bf16-rounded operands."""
+    g0 = _gen(K)
+    M = 3001
+    x = torch.randn(M, K, generator=g0).cuda()
+    w = (torch.randn(1, K, generator=g0) * 0.1).cuda()
+    b = torch.randn(1, generator=g0).cuda()
+    dy = torch.randn(M, 1, generator=g0).cuda()
+    x16, dy16 = ops.to_bf16(x), ops.to_bf16(dy)
+    xr, wr, dyr = x16.float().double(), w.to(torch.bfloat16).double(), dy16.float().double()
+    y = ops.linear16_fwd(x16, w, b, False, False)
+    assert_close(y.cpu(), (xr @ wr.t() + b.double()).float().cpu(), 1e-5, "linear16 one-column forward")
+    dx = ops.linear16_bwd_x(dy16, w, out_bf16=False)
+    assert_close(dx.cpu(), (dyr @ wr).float().cpu(), 1e-5, "linear16 one-column input gradient")
+    dw, db = ops.linear16_bwd_w(dy16, x16, True)
+    assert_close(dw.cpu(), (dyr.t() @ xr).float().cpu(), 1e-5, "linear16 one-column weight gradient")
+    assert_close(db.cpu(), dyr.sum(0).float().cpu(), 1e-5, "linear16 bias grad")
