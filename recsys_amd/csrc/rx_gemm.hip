@@ -2220,7 +2220,7 @@ extern "C" int rx_linear16_bwd_w(const uint16_t* dY16, int64_t ldd, const uint16
     return 0;
   }
   RX_REQUIRE(N % 4 == 0 && h16_ok(dY16, ldd), "rx_linear16_bwd_w: N must be a multiple of 4 and dY 16-byte aligned");
-  if (lt_bwd_w_too && lt_shape(M, N, K) && (int64_t)N * K >= (1 << 20)) {
+  if (lt_bwd_w_too && lt_shape(M, N, K) && (int64_t)N * K >= (4 << 20)) {   // measured: the library wins at 1672 x 3344 (626 against 383 TFLOP/s), loses at 836 x 1672 and below
     // dW^T (K x N, column-major, ld K) = X16^T dY16: A = X16 as K x M; B = dY16 as N x M, transposed.  Output tiles alone
     // fill the card at these widths, so the library needs no split over the batch; the bias gradient takes the
     // column-sum pass
