@@ -341,7 +341,8 @@ def kernels_that_run(op, opt=None):
     ks = OP_KERNELS.get(op)
     if ks is None:
         return None
-    spec = opt is not None and getattr(opt, "kind", None) == "sgd" and getattr(opt, "clip_norm", None) and not optim._NO_SPECULATION
+    spec = (opt is not None and getattr(opt, "kind", None) == "sgd" and getattr(opt, "clip_norm", None) and getattr(opt, "speculative", False)
+            and not optim._NO_SPECULATION)
     return [(k[0] if spec or len(k) == 1 else k[1]) if isinstance(k, tuple) else k for k in ks]
 
 

@@ -90,7 +90,8 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
             # not the first backward pass since the last step (gradient accumulation): rows that an earlier
             # pass of this step already moved go back first, and this pass keeps to the two-phase form
             self.owner._restore_speculative()
-        elif self.kind == "sgd" and not _NO_SPECULATION and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr)):
+        elif (self.kind == "sgd" and not _NO_SPECULATION and self.owner.speculative
+              and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr))):
             # Clipped SGD in one pass over the distinct rows when the clip does not bite: the reduce takes the
             # step with a factor of 1 and leaves undo records; step() redoes the rows only when the norm turns
             # out to exceed the bound (rx_fg_reduce_args.undo).  Bit-identical to the two-phase form either way.
@@ -116,7 +117,7 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
     dim = tsum.shape[1]
     if self.owner._pending:
         self.owner._restore_speculative()          # gradient accumulation: see the field-grouped branch above
-    elif (self.kind == "sgd" and _SPECULATE_SORTED and not _NO_SPECULATION and table.is_cuda and table.is_contiguous()
+    elif (self.kind == "sgd" and _SPECULATE_SORTED and not _NO_SPECULATION and self.owner.speculative and table.is_cuda and table.is_contiguous()
           and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr))):
         # the same one-pass clipped SGD step on the general sorted path (rows wider than the field groups take,
         # N > 1, B > 65536): undo records go where the reduce's `state` arguments point
@@ -153,13 +154,15 @@ class FusedOptimizer:
     ``kind`` in {"sgd", "adagrad", "rowwise_adagrad"} applies to the parameters the model lists
     in ``model.sparse_parameters()``; all other parameters are stepped densely with
     ``dense_kind`` (default: "sgd" for sgd, "adagrad" otherwise; "adam" allowed).
+    ``speculative``: whether clipped SGD over field groups takes its step inside the backward's reduce and redoes
+    rows only if the clip bites (default: only for models without dense parameters).
     ``kind="dense_adam"``: no sparse rule at all -- dense table gradients and Adam on every parameter,
     the reference pipelines' optimizer (``from_torch`` builds it from a ``torch.optim.Adam``).
     API mirrors torch.optim: ``zero_grad()``, ``step()``."""
 
     def __init__(self, model, kind: str = "sgd", lr: float = 0.01, eps: float = 1e-10,
                  clip_norm: Optional[float] = None, dense_kind: Optional[str] = None,
-                 betas=(0.9, 0.999), adam_eps: float = 1e-8):
+                 betas=(0.9, 0.999), adam_eps: float = 1e-8, speculative: Optional[bool] = None):
         if kind not in _MODES and kind != "dense_adam":
             raise ValueError(f"unknown sparse optimizer {kind!r}")
         self.kind, self.lr, self.eps, self.clip_norm = kind, lr, eps, clip_norm
@@ -193,6 +196,12 @@ class FusedOptimizer:
         elif self.dense_kind == "adam":
             for p in self.dense:
                 self._dense_state_for(p)
+        # Clipped SGD taken speculatively inside the reduce (see _rule_apply_fm) pays when the clip is idle and costs a
+        # second full pass over the rows when it bites.  Default: on for models that are embedding tables only (the FM:
+        # its gradient norm sits below the reference's bound of 1 after the first steps), off when a tower's
+        # gradients enter the norm (FieldDeepFM at the benchmark shape clips on every step: 1.41 ms per step with
+        # speculation, 1.35 without).  ``speculative=True / False`` decides it outright.
+        self.speculative = bool(speculative) if speculative is not None else not self.dense
         self._pending = []
         self._has_spec = False                        # a pending entry whose rows the reduce already moved (speculative clipped SGD)
         self._zero = None

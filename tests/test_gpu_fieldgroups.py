@@ -393,7 +393,9 @@ def test_speculative_clipped_sgd_equals_the_two_phase_step_bitwise(model, line_r
                 with torch.no_grad():
                     m.feature_embedding.weight.mul_(0.1)     # wide N(0, 1) rows saturate every logit
         m.train()
-        opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip)
+        opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip, speculative=True)   # (the default leaves models with a tower out)
+        assert optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip).speculative == (model == "fm")
+        opt = optim.FusedOptimizer(m, kind="sgd", lr=0.1, clip_norm=clip, speculative=True)   # the rules of the last one made are the ones in use
         losses, norms = [], []
         for b in batches:
             opt.zero_grad()
