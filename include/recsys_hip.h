@@ -588,6 +588,16 @@ size_t rx_multi_sumsq_partials(int32_t count);
 int rx_multi_sumsq(const rx_tensor_list* list, double* d_partial, int device, void* stream);
 int rx_multi_dense_update(const rx_tensor_list* list, int mode, float lr, float eps,
                           const float* d_scale, int device, void* stream);
+/* The tail of a clipped step (recsys/utils.py:101-103: clip_grad_norm_, optimizer.step) in ONE launch: the clip
+ * factor from the step's partial sums of squares (rx_clip_scale_parts: fp32 parts of the table reduces, fp64 parts
+ * of rx_multi_sumsq), the row updates of up to RX_SEG_MULTI_MAX tables from their compact gradients
+ * (rx_row_update_multi) and the update of up to RX_MULTI_MAX dense tensors (rx_multi_dense_update: dense_mode SGD
+ * or Adagrad, dense may be NULL).  Every block forms the factor itself, in the order of rx_clip_scale_parts, so the
+ * results equal the three calls bit for bit; d_scale / d_total_norm (may be NULL) receive factor and norm. */
+int rx_step_tail(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps, const rx_tensor_list* dense,
+                 int dense_mode, float dense_lr, float dense_eps, const float* d_parts, int64_t n_parts,
+                 const double* d_parts64, int64_t n_parts64, float max_norm, float* d_scale, float* d_total_norm,
+                 int device, void* stream);
 /* torch.optim.Adam over every parameter of a model -- what the reference's pipelines build
  * (recsys/pipelines/neuralcf/neumf.py:10, matrix_factorization/vanilla_mf.py:10) -- as ONE launch for up to
  * RX_MULTI_MAX tensors: rx_dense_adam / rx_dense_adam_dstep element by element (d_step != NULL: the step count

@@ -174,6 +174,8 @@ PROTOTYPES = {
     "rx_multi_sumsq_partials": (C.c_size_t, [i32]),
     "rx_multi_sumsq": (C.c_int, [C.POINTER(TensorList), vp, C.c_int, vp]),
     "rx_multi_dense_update": (C.c_int, [C.POINTER(TensorList), C.c_int, f32, f32, vp, C.c_int, vp]),
+    "rx_step_tail": (C.c_int, [C.POINTER(SegTable), i32, C.c_int, f32, f32, C.POINTER(TensorList), C.c_int, f32, f32, vp, i64, vp, i64, f32,
+                               vp, vp, C.c_int, vp]),
     "rx_multi_dense_adam": (C.c_int, [C.POINTER(AdamList), f32, f32, f32, f32, i32, vp, vp, C.c_int, vp]),
     "rx_reduce_sum": (C.c_int, [vp, i64, vp, vp, sz, C.c_int, vp]),
     "rx_linear_fwd": (C.c_int, [vp, i64, vp, vp, vp, i64, i64, i32, i32, C.c_int, C.c_int, C.c_int, vp]),

@@ -914,7 +914,7 @@ template <int CH> __host__ __device__ constexpr int upd_rows() { return CH == 1 
 static inline int upd_rows_of(int chunks, int mode) { return mode == RX_SEG_SGD_SPEC ? 1 : (chunks == 1 ? 4 : (chunks == 2 ? 2 : 1)); }
 
 template <int VEC, int CH, int MODE>
-__device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned blk) {
+__device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned blk, const float scale) {
   const int group = a.group, dim = a.dim;
   const int64_t gid = (int64_t)blk * blockDim.x + threadIdx.x;
   const int lg = (int)(gid % group);
@@ -924,7 +924,6 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
     const int64_t row = a.uniq_rows[u];
     if (row < 0 || row >= a.n_rows) return;
     // redo the row from its record: old - lr * (factor * G), what RX_SEG_COMPACT + RX_SEG_SGD leave
-    const float scale = a.scale ? a.scale[0] : 1.f;
     const float* ud = a.occ + u * (int64_t)(2 * dim);
     float* w = a.target + row * (int64_t)dim;
 #pragma unroll
@@ -969,7 +968,6 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
     ACC_FOREACH(k, i) { x[r].p[k].v[i] = 0.f; st[r].p[k].v[i] = 0.f; }
     load_old<VEC, CH, MODE, false>(a, ok[r] ? rows[r] : 0, lg, x[r], st[r]);
   }
-  const float scale = a.scale ? a.scale[0] : 1.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (!ok[r]) continue;
@@ -987,9 +985,9 @@ row_update_kernel(SegArgs a) {
     // strides over the list, so that the common case costs a few hundred blocks reading one float.
     const float scale = a.scale ? a.scale[0] : 1.f;
     if (scale == 1.f && !a.force) return;
-    for (unsigned b = blockIdx.x; b < a.upd_blocks; b += gridDim.x) row_update_body<VEC, CH, MODE>(a, b);
+    for (unsigned b = blockIdx.x; b < a.upd_blocks; b += gridDim.x) row_update_body<VEC, CH, MODE>(a, b, scale);
   } else {
-    row_update_body<VEC, CH, MODE>(a, blockIdx.x);
+    row_update_body<VEC, CH, MODE>(a, blockIdx.x, a.scale ? a.scale[0] : 1.f);
   }
 }
 
@@ -997,7 +995,7 @@ template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 row_update_multi_kernel(SegMulti m) {
   const int t = seg_multi_table(m);
-  row_update_body<VEC, CH, MODE>(m.t[t], blockIdx.x - m.first[t]);
+  row_update_body<VEC, CH, MODE>(m.t[t], blockIdx.x - m.first[t], m.t[t].scale ? m.t[t].scale[0] : 1.f);
 }
 
 extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t* d_uniq_rows,
@@ -1297,15 +1295,13 @@ multi_sumsq_kernel(rx_tensor_list t, double* __restrict__ partial) {
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(RX_BLOCK)
-multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __restrict__ scale) {
-  const int k = blockIdx.y;
+__device__ __forceinline__ void multi_dense_body(const rx_tensor_list& t, const int k, const unsigned bx, const unsigned nbx, float lr, float eps,
+                                                 const float sc) {
   float* __restrict__ w = t.w[k];
   const float* __restrict__ g = t.g[k];
   float* __restrict__ s = t.state[k];
   const int64_t n = t.n[k];
-  const float sc = scale ? scale[0] : 1.f;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tid = (int64_t)bx * blockDim.x + threadIdx.x, stride = (int64_t)nbx * blockDim.x;
   auto one = [&](float wi, float gi_, float& si) {   // the rule on one element (same arithmetic whatever the access width)
     const float gi = gi_ * sc;
     if (MODE == RX_SEG_SGD) return wi - lr * gi;
@@ -1337,6 +1333,12 @@ multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __
     w[j] = one(w[j], g[j], sj);
     if (MODE != RX_SEG_SGD) s[j] = sj;
   }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(RX_BLOCK)
+multi_dense_update_kernel(rx_tensor_list t, float lr, float eps, const float* __restrict__ scale) {
+  multi_dense_body<MODE>(t, blockIdx.y, blockIdx.x, gridDim.x, lr, eps, scale ? scale[0] : 1.f);
 }
 
 // Adam on up to RX_MULTI_MAX tensors in one launch (blockIdx.y selects the tensor): the arithmetic of
@@ -1431,13 +1433,10 @@ extern "C" int rx_multi_dense_update(const rx_tensor_list* list, int mode, float
   return 0;
 }
 
-// One block: thread t adds parts[t], parts[t + 256], ... in order (fp64), fixed xor trees and a
-// fixed order over the four waves join them; then the clip factor.
-__global__ void __launch_bounds__(RX_BLOCK)
-clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double* __restrict__ parts64, int64_t n64,
-                        const double* __restrict__ acc, float max_norm, float* __restrict__ scale,
-                        float* __restrict__ total_norm) {
-  __shared__ double wsum[RX_BLOCK / 64];
+// Thread t adds parts[t], parts[t + 256], ... in order (fp64), fixed xor trees and a fixed order over the four
+// waves join them; then the clip factor.  Every thread of the block gets the factor (and the norm in *tn).
+__device__ __forceinline__ float clip_parts_block(const float* __restrict__ parts, int64_t n, const double* __restrict__ parts64, int64_t n64,
+                                                  const double* __restrict__ acc, float max_norm, double* wsum, float* tn_out) {
   double s = 0.0;
   // eight loads in flight, added in index order: the sum is the one of the plain loop, bit for bit
   int64_t i = threadIdx.x;
@@ -1453,12 +1452,119 @@ clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double
   s = rx_wave_sum_f64(s);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x != 0) return;
   const double total = (acc ? acc[0] : 0.0) + ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
   const float tn = (float)sqrt(total);
   const float coef = max_norm / (tn + 1e-6f);
-  scale[0] = coef < 1.f ? coef : 1.f;
+  *tn_out = tn;
+  return coef < 1.f ? coef : 1.f;
+}
+
+__global__ void __launch_bounds__(RX_BLOCK)
+clip_scale_parts_kernel(const float* __restrict__ parts, int64_t n, const double* __restrict__ parts64, int64_t n64,
+                        const double* __restrict__ acc, float max_norm, float* __restrict__ scale,
+                        float* __restrict__ total_norm) {
+  __shared__ double wsum[RX_BLOCK / 64];
+  float tn;
+  const float sc = clip_parts_block(parts, n, parts64, n64, acc, max_norm, wsum, &tn);
+  if (threadIdx.x != 0) return;
+  scale[0] = sc;
   if (total_norm) total_norm[0] = tn;
+}
+
+// The tail of a clipped step in ONE launch: clip factor (formed by every block from the step's partial sums of
+// squares: same order and tree as clip_scale_parts_kernel, so all blocks hold the same bits), the row updates of up
+// to RX_SEG_MULTI_MAX tables (blocks [0, row_blocks)) and the update of up to RX_MULTI_MAX dense tensors (the
+// blocks behind them, RX_MULTI_BLOCKS per tensor).  Results equal rx_clip_scale_parts + rx_row_update_multi +
+// rx_multi_dense_update bit for bit; two launches of a few microseconds leave the step's critical path.
+struct StepTail {
+  const float* parts; int64_t n;
+  const double* parts64; int64_t n64;
+  float max_norm;
+  float* scale_out; float* norm_out;
+  rx_tensor_list dense;
+  int dense_mode;
+  float dense_lr, dense_eps;
+  unsigned row_blocks;
+};
+
+template <int VEC, int CH, int MODE, bool FM>
+__global__ void __launch_bounds__(RX_BLOCK)
+step_tail_kernel(SegMulti m, StepTail x) {
+  __shared__ double wsum[RX_BLOCK / 64];
+  float tn;
+  const float sc = clip_parts_block(x.parts, x.n, x.parts64, x.n64, nullptr, x.max_norm, wsum, &tn);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    x.scale_out[0] = sc;
+    if (x.norm_out) x.norm_out[0] = tn;
+  }
+  if (blockIdx.x < x.row_blocks) {
+    const int t = seg_multi_table(m);
+    row_update_body<VEC, CH, MODE>(m.t[t], blockIdx.x - m.first[t], sc);
+    return;
+  }
+  const unsigned b = blockIdx.x - x.row_blocks;
+  const int k = (int)(b / RX_MULTI_BLOCKS);
+  const unsigned bx = b % RX_MULTI_BLOCKS;
+  if (x.dense_mode == RX_SEG_SGD) multi_dense_body<RX_SEG_SGD>(x.dense, k, bx, RX_MULTI_BLOCKS, x.dense_lr, x.dense_eps, sc);
+  else multi_dense_body<RX_SEG_ADAGRAD>(x.dense, k, bx, RX_MULTI_BLOCKS, x.dense_lr, x.dense_eps, sc);
+}
+
+extern "C" int rx_step_tail(const rx_seg_table* tables, int32_t count, int mode, float lr, float eps, const rx_tensor_list* dense,
+                            int dense_mode, float dense_lr, float dense_eps, const float* d_parts, int64_t n_parts,
+                            const double* d_parts64, int64_t n_parts64, float max_norm, float* d_scale, float* d_total_norm,
+                            int device, void* stream) {
+  RX_ENTER(device);
+  RX_REQUIRE(count >= 1 && count <= SEG_MULTI_MAX && tables, "rx_step_tail: 1..%d tables per call", SEG_MULTI_MAX);
+  RX_REQUIRE(mode == RX_SEG_SGD || mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD, "rx_step_tail: row rule must be SGD, Adagrad or row-wise Adagrad");
+  RX_REQUIRE(!dense || (dense->count >= 0 && dense->count <= RX_MULTI_MAX), "rx_step_tail: bad dense tensor list");
+  RX_REQUIRE(!dense || dense->count == 0 || dense_mode == RX_SEG_SGD || dense_mode == RX_SEG_ADAGRAD, "rx_step_tail: dense rule must be SGD or Adagrad");
+  RX_REQUIRE(n_parts >= 0 && (d_parts || n_parts == 0) && n_parts64 >= 0 && (d_parts64 || n_parts64 == 0) && d_scale, "rx_step_tail: bad clip arguments");
+  SegMulti m{};
+  RxRowShape sh0{};
+  unsigned blocks = 0;
+  int k = 0;
+  for (int i = 0; i < count; ++i) {
+    const rx_seg_table& t = tables[i];
+    RX_REQUIRE(t.n >= 0 && t.dim >= 1 && t.dim <= RX_MAX_DIM, "rx_step_tail: bad shape");
+    if (mode_check(mode, t.state, "rx_step_tail", false)) return 1;
+    RX_REQUIRE((t.occ2 == nullptr) == (t.target2 == nullptr), "rx_step_tail: companion gradient and table come as a pair");
+    RX_REQUIRE(!t.target2 || !(mode == RX_SEG_ADAGRAD || mode == RX_SEG_ROWWISE_ADAGRAD) || t.state2, "rx_step_tail: companion Adagrad state missing");
+    if (t.n == 0) continue;
+    RX_REQUIRE(t.occ && t.uniq_rows && t.n_uniq && t.target && t.n_rows >= 1, "rx_step_tail: null argument");
+    for (int j = 0; j < k; ++j)
+      RX_REQUIRE(m.t[j].target != t.target, "rx_step_tail: a table may appear once per call (two updates of one row would race)");
+    RxRowShape sh;
+    if (seg_shape(t.dim, t.dim, t.occ, t.target, mode == RX_SEG_ADAGRAD ? t.state : nullptr, &sh, "rx_step_tail")) return 1;
+    RX_REQUIRE(k == 0 || (sh.vec == sh0.vec && sh.chunks == sh0.chunks), "rx_step_tail: the tables of one call must share the row shape");
+    sh0 = sh;
+    SegArgs a;
+    seg_from_table(t, mode, lr, eps, nullptr, &a);
+    a.occ_ld = t.dim; a.group = sh.group; a.sq_part = nullptr;
+    m.t[k] = a; m.first[k] = blocks;
+    blocks += (unsigned)rx_cdiv(rx_cdiv(t.n, upd_rows_of(sh.chunks, mode)) * sh.group, RX_BLOCK);
+    ++k;
+  }
+  RX_REQUIRE(k >= 1, "rx_step_tail: every table is empty; use rx_clip_scale_parts + rx_multi_dense_update");
+  m.first[k] = blocks; m.count = k;
+  StepTail x{};
+  x.parts = d_parts; x.n = n_parts; x.parts64 = d_parts64; x.n64 = n_parts64; x.max_norm = max_norm;
+  x.scale_out = d_scale; x.norm_out = d_total_norm;
+  x.dense_mode = dense_mode; x.dense_lr = dense_lr; x.dense_eps = dense_eps; x.row_blocks = blocks;
+  int n_dense = 0;
+  if (dense) {
+    x.dense = *dense;
+    n_dense = dense->count;
+    for (int i = 0; i < n_dense; ++i)
+      RX_REQUIRE(dense->n[i] >= 0 && ((dense->w[i] && dense->g[i] && (dense_mode == RX_SEG_SGD || dense->state[i])) || dense->n[i] == 0), "rx_step_tail: bad dense tensor %d", i);
+  }
+  const dim3 grid(blocks + (unsigned)n_dense * RX_MULTI_BLOCKS);
+  switch (mode) {     // (the three optimizer rules only: no gradient-buffer or speculative instantiations of this kernel)
+    case RX_SEG_SGD: SEG_DISPATCH_MF(RX_SEG_SGD, false, sh0, step_tail_kernel, grid, 0, (hipStream_t)stream, m, x); break;
+    case RX_SEG_ADAGRAD: SEG_DISPATCH_MF(RX_SEG_ADAGRAD, false, sh0, step_tail_kernel, grid, 0, (hipStream_t)stream, m, x); break;
+    default: SEG_DISPATCH_MF(RX_SEG_ROWWISE_ADAGRAD, false, sh0, step_tail_kernel, grid, 0, (hipStream_t)stream, m, x); break;
+  }
+  RX_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int rx_clip_scale_parts(const float* d_parts, int64_t n_parts, const double* d_parts64, int64_t n_parts64,

@@ -943,6 +943,28 @@ def row_update_multi(items: Sequence[TableReduce], mode: int, *, lr: float = 0.0
                                   _stream(items[0].target)), "rx_row_update_multi")
 
 
+def step_tail(items: Sequence[TableReduce], mode: int, lr: float, eps: float, dense_ws, dense_gs, dense_states, dense_mode: int,
+              dense_lr: float, dense_eps: float, parts: Optional[Tensor], parts64: Optional[Tensor], max_norm: float):
+    """rx_step_tail: clip factor + row updates of several tables + update of the dense tensors, one launch.
+    ``items`` as for ``row_update_multi``; returns (scale, total norm) as one-element tensors."""
+    arr = _seg_tables(items, compact=True)
+    dev = items[0].target.device
+    t = _tensor_list(dense_ws, dense_gs, dense_states) if dense_gs else None
+    if parts is not None:
+        _req(parts, torch.float32, "parts")
+        if not parts.is_contiguous():
+            raise ValueError("parts: contiguous partial sums expected")
+    if parts64 is not None:
+        _req(parts64, torch.float64, "parts64")
+    scale = torch.empty(1, dtype=torch.float32, device=dev)
+    total = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib.rx_step_tail(arr, len(items), mode, lr, eps, C.byref(t) if t is not None else None, dense_mode, dense_lr, dense_eps,
+                           _p(parts), parts.numel() if parts is not None else 0, _p(parts64),
+                           parts64.numel() if parts64 is not None else 0, max_norm, _p(scale), _p(total), _dev(items[0].target),
+                           _stream(items[0].target)), "rx_step_tail")
+    return scale, total
+
+
 # ------------------------------------------------------------------ dense optimizers / reductions
 def dense_adam(w, g, m, v, lr, beta1, beta2, eps, step, scale=None):
     """``step``: the step count t >= 1 as an int, or an int32 device tensor holding it (the form a

@@ -31,6 +31,7 @@ _NO_SPECULATION = os.environ.get("RX_NO_SPECULATIVE_SGD") == "1"   # A/B: clippe
 # row's undo record is eight new 128-byte lines per distinct row, and first-touch line writes cost more than the
 # second pass they save.
 _SPECULATE_SORTED = os.environ.get("RX_SPECULATIVE_SGD_SORTED") == "1"
+_NO_FUSED_TAIL = os.environ.get("RX_NO_FUSED_TAIL") == "1"      # clip factor, row updates and dense update as three launches (A/B)
 
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
 
@@ -353,6 +354,42 @@ class FusedOptimizer:
                                              state2=rule2._state_for(param2) if rule2 is not None else None))
             ops.row_update_multi(items, r0.mode, lr=r0.lr, eps=r0.eps, scale=scale)
 
+    def _fused_tail(self, parts, parts64) -> bool:
+        """Clip factor, row updates and dense update in one launch (rx_step_tail) when the whole tail of the step is
+        of the plain kind: compact gradients of sorted tables under one rule and width (the MF and NCF families),
+        at most 24 contiguous dense tensors under SGD or Adagrad, every partial sum in ``parts`` / ``parts64``.
+        Same bits as the three launches it replaces; RX_NO_FUSED_TAIL=1 keeps those."""
+        if _NO_FUSED_TAIL or not self._pending or len(self._pending) > _lib.RX_SEG_MULTI_MAX or _ONE_LAUNCH_PER_TABLE:
+            return False
+        r0 = self._pending[0][0]
+        d0 = self._pending[0][2].shape[1]
+        seen = set()
+        for (rule, param, compact, si, _, comp, spec) in self._pending:
+            if spec or isinstance(si, ops.FieldGroups) or not param.is_cuda or id(param) in seen:
+                return False
+            if (rule.mode, rule.lr, rule.eps, compact.shape[1]) != (r0.mode, r0.lr, r0.eps, d0):
+                return False
+            seen.add(id(param))
+        if self.dense_kind == "adam":
+            return False
+        live = [(p, p.grad) for p in self.dense if p.grad is not None]
+        if len(live) > _lib.RX_MULTI_MAX or any(not (p.data.is_contiguous() and g.is_contiguous() and p.is_cuda) for p, g in live):
+            return False
+        items = []
+        for (rule, param, compact, si, _, comp, spec) in self._pending:
+            rule2, param2, compact2 = comp if comp is not None else (None, None, None)
+            items.append(ops.TableReduce(compact, si, param.data, d0, state=rule._state_for(param), occ2=compact2,
+                                         target2=param2.data if param2 is not None else None,
+                                         state2=rule2._state_for(param2) if rule2 is not None else None))
+        dmode = _lib.RX_SEG_SGD if self.dense_kind == "sgd" else _lib.RX_SEG_ADAGRAD
+        states = [self._dense_state_for(p) for p, _ in live] if dmode == _lib.RX_SEG_ADAGRAD else None
+        scale, self.last_total_norm = ops.step_tail(items, r0.mode, r0.lr, r0.eps, [p.data for p, _ in live], [g for _, g in live], states,
+                                                    dmode, self.lr, self.eps, parts, parts64, float(self.clip_norm))
+        self._pending.clear()
+        self._has_spec = False
+        self._sq_used = 0
+        return True
+
     def _sq_slice(self, n: int, dim: int, device, need: Optional[int] = None):
         """Room for one reduce's norm partials in the step's shared buffer (None when it is full: the
         reduce then allocates its own and the step adds it separately).  ``need``: number of partials
@@ -483,6 +520,8 @@ class FusedOptimizer:
                     state2=rule2._state_for(param2) if rule2 is not None else None,
                     clip_parts=parts[0], max_norm=float(self.clip_norm))
                 self._pending.clear()
+            elif (parts or parts64 is not None) and acc is None and self._fused_tail(parts[-1] if parts else None, parts64):
+                return
             elif parts or parts64 is not None:
                 scale, self.last_total_norm = ops.clip_scale_parts(parts[-1] if parts else None, acc,
                                                                    float(self.clip_norm), parts64)

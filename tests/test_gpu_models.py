@@ -426,3 +426,40 @@ def test_fused_forward_loss_of_the_mf_family_equals_the_two_launch_path(name, la
         assert abs(x - y) <= 1e-6 * abs(x) if label_dtype == torch.float32 else abs(x - y) <= 1e-12 * abs(x)
     for k in wa:
         assert torch.equal(wa[k], wb[k]), k
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "rowwise_adagrad"])
+@pytest.mark.parametrize("fixture", ["VanillaMF_d16", "NeuMF_d16", "NeuMF_d64", "GMF_d16", "MLP_d16", "BiasMF_d16"])
+def test_step_tail_in_one_launch_equals_the_three_launches_bitwise(fixture, kind, monkeypatch):
+    """rx_step_tail (clip factor + row updates of all tables + dense update in one launch) against
+    rx_clip_scale_parts + rx_row_update_multi + rx_multi_dense_update: weights, optimizer state and clip norm bit
+    for bit after three clipped steps, for every ML-1M-sized model family and all three fused rules; the bound
+    (0.05) bites on every step."""
+    from recsys_amd import optim
+    if fixture not in MODEL_FIXTURES:
+        pytest.skip(f"no golden capture named {fixture}")
+    rec = load_golden(fixture)
+    batch = to_torch(group(rec, "batch"), "cuda")
+
+    def run(fused):
+        monkeypatch.setattr(optim, "_NO_FUSED_TAIL", not fused)
+        calls = []
+        orig = optim.ops.step_tail
+        monkeypatch.setattr(optim.ops, "step_tail", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        m = _build(rec, fixture.split("_")[0]).train()
+        o = optim.FusedOptimizer(m, kind=kind, lr=0.05, clip_norm=0.05)
+        norms = []
+        for _ in range(3):
+            o.zero_grad(); m.loss(batch).backward(); o.step()
+            norms.append(o.last_total_norm.clone())
+        monkeypatch.setattr(optim.ops, "step_tail", orig)
+        state = [st.clone() for r, p in zip(o.rules, o.sparse) for st in [r._state_for(p)] if st is not None]
+        return [p.detach().clone() for p in m.parameters()], norms, state, len(calls)
+
+    w1, n1, s1, c1 = run(True)
+    w0, n0, s0, c0 = run(False)
+    # the one-launch tail is what ran, and what did not (BiasMF's tables have two widths -- rows of 16 floats and of
+    # one -- which is two update launches: it keeps the three-launch form)
+    assert c0 == 0 and c1 == (0 if fixture.startswith("BiasMF") else 3)
+    for a, b in zip(w1 + n1 + s1, w0 + n0 + s0):
+        assert torch.equal(a, b)
