@@ -72,6 +72,7 @@ struct NmArgs {
   int N;
   const float *W1, *b1, *W2, *b2, *Wg, *bg, *wf, *bf;
   float p_drop;
+  double inv_m;           // 1 / (B N), formed on the host: a kernel argument stays in scalar registers
   const int64_t* seed;    // device counter: the dropout stream of this call (NULL: 0)
   float *du_g, *du_m, *di_g, *di_m;
   float* raw;
@@ -90,24 +91,26 @@ __device__ __forceinline__ uint64_t nm_mix(uint64_t seed, uint64_t counter) {
 
 #define NM_ROW(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))   // row of accumulator register r inside a 32 x 32 tile
 
-// Row-chunk mapping of the gathers and the per-pair outputs: thread -> columns qc .. qc + 3 of the pairs
-// qp, qp + 16, qp + 32, qp + 48 of a tile (a float4 of each of the pair's four rows).
+// Row-chunk mapping of the gathers and the per-pair outputs: thread -> columns qc .. qc + 3 of KI pairs of a tile,
+// qp, qp + 64 / KI, ... (a float4 of each of the pair's four rows); KI = 4 with four wavefronts, 2 with eight.
+template <int KI>
 struct NmIdx {
-  int64_t u[4], it[4];
-  unsigned have;          // bit k: the tile has a pair qp + 16 k
+  int64_t u[KI], it[KI];
+  unsigned have;          // bit k: the tile has a pair qp + (64 / KI) k
 };
 
-__device__ __forceinline__ void nm_load_idx(const NmArgs& a, int64_t tile, int64_t tiles, int S, int N, int qp, NmIdx& x) {
+template <int KI>
+__device__ __forceinline__ void nm_load_idx(const NmArgs& a, int64_t tile, int64_t tiles, int S, int N, int qp, NmIdx<KI>& x) {
   x.have = 0u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { x.u[k] = 0; x.it[k] = 0; }
+  for (int k = 0; k < KI; ++k) { x.u[k] = 0; x.it[k] = 0; }
   if (tile >= tiles) return;
   const int64_t s0 = tile * S;
   const int ns = (int)((a.B - s0 < S) ? a.B - s0 : S);
   const int PT = ns * N;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int p = qp + 16 * k;
+  for (int k = 0; k < KI; ++k) {
+    const int p = qp + (64 / KI) * k;
     if (p < PT) {
       x.u[k] = a.users[s0 + p / N];
       x.it[k] = a.items[s0 * N + p];
@@ -118,10 +121,11 @@ __device__ __forceinline__ void nm_load_idx(const NmArgs& a, int64_t tile, int64
 
 // Row offsets of the fetch: a missing pair or an index outside its table reads row 0 (and is masked at use).
 // Returns the bits of the pairs whose rows count.
-__device__ __forceinline__ unsigned nm_row_offsets(const NmArgs& a, const NmIdx& x, int64_t (&ou)[4], int64_t (&oi)[4], bool& bad) {
+template <int KI>
+__device__ __forceinline__ unsigned nm_row_offsets(const NmArgs& a, const NmIdx<KI>& x, int64_t (&ou)[KI], int64_t (&oi)[KI], bool& bad) {
   unsigned ok = 0u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KI; ++k) {
     const int64_t u = x.u[k], it = x.it[k];
     const bool in = u >= 0 && u < a.n_users && it >= 0 && it < a.n_items;
     const bool have = (x.have >> k) & 1u;
@@ -136,10 +140,11 @@ __device__ __forceinline__ unsigned nm_row_offsets(const NmArgs& a, const NmIdx&
 // Issues the four row loads of every pair of the mapping and returns at once.  The loads are unconditional so
 // that nothing but the loads defines the registers: the wait for them then sits at their first use, a whole
 // phase of matrix products later, where nm_mask_rows() zeroes what was not a pair.
-__device__ __forceinline__ void nm_load_rows(const NmArgs& a, const int64_t (&ou)[4], const int64_t (&oi)[4], int qc, float4 (&um)[4], float4 (&im)[4],
-                                             float4 (&ug)[4], float4 (&ig)[4]) {
+template <int KI>
+__device__ __forceinline__ void nm_load_rows(const NmArgs& a, const int64_t (&ou)[KI], const int64_t (&oi)[KI], int qc, float4 (&um)[KI], float4 (&im)[KI],
+                                             float4 (&ug)[KI], float4 (&ig)[KI]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KI; ++k) {
     um[k] = *reinterpret_cast<const float4*>(a.Um + ou[k] + qc);
     im[k] = *reinterpret_cast<const float4*>(a.Im + oi[k] + qc);
     ug[k] = *reinterpret_cast<const float4*>(a.Ug + ou[k] + qc);
@@ -147,10 +152,11 @@ __device__ __forceinline__ void nm_load_rows(const NmArgs& a, const int64_t (&ou
   }
 }
 
-__device__ __forceinline__ void nm_mask_rows(unsigned ok, float4 (&um)[4], float4 (&im)[4], float4 (&ug)[4], float4 (&ig)[4]) {
+template <int KI>
+__device__ __forceinline__ void nm_mask_rows(unsigned ok, float4 (&um)[KI], float4 (&im)[KI], float4 (&ug)[KI], float4 (&ig)[KI]) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < KI; ++k)
     if (!((ok >> k) & 1u)) { um[k] = z; im[k] = z; ug[k] = z; ig[k] = z; }
 }
 
@@ -159,23 +165,23 @@ __device__ __forceinline__ void nm_mask_rows(unsigned ok, float4 (&um)[4], float
 // operands of the next eight steps are read while the eight products of the current ones run: with one
 // wavefront per SIMD nothing else hides the LDS latency, and the scheduler left alone reads two operands,
 // waits, and multiplies twice.
-template <int STEPS, int SA, int SB>
+template <int STEPS, int SA, int SB, int BATCH = 8>
 __device__ __forceinline__ void nm_mm(f32x16& acc, const float* ap, const float* bp) {
-  float av[2][8], bv[2][8];
+  float av[2][BATCH], bv[2][BATCH];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; }
+  for (int j = 0; j < BATCH; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; }
 #pragma unroll
-  for (int b = 0; b < STEPS / 8; ++b) {
-    if (b + 1 < STEPS / 8) {
+  for (int b = 0; b < STEPS / BATCH; ++b) {
+    if (b + 1 < STEPS / BATCH) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        av[(b + 1) & 1][j] = ap[2 * (8 * (b + 1) + j) * SA];
-        bv[(b + 1) & 1][j] = bp[2 * (8 * (b + 1) + j) * SB];
+      for (int j = 0; j < BATCH; ++j) {
+        av[(b + 1) & 1][j] = ap[2 * (BATCH * (b + 1) + j) * SA];
+        bv[(b + 1) & 1][j] = bp[2 * (BATCH * (b + 1) + j) * SB];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc, 0, 0, 0);
+    for (int j = 0; j < BATCH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -206,9 +212,18 @@ __device__ __forceinline__ void nm_mm2(f32x16& acc1, f32x16& acc2, const float* 
   }
 }
 
-template <bool F64>
-__global__ void __launch_bounds__(RX_BLOCK)
+// WAVES = 4 or 8 wavefronts per workgroup (one workgroup per CU either way: the LDS map is the same).  With eight,
+// every SIMD holds two wavefronts, so the scalar phases (staging, logits, outputs) run on twice the lanes and one
+// wavefront's LDS waits hide behind the other's products; each wavefront then owns one 32 x 32 tile of dW1 and of dx
+// instead of two, and the h1 product is split over k (the two halves meet in LDS).
+template <bool F64, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 neumf_step_kernel(NmArgs a) {
+  constexpr int NT = 64 * WAVES;     // threads
+  constexpr int KI = 1024 / NT;      // pairs per thread in the row-chunk mapping
+  constexpr int QS = NT / 16;        // their stride
+  constexpr int TP = NT / 64;        // threads per pair in the logit phase
+  constexpr int PW = 64 / WAVES;     // pairs per wavefront in the dz1 phase
   extern __shared__ float lds[];
   float* X = lds + NM_OFF_X;       // tower input [pair][2 D]; its gradient once the products that read it are done
   float* H1 = lds + NM_OFF_H1;     // h1 [pair][D]; dz1 once the logit is known
@@ -220,7 +235,7 @@ neumf_step_kernel(NmArgs a) {
   float* DL = lds + NM_OFF_DL;
   float* ZD = lds + NM_OFF_ZD;     // tg . zg of the pair
   float* C0 = lds + NM_OFF_C0;
-  __shared__ double lsum_w[RX_BLOCK / 64];
+  __shared__ double lsum_w[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5, l31 = lane & 31;
@@ -228,18 +243,17 @@ neumf_step_kernel(NmArgs a) {
   const int N = a.N;
   const int S = NM_P / N;                       // whole samples per tile
   const int64_t tiles = (a.B + S - 1) / S;
-  const double inv_m = 1.0 / ((double)a.B * (double)N);
 
   // the first tile's rows are on their way while the weights are laid out
-  NmIdx ix;
-  float4 rum[4], rim[4], rug[4], rig[4];
+  NmIdx<KI> ix;
+  float4 rum[KI], rim[KI], rug[KI], rig[KI];
   nm_load_idx(a, blockIdx.x, tiles, S, N, qp, ix);
-  int64_t ou[4], oi[4];
+  int64_t ou[KI], oi[KI];
   bool bad = false;
   unsigned rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
   nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
 
-  for (int i = tid; i < 64 * 128; i += RX_BLOCK) W1T[(i & 127) * NM_LD + (i >> 7)] = a.W1[i];
+  for (int i = tid; i < 64 * 128; i += NT) W1T[(i & 127) * NM_LD + (i >> 7)] = a.W1[i];
   if (tid < 64) {
     float s = 0.f;
     for (int o = 0; o < 32; ++o) s += a.wf[32 + o] * a.W2[o * 64 + tid];
@@ -260,12 +274,15 @@ neumf_step_kernel(NmArgs a) {
   const uint32_t thr = drop ? (uint32_t)((double)a.p_drop * 4294967296.0) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.p_drop) : 1.f;
 
-  f32x16 dW1a[2];
+  f32x16 dW1a[WAVES == 4 ? 2 : 1];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { dW1a[0][r] = 0.f; dW1a[1][r] = 0.f; }
-  float va = 0.f, db1a = 0.f;       // column (tid % 64) of v and db1 over the pairs 16 wave .. 16 wave + 15 of every tile
+  for (int r = 0; r < 16; ++r) {
+    dW1a[0][r] = 0.f;
+    if (WAVES == 4) dW1a[WAVES == 4 ? 1 : 0][r] = 0.f;
+  }
+  float va = 0.f, db1a = 0.f;       // column (tid % 64) of v and db1 over the pairs PW wave .. PW wave + PW - 1 of every tile
   float vga[4] = {0.f, 0.f, 0.f, 0.f};   // columns qc .. qc + 3 of vg over this thread's pairs
-  float sdl = 0.f;                  // sum of dl over the pair tid / 4 of every tile (threads with tid % 4 == 0)
+  float sdl = 0.f;                  // sum of dl over the pair tid / TP of every tile (threads with tid % TP == 0)
   double lsum = 0.0;
   __syncthreads();
   const float t2c = T2[tid & 63];
@@ -288,8 +305,8 @@ neumf_step_kernel(NmArgs a) {
     // ---- 1. the fetched rows: tower input into LDS, tg . zg of every pair
     nm_mask_rows(rows_ok, rum, rim, rug, rig);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = qp + 16 * k;
+    for (int k = 0; k < KI; ++k) {
+      const int p = qp + QS * k;
       float* xr = X + p * NM_LDX + qc;
       xr[0] = rum[k].x; xr[1] = rum[k].y; xr[2] = rum[k].z; xr[3] = rum[k].w;
       xr[64] = rim[k].x; xr[65] = rim[k].y; xr[66] = rim[k].z; xr[67] = rim[k].w;
@@ -299,20 +316,33 @@ neumf_step_kernel(NmArgs a) {
     }
     __syncthreads();
     NM_STAMP(1);
-    // ---- 2. h1 = dropout(relu(x W1^T + b1)): wave -> 32 x 32 tile (rt, ct) of [64 pairs, 64 units]
+    // ---- 2. h1 = dropout(relu(x W1^T + b1)): wave -> 32 x 32 tile (rt, ct) of [64 pairs, 64 units]; with eight
+    //         wavefronts, half kh of the 128 inputs each: the upper halves leave their sums in h1's place
     {
-      const int rt = wave >> 1, ct = wave & 1;
+      const int w4 = wave & 3, kh = wave >> 2;
+      const int rt = w4 >> 1, ct = w4 & 1;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* ap = X + (rt * 32 + l31) * NM_LDX + hh;
       const float* bp = W1T + hh * NM_LD + ct * 32 + l31;
-      nm_mm<64, 1, NM_LD>(acc, ap, bp);
       const int col = ct * 32 + l31;
+      if (WAVES == 4) {
+        nm_mm<64, 1, NM_LD>(acc, ap, bp);
+      } else {
+        nm_mm<32, 1, NM_LD, 4>(acc, ap + kh * 64, bp + kh * 64 * NM_LD);
+        if (kh == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) H1[(rt * 32 + NM_ROW(r, hh)) * NM_LD + col] = acc[r];
+        }
+        __syncthreads();
+      }
       const float bv = B1[col];
+      if (WAVES == 4 || kh == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rt * 32 + NM_ROW(r, hh);
+        if (WAVES == 8) acc[r] += H1[row * NM_LD + col];
         float v = acc[r] + bv;
         v = v > 0.f ? v : 0.f;
         if (drop) {
@@ -321,23 +351,26 @@ neumf_step_kernel(NmArgs a) {
         }
         H1[row * NM_LD + col] = row < PT ? v : 0.f;
       }
+      }
     }
     __syncthreads();
     NM_STAMP(2);
-    // ---- 3. logit = c0 + tg . zg + t2 . h1 (four threads per pair), BCE term (fp64), dL/dlogit
+    // ---- 3. logit = c0 + tg . zg + t2 . h1 (TP threads per pair), BCE term (fp64), dL/dlogit
     // The next tile's row offsets are taken here, pinned in registers: the indices arrived two phases ago, and
     // a wait placed behind the label loads and gradient stores below would wait for those as well.
     rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(ou[k]), "+v"(oi[k]));
+    for (int k = 0; k < KI; ++k) asm volatile("" : "+v"(ou[k]), "+v"(oi[k]));
     {
-      const int p = tid >> 2, part = (tid & 3) * 16;
+      int p = tid / TP;
+      asm volatile("" : "+v"(p));     // (addresses off p are formed here, per tile: kept across the loop they cost registers all the way)
+      const int part = (tid % TP) * (64 / TP);
       const float* hp = H1 + p * NM_LD + part;
       float x = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) x += hp[j] * T2[part + j];
-      x = rx_group_sum(x, 4);
-      if ((tid & 3) == 0) {
+      for (int j = 0; j < 64 / TP; ++j) x += hp[j] * T2[part + j];
+      x = rx_group_sum(x, TP);
+      if (tid % TP == 0) {
         float dl = 0.f;
         if (p < PT) {
           x += c0 + ZD[p];
@@ -347,7 +380,7 @@ neumf_step_kernel(NmArgs a) {
           const double e = exp(-fabs(xd));
           lsum += fmax(xd, 0.0) - xd * y + log1p(e);
           const double sig = xd >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
-          dl = (float)((sig - y) * inv_m);
+          dl = (float)((sig - y) * a.inv_m);
         }
         DL[p] = dl;
         sdl += dl;
@@ -360,7 +393,7 @@ neumf_step_kernel(NmArgs a) {
     {
       const int c = tid & 63;
 #pragma unroll
-      for (int p = wave * 16; p < wave * 16 + 16; ++p) {
+      for (int p = wave * PW; p < wave * PW + PW; ++p) {
         const float h = H1[p * NM_LD + c], dl = DL[p];
         va += dl * h;
         const float dz = h > 0.f ? (dl * t2c) * inv_keep : 0.f;
@@ -369,8 +402,8 @@ neumf_step_kernel(NmArgs a) {
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = qp + 16 * k;
+    for (int k = 0; k < KI; ++k) {
+      const int p = qp + QS * k;
       const float dl = DL[p];
       vga[0] += dl * (rug[k].x * rig[k].x); vga[1] += dl * (rug[k].y * rig[k].y);
       vga[2] += dl * (rug[k].z * rig[k].z); vga[3] += dl * (rug[k].w * rig[k].w);
@@ -383,13 +416,24 @@ neumf_step_kernel(NmArgs a) {
     nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
     __syncthreads();
     NM_STAMP(4);
-    // ---- 5. dW1 += dz1^T x (two tiles per wave); dx = dz1 W1 (two tiles per wave)
-    {
+    // ---- 5. dW1 += dz1^T x; dx = dz1 W1 (two 32 x 32 tiles of each per wave with four wavefronts, one with eight)
+    if (WAVES == 8) {
+      f32x16 acc1;
+      const int ht = wave & 1, cq = wave >> 1;
+      nm_mm<NM_P / 2, NM_LD, NM_LDX, 4>(dW1a[0], H1 + hh * NM_LD + ht * 32 + l31, X + hh * NM_LDX + cq * 32 + l31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      nm_mm<32, 1, 1, 4>(acc1, H1 + (ht * 32 + l31) * NM_LD + hh, W1T + (cq * 32 + l31) * NM_LD + hh);
+      NM_STAMP(5);
+      __syncthreads();    // every read of x is done: it now takes dx
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[(ht * 32 + NM_ROW(r, hh)) * NM_LDX + cq * 32 + l31] = acc1[r];
+    } else {
       f32x16 acc1, acc2;
       const int ht = wave & 1, cp = wave >> 1;
       const float* ap = H1 + hh * NM_LD + ht * 32 + l31;                 // A[i = unit][k = pair]
       const float* bp = X + hh * NM_LDX + cp * 64 + l31;                 // B[k = pair][j = input]
-      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[1], ap, bp);
+      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[WAVES == 4 ? 1 : 0], ap, bp);
       const int rt = wave & 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
@@ -409,14 +453,14 @@ neumf_step_kernel(NmArgs a) {
     NM_STAMP(6);
     // ---- 6. embedding gradients out: item MLP rows per pair, user rows summed over the sample's pairs in pair order
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = qp + 16 * k;
+    for (int k = 0; k < KI; ++k) {
+      const int p = qp + QS * k;
       if (p < PT) {
         const float* xr = X + p * NM_LDX + 64 + qc;
         *reinterpret_cast<float4*>(a.di_m + (p0 + p) * NM_D + qc) = make_float4(xr[0], xr[1], xr[2], xr[3]);
       }
     }
-    for (int q = tid; q < ns * 16; q += RX_BLOCK) {
+    for (int q = tid; q < ns * 16; q += NT) {
       const int s = q >> 4, c = (q & 15) * 4;
       float4 m = make_float4(0.f, 0.f, 0.f, 0.f), g = m;
       for (int n = 0; n < N; ++n) {
@@ -441,36 +485,48 @@ neumf_step_kernel(NmArgs a) {
   if (bad && a.err_flag) atomicOr(a.err_flag, RX_ERR_INDEX);
   // ---- this workgroup's partial: [dW1 | db1 | v | vg | sum dl]; the thread-level pieces meet in LDS, fixed order
   float* wp = a.raw + (size_t)blockIdx.x * NM_RAW;
-  {
+  if (WAVES == 8) {
+    const int ht = wave & 1, cq = wave >> 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wp[(ht * 32 + NM_ROW(r, hh)) * 128 + cq * 32 + l31] = dW1a[0][r];
+  } else {
     const int ht = wave & 1, cp = wave >> 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int h = ht * 32 + NM_ROW(r, hh);
       wp[h * 128 + cp * 64 + l31] = dW1a[0][r];
-      wp[h * 128 + cp * 64 + 32 + l31] = dW1a[1][r];
+      wp[h * 128 + cp * 64 + 32 + l31] = dW1a[WAVES == 4 ? 1 : 0][r];
     }
   }
-  float* red = X;
+  float* red = X;        // [db1: WAVES x 64 | v: WAVES x 64 at 512 | vg: QS x 64 at 1024 | sum dl: 64 at 3072]
   red[wave * 64 + lane] = db1a;
-  red[256 + wave * 64 + lane] = va;
+  red[512 + wave * 64 + lane] = va;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[512 + qp * 64 + qc + e] = vga[e];
-  if ((tid & 3) == 0) red[1536 + (tid >> 2)] = sdl;
+  for (int e = 0; e < 4; ++e) red[1024 + qp * 64 + qc + e] = vga[e];
+  if (tid % TP == 0) red[3072 + tid / TP] = sdl;
   lsum = rx_wave_sum_f64(lsum);
   if (lane == 0) lsum_w[wave] = lsum;
   __syncthreads();
   if (tid < 64) {
-    wp[64 * 128 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
-    wp[NM_RAW_V + tid] = (red[256 + tid] + red[320 + tid]) + (red[384 + tid] + red[448 + tid]);
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int g = 0; g < WAVES; ++g) { s += red[g * 64 + tid]; t += red[512 + g * 64 + tid]; }
+    wp[64 * 128 + tid] = s;
+    wp[NM_RAW_V + tid] = t;
   } else if (tid < 128) {
     float s = 0.f;
-    for (int g = 0; g < 16; ++g) s += red[512 + g * 64 + (tid - 64)];
+    for (int g = 0; g < QS; ++g) s += red[1024 + g * 64 + (tid - 64)];
     wp[NM_RAW_VG + (tid - 64)] = s;
   } else if (tid < 192) {
-    const float s = rx_wave_sum(red[1536 + (tid - 128)]);
+    const float s = rx_wave_sum(red[3072 + (tid - 128)]);
     if (tid == 128) wp[NM_RAW_SDL] = s;
   }
-  if (tid == 0) a.loss_part[blockIdx.x] = (lsum_w[0] + lsum_w[1]) + (lsum_w[2] + lsum_w[3]);
+  if (tid == 0) {
+    double l = 0.0;
+#pragma unroll
+    for (int g = 0; g < WAVES; ++g) l += lsum_w[g];
+    a.loss_part[blockIdx.x] = l;
+  }
 }
 
 // Adds the workgroups' partials in a fixed order (bitwise reproducible), expands v, vg and sum(dl) into the
@@ -614,20 +670,30 @@ extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, 
   a.B = r->B; a.N = r->N;
   a.W1 = r->w1; a.b1 = r->b1; a.W2 = r->w2; a.b2 = r->b2; a.Wg = r->wg; a.bg = r->bg; a.wf = r->wf; a.bf = r->bf;
   a.p_drop = r->p_drop; a.seed = r->seed;
+  a.inv_m = 1.0 / ((double)r->B * (double)r->N);
   a.du_g = r->du_gmf; a.du_m = r->du_mlp; a.di_g = r->di_gmf; a.di_m = r->di_mlp;
   a.raw = (float*)ws;
   a.loss_part = (double*)((char*)ws + rx_align_up((size_t)grid * NM_RAW * sizeof(float), 256));
   a.logits = r->logits; a.err_flag = err_flag;
   const size_t lds = NM_LDS_FLOATS * sizeof(float);
+  // RX_NEUMF_WAVES=4 runs the step with four wavefronts per workgroup instead of eight (A/B timing)
+  static const bool four = [] { const char* e = getenv("RX_NEUMF_WAVES"); return e && e[0] == '4'; }();
   static bool attr_set[64] = {};
   if (device >= 64 || !attr_set[device]) {   // LDS beyond 64 KiB per workgroup has to be asked for, per device
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (device < 64) attr_set[device] = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (r->labels_f64) hipLaunchKernelGGL(neumf_step_kernel<true>, dim3(grid), dim3(RX_BLOCK), lds, st, a);
-  else hipLaunchKernelGGL(neumf_step_kernel<false>, dim3(grid), dim3(RX_BLOCK), lds, st, a);
+  if (four) {
+    if (r->labels_f64) hipLaunchKernelGGL((neumf_step_kernel<true, 4>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((neumf_step_kernel<false, 4>), dim3(grid), dim3(256), lds, st, a);
+  } else {
+    if (r->labels_f64) hipLaunchKernelGGL((neumf_step_kernel<true, 8>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((neumf_step_kernel<false, 8>), dim3(grid), dim3(512), lds, st, a);
+  }
   RX_LAUNCH_CHECK();
   NmFin f{};
   f.raw = a.raw; f.n_parts = grid; f.wgrad = r->wgrad;

@@ -347,8 +347,24 @@ def test_neumf_one_launch_step_matches_the_per_layer_path(B, N, monkeypatch):
         res.append((loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
     (la, ga), (lb, gb) = res
     assert_close(lb, la, rtol=1e-6, what="loss")
+    # A first-layer unit whose pre-activation is zero to fp32 rounding passes its gradient under one summation
+    # order and not under another (ReLU's gate is h > 0 in both paths): where fp64 puts |z| below 1e-6 the rows
+    # that unit feeds -- the pair's two tower rows, the unit's row of W1 and its bias -- are left out.
+    with torch.no_grad():
+        u = batch["user_code"][:, None].expand(B, N).reshape(-1)
+        it = batch["item_code"].reshape(-1)
+        x = torch.cat([m.user_embedding_mlp.weight[u], m.item_embedding_mlp.weight[it]], 1).double()
+        z = x @ m.linear_mlp[0].weight.double().t() + m.linear_mlp[0].bias.double()
+        near = (z.abs() < 1e-6).nonzero().cpu()
+    assert len(near) <= 32
+    skip = {"user_embedding_mlp.weight": u[near[:, 0]].cpu(), "item_embedding_mlp.weight": it[near[:, 0]].cpu(),
+            "linear_mlp.0.weight": near[:, 1], "linear_mlp.0.bias": near[:, 1]}
     for k in ga:
-        assert_close(gb[k].cpu().numpy(), ga[k].cpu().numpy(), what=f"grad {k}", atol=1e-9)
+        a, e = gb[k].cpu().clone(), ga[k].cpu().clone()
+        if k in skip and len(near):
+            a[skip[k]] = 0
+            e[skip[k]] = 0
+        assert_close(a.numpy(), e.numpy(), what=f"grad {k}", atol=1e-9)
 
 
 def test_neumf_one_launch_step_dropout_stream():
