@@ -29,7 +29,7 @@
 //                          kernel, which also expands v, vg, sum(dl) into the gradients of W2, b2, Wg, bg, wf, bf
 //   loss partials          fp64, one per workgroup
 // The embedding gradients then take the usual deterministic path (sort + segmented reduce, fused row update).
-// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 101 KB of LDS per workgroup.
+// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 153 KB of LDS per workgroup.
 //
 // LDS operands are read in the two patterns an MFMA lane needs -- (index = lane % 32, k = lane / 32) and
 // (k = lane / 32, index = lane % 32) -- from the same arrays; every array has an ODD row pitch, so both
@@ -37,11 +37,13 @@
 #include "rx_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define NM_D 64
 #define NM_P 64       // pair rows of a tile (two MFMA row tiles)
 #define NM_LDX 129    // pitch of the tower input / its gradient [pair][2 D]
 #define NM_LD 65      // pitch of the 64-wide arrays
+#define NM_LG 72      // pitch (bf16 elements) of the two gate arrays: 16-byte reads of 32 consecutive rows touch every bank once
 #define NM_WP (64 * 128 + 64 + 32 * 64 + 32 + 32 * 64 + 32 + 64 + 1)   // floats of the weight gradient [W1|b1|W2|b2|Wg|bg|wf|bf]
 #define NM_RAW (64 * 128 + 64 + 64 + 64 + 1)                            // floats of one workgroup's partial [dW1|db1|v|vg|sum dl]
 #define NM_RAW_V (64 * 128 + 64)
@@ -60,7 +62,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NM_OFF_DL (NM_OFF_TG + 64)
 #define NM_OFF_ZD (NM_OFF_DL + 64)
 #define NM_OFF_C0 (NM_OFF_ZD + 64)
-#define NM_LDS_FLOATS (NM_OFF_C0 + 4)
+#define NM_OFF_G (NM_OFF_C0 + 4)                 // gate of the first layer [pair][unit], bf16 1.0 / 0.0
+#define NM_OFF_GT (NM_OFF_G + 64 * NM_LG / 2)    // the same, [unit][pair]
+#define NM_OFF_WH (NM_OFF_GT + 64 * NM_LG / 2)   // t2 / keep . W1 as [input][unit], bf16: the top 8 significant bits
+#define NM_OFF_WM (NM_OFF_WH + 128 * NM_LG / 2)  // the next 8 (the last 8 stay in registers)
+#define NM_LDS_FLOATS (NM_OFF_WM + 128 * NM_LG / 2)
 
 struct NmArgs {
   const float *Ug, *Ig, *Um, *Im;
@@ -216,6 +222,42 @@ __device__ __forceinline__ void nm_mm2(f32x16& acc1, f32x16& acc2, const float* 
 // every SIMD holds two wavefronts, so the scalar phases (staging, logits, outputs) run on twice the lanes and one
 // wavefront's LDS waits hide behind the other's products; each wavefront then owns one 32 x 32 tile of dW1 and of dx
 // instead of two, and the h1 product is split over k (the two halves meet in LDS).
+// BCE-with-logits term of one pair and sigmoid(x), fp64.  Kept out of line: inlined into the tile loop, the two
+// dozen fp64 coefficients of exp and log1p are held in registers across the whole loop (about fifty of them).
+struct NmBce { double term, sig; };
+__device__ __noinline__ NmBce nm_bce_term(double xd, double y) {
+  const double e = exp(-fabs(xd));
+  NmBce r;
+  r.sig = xd >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+  r.term = fmax(xd, 0.0) - xd * y + log1p(e);
+  return r;
+}
+
+// Eight fp32 values as three bf16 planes whose sum is the value, exactly: the top 8 significant bits, the next 8,
+// the last 8 (each piece is cut, not rounded, so the remainders are exact and the third needs no cut).  A product
+// with a 0 / 1 operand on v_mfma_f32_32x32x16_bf16 then accumulates exactly the fp32 terms, at an eighth of the
+// passes of v_mfma_f32_32x32x2_f32.
+__device__ __forceinline__ void nm_split8(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    h[k] = __float_as_uint(v[k]);
+    const float r = v[k] - __uint_as_float(h[k] & 0xffff0000u);
+    m[k] = __float_as_uint(r);
+    l[k] = __float_as_uint(r - __uint_as_float(m[k] & 0xffff0000u));
+  }
+  uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {     // element 2 j in the low half of the word: the upper halves of two floats, one byte permute
+    ph[j] = __builtin_amdgcn_perm(h[2 * j + 1], h[2 * j], 0x07060302u);
+    pm[j] = __builtin_amdgcn_perm(m[2 * j + 1], m[2 * j], 0x07060302u);
+    pl[j] = __builtin_amdgcn_perm(l[2 * j + 1], l[2 * j], 0x07060302u);
+  }
+  hi = *reinterpret_cast<bf16x8*>(ph);
+  mid = *reinterpret_cast<bf16x8*>(pm);
+  lo = *reinterpret_cast<bf16x8*>(pl);
+}
+
 template <bool F64, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 neumf_step_kernel(NmArgs a) {
@@ -235,6 +277,10 @@ neumf_step_kernel(NmArgs a) {
   float* DL = lds + NM_OFF_DL;
   float* ZD = lds + NM_OFF_ZD;     // tg . zg of the pair
   float* C0 = lds + NM_OFF_C0;
+  uint16_t* G16 = reinterpret_cast<uint16_t*>(lds + NM_OFF_G);
+  uint16_t* GT16 = reinterpret_cast<uint16_t*>(lds + NM_OFF_GT);
+  uint16_t* WH16 = reinterpret_cast<uint16_t*>(lds + NM_OFF_WH);
+  uint16_t* WM16 = reinterpret_cast<uint16_t*>(lds + NM_OFF_WM);
   __shared__ double lsum_w[WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,12 +320,12 @@ neumf_step_kernel(NmArgs a) {
   const uint32_t thr = drop ? (uint32_t)((double)a.p_drop * 4294967296.0) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.p_drop) : 1.f;
 
-  f32x16 dW1a[WAVES == 4 ? 2 : 1];
+  // dW1 accumulators.  Four wavefronts: tiles (unit half wave % 2, input quarters 2 (wave / 2), + 1) of dz1^T x.
+  // Eight: both unit halves of input quarter wave % 4 over the pairs 32 (wave / 4) .. + 31 of every tile, of
+  // gate^T (dl x); the two pair halves meet, and t2[unit] / keep comes in, when the partial is written.
+  f32x16 dW1a[2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dW1a[0][r] = 0.f;
-    if (WAVES == 4) dW1a[WAVES == 4 ? 1 : 0][r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) { dW1a[0][r] = 0.f; dW1a[1][r] = 0.f; }
   float va = 0.f, db1a = 0.f;       // column (tid % 64) of v and db1 over the pairs PW wave .. PW wave + PW - 1 of every tile
   float vga[4] = {0.f, 0.f, 0.f, 0.f};   // columns qc .. qc + 3 of vg over this thread's pairs
   float sdl = 0.f;                  // sum of dl over the pair tid / TP of every tile (threads with tid % TP == 0)
@@ -288,6 +334,28 @@ neumf_step_kernel(NmArgs a) {
   const float t2c = T2[tid & 63];
   const float4 tg4 = make_float4(TG[qc], TG[qc + 1], TG[qc + 2], TG[qc + 3]);
   const float c0 = C0[0];
+  // eight wavefronts: the B operand of dx = dl (gate (t2 / keep . W1)) is the same for every tile -- three bf16
+  // planes of 64 units x 32 inputs per wavefront (pair half wave % 2, input quarter wave / 2): the first two in
+  // LDS (written by the wavefronts of pair half 0), the third in registers
+  bf16x8 wlo[WAVES == 8 ? 4 : 1];
+  if constexpr (WAVES == 8) {
+    const int j = (wave >> 1) * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float w[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int u = 16 * ks + 8 * hh + kk;
+        w[kk] = (T2[u] * inv_keep) * W1T[j * NM_LD + u];
+      }
+      bf16x8 whi, wmid;
+      nm_split8(w, whi, wmid, wlo[ks]);
+      if ((wave & 1) == 0) {
+        *reinterpret_cast<bf16x8*>(WH16 + j * NM_LG + 16 * ks + 8 * hh) = whi;
+        *reinterpret_cast<bf16x8*>(WM16 + j * NM_LG + 16 * ks + 8 * hh) = wmid;
+      }
+    }
+  }
 
 #ifdef NM_PHASE_TIMES
   long long stamp[9] = {};
@@ -339,6 +407,7 @@ neumf_step_kernel(NmArgs a) {
       }
       const float bv = B1[col];
       if (WAVES == 4 || kh == 0) {
+      uint16_t gate[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rt * 32 + NM_ROW(r, hh);
@@ -346,10 +415,23 @@ neumf_step_kernel(NmArgs a) {
         float v = acc[r] + bv;
         v = v > 0.f ? v : 0.f;
         if (drop) {
-          const uint32_t draw = (uint32_t)(nm_mix(seed, (uint64_t)(p0 + row) * 64ull + (uint64_t)col) >> 32);
+          int rowv = row;
+          asm volatile("" : "+v"(rowv));    // (formed here: sixteen 64-bit counters kept across the tile loop would cost 32 registers)
+          const uint32_t draw = (uint32_t)(nm_mix(seed, (uint64_t)(p0 + rowv) * 64ull + (uint64_t)col) >> 32);
           v = draw >= thr ? v * inv_keep : 0.f;
         }
-        H1[row * NM_LD + col] = row < PT ? v : 0.f;
+        v = row < PT ? v : 0.f;
+        H1[row * NM_LD + col] = v;
+        if constexpr (WAVES == 8) {
+          gate[r] = v > 0.f ? (uint16_t)0x3F80 : (uint16_t)0;
+          G16[row * NM_LG + col] = gate[r];
+        }
+      }
+      if constexpr (WAVES == 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)     // rows 8 q + 4 hh .. + 3 of the tile sit in registers 4 q .. 4 q + 3
+          *reinterpret_cast<uint2*>(GT16 + col * NM_LG + rt * 32 + 8 * q + 4 * hh) =
+              make_uint2((uint32_t)gate[4 * q] | ((uint32_t)gate[4 * q + 1] << 16), (uint32_t)gate[4 * q + 2] | ((uint32_t)gate[4 * q + 3] << 16));
       }
       }
     }
@@ -377,10 +459,9 @@ neumf_step_kernel(NmArgs a) {
           if (a.logits) a.logits[p0 + p] = x;
           const double xd = (double)x;
           const double y = F64 ? reinterpret_cast<const double*>(a.labels)[p0 + p] : (double)reinterpret_cast<const float*>(a.labels)[p0 + p];
-          const double e = exp(-fabs(xd));
-          lsum += fmax(xd, 0.0) - xd * y + log1p(e);
-          const double sig = xd >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
-          dl = (float)((sig - y) * a.inv_m);
+          const NmBce t = nm_bce_term(xd, y);
+          lsum += t.term;
+          dl = (float)((t.sig - y) * a.inv_m);
         }
         DL[p] = dl;
         sdl += dl;
@@ -396,9 +477,13 @@ neumf_step_kernel(NmArgs a) {
       for (int p = wave * PW; p < wave * PW + PW; ++p) {
         const float h = H1[p * NM_LD + c], dl = DL[p];
         va += dl * h;
-        const float dz = h > 0.f ? (dl * t2c) * inv_keep : 0.f;
-        db1a += dz;
-        H1[p * NM_LD + c] = dz;
+        if constexpr (WAVES == 8) {
+          db1a += h > 0.f ? dl : 0.f;      // (t2 / keep comes in at the end)
+        } else {
+          const float dz = h > 0.f ? (dl * t2c) * inv_keep : 0.f;
+          db1a += dz;
+          H1[p * NM_LD + c] = dz;
+        }
       }
     }
 #pragma unroll
@@ -417,23 +502,54 @@ neumf_step_kernel(NmArgs a) {
     __syncthreads();
     NM_STAMP(4);
     // ---- 5. dW1 += dz1^T x; dx = dz1 W1 (two 32 x 32 tiles of each per wave with four wavefronts, one with eight)
-    if (WAVES == 8) {
+    if constexpr (WAVES == 8) {
+      // The gate is 0 / 1, so dz1 = gate (dl t2 / keep) factors: dW1 = (t2 / keep) . gate^T (dl x) and
+      // dx = dl . gate (t2 / keep . W1), with the fp32 factor cut into three bf16 planes (nm_split8).
+      {
+        const int cq = wave & 3, kh = wave >> 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int k0 = kh * 32 + ks * 16 + 8 * hh;       // this lane's eight pairs
+          float xv[8];
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) xv[kk] = X[(k0 + kk) * NM_LDX + cq * 32 + l31] * DL[k0 + kk];
+          bf16x8 bh, bm, bl;
+          nm_split8(xv, bh, bm, bl);
+#pragma unroll
+          for (int ht = 0; ht < 2; ++ht) {
+            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(GT16 + (ht * 32 + l31) * NM_LG + k0);
+            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bh, dW1a[ht], 0, 0, 0);
+            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bm, dW1a[ht], 0, 0, 0);
+            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bl, dW1a[ht], 0, 0, 0);
+          }
+        }
+      }
       f32x16 acc1;
-      const int ht = wave & 1, cq = wave >> 1;
-      nm_mm<NM_P / 2, NM_LD, NM_LDX, 4>(dW1a[0], H1 + hh * NM_LD + ht * 32 + l31, X + hh * NM_LDX + cq * 32 + l31);
+      const int rt = wave & 1, cq = wave >> 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-      nm_mm<32, 1, 1, 4>(acc1, H1 + (ht * 32 + l31) * NM_LD + hh, W1T + (cq * 32 + l31) * NM_LD + hh);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 ga = *reinterpret_cast<const bf16x8*>(G16 + (rt * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(WH16 + (cq * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
+        const bf16x8 wm = *reinterpret_cast<const bf16x8*>(WM16 + (cq * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wh, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wm, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wlo[ks], acc1, 0, 0, 0);
+      }
       NM_STAMP(5);
       __syncthreads();    // every read of x is done: it now takes dx
 #pragma unroll
-      for (int r = 0; r < 16; ++r) X[(ht * 32 + NM_ROW(r, hh)) * NM_LDX + cq * 32 + l31] = acc1[r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * 32 + NM_ROW(r, hh);
+        X[row * NM_LDX + cq * 32 + l31] = acc1[r] * DL[row];
+      }
     } else {
       f32x16 acc1, acc2;
       const int ht = wave & 1, cp = wave >> 1;
       const float* ap = H1 + hh * NM_LD + ht * 32 + l31;                 // A[i = unit][k = pair]
       const float* bp = X + hh * NM_LDX + cp * 64 + l31;                 // B[k = pair][j = input]
-      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[WAVES == 4 ? 1 : 0], ap, bp);
+      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[1], ap, bp);
       const int rt = wave & 1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
@@ -485,17 +601,35 @@ neumf_step_kernel(NmArgs a) {
   if (bad && a.err_flag) atomicOr(a.err_flag, RX_ERR_INDEX);
   // ---- this workgroup's partial: [dW1 | db1 | v | vg | sum dl]; the thread-level pieces meet in LDS, fixed order
   float* wp = a.raw + (size_t)blockIdx.x * NM_RAW;
-  if (WAVES == 8) {
-    const int ht = wave & 1, cq = wave >> 1;
+  if constexpr (WAVES == 8) {
+    // the two pair halves of gate^T (dl x) meet in LDS (x is done with); the unit's t2 / keep comes in here
+    const int cq = wave & 3, kh = wave >> 2;
+    float* half = X + cq * 2048;
+    if (kh == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wp[(ht * 32 + NM_ROW(r, hh)) * 128 + cq * 32 + l31] = dW1a[0][r];
+      for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) half[(ht * 16 + r) * 64 + lane] = dW1a[ht][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int u = ht * 32 + NM_ROW(r, hh);
+          wp[u * 128 + cq * 32 + l31] = (dW1a[ht][r] + half[(ht * 16 + r) * 64 + lane]) * (T2[u] * inv_keep);
+        }
+    }
+    __syncthreads();
+    db1a *= t2c * inv_keep;
   } else {
     const int ht = wave & 1, cp = wave >> 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int h = ht * 32 + NM_ROW(r, hh);
       wp[h * 128 + cp * 64 + l31] = dW1a[0][r];
-      wp[h * 128 + cp * 64 + 32 + l31] = dW1a[WAVES == 4 ? 1 : 0][r];
+      wp[h * 128 + cp * 64 + 32 + l31] = dW1a[1][r];
     }
   }
   float* red = X;        // [db1: WAVES x 64 | v: WAVES x 64 at 512 | vg: QS x 64 at 1024 | sum dl: 64 at 3072]
