@@ -36,6 +36,8 @@
 // patterns spread a wavefront's reads over all banks and W1 is kept once (as [in][out]).
 #include "rx_common.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -43,7 +45,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define NM_P 64       // pair rows of a tile (two MFMA row tiles)
 #define NM_LDX 129    // pitch of the tower input / its gradient [pair][2 D]
 #define NM_LD 65      // pitch of the 64-wide arrays
-#define NM_LG 72      // pitch (bf16 elements) of the two gate arrays: 16-byte reads of 32 consecutive rows touch every bank once
+#define NM_LG 72      // pitch (bf16 elements) of the 64-wide bf16 arrays: 16-byte reads of 32 consecutive rows touch every bank once
+#define NM_LW 136     // pitch (bf16 elements) of the planes of W1 [unit][input]: likewise
 #define NM_WP (64 * 128 + 64 + 32 * 64 + 32 + 32 * 64 + 32 + 64 + 1)   // floats of the weight gradient [W1|b1|W2|b2|Wg|bg|wf|bf]
 #define NM_RAW (64 * 128 + 64 + 64 + 64 + 1)                            // floats of one workgroup's partial [dW1|db1|v|vg|sum dl]
 #define NM_RAW_V (64 * 128 + 64)
@@ -52,11 +55,11 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define NM_MAX_GRID 256
 
 // LDS map (floats)
+#define NM_THREADS 512
 #define NM_OFF_X 0
 #define NM_OFF_H1 (NM_OFF_X + NM_P * NM_LDX)
-#define NM_OFF_GU (NM_OFF_H1 + NM_P * NM_LD)
-#define NM_OFF_W1T (NM_OFF_GU + NM_P * NM_LD)
-#define NM_OFF_B1 (NM_OFF_W1T + 128 * NM_LD)
+#define NM_OFF_W1P (NM_OFF_H1 + NM_P * NM_LD)              // W1 [unit][input] as three bf16 planes
+#define NM_OFF_B1 (NM_OFF_W1P + 3 * 64 * NM_LW / 2)
 #define NM_OFF_T2 (NM_OFF_B1 + 64)
 #define NM_OFF_TG (NM_OFF_T2 + 64)
 #define NM_OFF_DL (NM_OFF_TG + 64)
@@ -67,6 +70,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define NM_OFF_WH (NM_OFF_GT + 64 * NM_LG / 2)   // t2 / keep . W1 as [input][unit], bf16: the top 8 significant bits
 #define NM_OFF_WM (NM_OFF_WH + 128 * NM_LG / 2)  // the next 8 (the last 8 stay in registers)
 #define NM_LDS_FLOATS (NM_OFF_WM + 128 * NM_LG / 2)
+static_assert(NM_OFF_H1 % 4 == 0 && NM_OFF_W1P % 4 == 0 && NM_OFF_G % 4 == 0 && NM_OFF_GT % 4 == 0 && NM_OFF_WH % 4 == 0 && NM_OFF_WM % 4 == 0,
+              "16-byte reads of the bf16 arrays");
+static_assert(NM_LDS_FLOATS * 4 <= 160 * 1024, "LDS of one CU");
 
 struct NmArgs {
   const float *Ug, *Ig, *Um, *Im;
@@ -166,62 +172,6 @@ __device__ __forceinline__ void nm_mask_rows(unsigned ok, float4 (&um)[KI], floa
     if (!((ok >> k) & 1u)) { um[k] = z; im[k] = z; ug[k] = z; ig[k] = z; }
 }
 
-// acc += A B over k = 0 .. 2 STEPS - 1 on v_mfma_f32_32x32x2_f32, operands in LDS: this lane's A element of step t
-// at ap[2 t SA], its B element at bp[2 t SB] (both pointers already at the lane's index and k half).  The
-// operands of the next eight steps are read while the eight products of the current ones run: with one
-// wavefront per SIMD nothing else hides the LDS latency, and the scheduler left alone reads two operands,
-// waits, and multiplies twice.
-template <int STEPS, int SA, int SB, int BATCH = 8>
-__device__ __forceinline__ void nm_mm(f32x16& acc, const float* ap, const float* bp) {
-  float av[2][BATCH], bv[2][BATCH];
-#pragma unroll
-  for (int j = 0; j < BATCH; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; }
-#pragma unroll
-  for (int b = 0; b < STEPS / BATCH; ++b) {
-    if (b + 1 < STEPS / BATCH) {
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        av[(b + 1) & 1][j] = ap[2 * (BATCH * (b + 1) + j) * SA];
-        bv[(b + 1) & 1][j] = bp[2 * (BATCH * (b + 1) + j) * SB];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < BATCH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// two products with one A operand: acc1 += A B, acc2 += A B' with B' = B + BOFF floats
-template <int STEPS, int SA, int SB, int BOFF>
-__device__ __forceinline__ void nm_mm2(f32x16& acc1, f32x16& acc2, const float* ap, const float* bp) {
-  float av[2][4], bv[2][4], cv[2][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { av[0][j] = ap[2 * j * SA]; bv[0][j] = bp[2 * j * SB]; cv[0][j] = bp[2 * j * SB + BOFF]; }
-#pragma unroll
-  for (int b = 0; b < STEPS / 4; ++b) {
-    if (b + 1 < STEPS / 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        av[(b + 1) & 1][j] = ap[2 * (4 * (b + 1) + j) * SA];
-        bv[(b + 1) & 1][j] = bp[2 * (4 * (b + 1) + j) * SB];
-        cv[(b + 1) & 1][j] = bp[2 * (4 * (b + 1) + j) * SB + BOFF];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], bv[b & 1][j], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], cv[b & 1][j], acc2, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// WAVES = 4 or 8 wavefronts per workgroup (one workgroup per CU either way: the LDS map is the same).  With eight,
-// every SIMD holds two wavefronts, so the scalar phases (staging, logits, outputs) run on twice the lanes and one
-// wavefront's LDS waits hide behind the other's products; each wavefront then owns one 32 x 32 tile of dW1 and of dx
-// instead of two, and the h1 product is split over k (the two halves meet in LDS).
 // BCE-with-logits term of one pair and sigmoid(x), fp64.  Kept out of line: inlined into the tile loop, the two
 // dozen fp64 coefficients of exp and log1p are held in registers across the whole loop (about fifty of them).
 struct NmBce { double term, sig; };
@@ -234,9 +184,7 @@ __device__ __noinline__ NmBce nm_bce_term(double xd, double y) {
 }
 
 // Eight fp32 values as three bf16 planes whose sum is the value, exactly: the top 8 significant bits, the next 8,
-// the last 8 (each piece is cut, not rounded, so the remainders are exact and the third needs no cut).  A product
-// with a 0 / 1 operand on v_mfma_f32_32x32x16_bf16 then accumulates exactly the fp32 terms, at an eighth of the
-// passes of v_mfma_f32_32x32x2_f32.
+// the last 8 (each piece is cut, not rounded, so the remainders are exact and the third needs no cut).
 __device__ __forceinline__ void nm_split8(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
   uint32_t h[8], m[8], l[8];
 #pragma unroll
@@ -258,19 +206,44 @@ __device__ __forceinline__ void nm_split8(const float (&v)[8], bf16x8& hi, bf16x
   lo = *reinterpret_cast<bf16x8*>(pl);
 }
 
-template <bool F64, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES)
+// Sum over aligned groups of 8 / 16 lanes, every lane of the group getting it, on the data-parallel-primitive
+// path of the vector unit (lane exchanges inside a row of 16: no LDS crossbar round trip per step).  After the two
+// quad steps the four lanes of a quad hold one value, so the mirrors stand in for the exchanges at distance 4 / 8.
+template <int CTRL>
+__device__ __forceinline__ float nm_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float nm_sum8(float v) {
+  v += nm_dpp<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+  v += nm_dpp<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+  v += nm_dpp<0x141>(v);     // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float nm_sum16(float v) {
+  v = nm_sum8(v);
+  v += nm_dpp<0x140>(v);     // row_mirror
+  return v;
+}
+
+#define NM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// Eight wavefronts per workgroup, one workgroup per CU (LDS): every SIMD holds two wavefronts, so one's operand
+// preparation (LDS reads, plane cuts) runs under the other's matrix instructions.
+template <bool F64>
+__global__ void __launch_bounds__(NM_THREADS)
 neumf_step_kernel(NmArgs a) {
-  constexpr int NT = 64 * WAVES;     // threads
+  constexpr int NT = NM_THREADS;
+  constexpr int WAVES = NT / 64;
   constexpr int KI = 1024 / NT;      // pairs per thread in the row-chunk mapping
   constexpr int QS = NT / 16;        // their stride
   constexpr int TP = NT / 64;        // threads per pair in the logit phase
-  constexpr int PW = 64 / WAVES;     // pairs per wavefront in the dz1 phase
-  extern __shared__ float lds[];
+  constexpr int PW = 64 / WAVES;     // pairs per wavefront in the v / db1 phase
+  constexpr int PL = 64 * NM_LW;     // bf16 elements of one plane of W1
+  extern __shared__ __align__(16) float lds[];
   float* X = lds + NM_OFF_X;       // tower input [pair][2 D]; its gradient once the products that read it are done
-  float* H1 = lds + NM_OFF_H1;     // h1 [pair][D]; dz1 once the logit is known
-  float* GU = lds + NM_OFF_GU;     // the pair's share of the user's GMF-row gradient
-  float* W1T = lds + NM_OFF_W1T;   // W1 as [in][out]
+  float* H1 = lds + NM_OFF_H1;     // h1 [pair][D]
+  float* GU = lds + NM_OFF_H1;     // ... and, once h1 is done with, the pair's share of the user's GMF-row gradient
+  uint16_t* WP16 = reinterpret_cast<uint16_t*>(lds + NM_OFF_W1P);   // W1 [unit][input], three bf16 planes
   float* B1 = lds + NM_OFF_B1;
   float* T2 = lds + NM_OFF_T2;
   float* TG = lds + NM_OFF_TG;
@@ -299,7 +272,17 @@ neumf_step_kernel(NmArgs a) {
   unsigned rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
   nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
 
-  for (int i = tid; i < 64 * 128; i += NT) W1T[(i & 127) * NM_LD + (i >> 7)] = a.W1[i];
+  for (int c = tid; c < 64 * 16; c += NT) {       // W1 [unit][input] in pieces of eight inputs
+    const int u = c >> 4, k0 = (c & 15) * 8;
+    float w[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) w[kk] = a.W1[u * 128 + k0 + kk];
+    bf16x8 wh, wm, wl;
+    nm_split8(w, wh, wm, wl);
+    *reinterpret_cast<bf16x8*>(WP16 + u * NM_LW + k0) = wh;
+    *reinterpret_cast<bf16x8*>(WP16 + PL + u * NM_LW + k0) = wm;
+    *reinterpret_cast<bf16x8*>(WP16 + 2 * PL + u * NM_LW + k0) = wl;
+  }
   if (tid < 64) {
     float s = 0.f;
     for (int o = 0; o < 32; ++o) s += a.wf[32 + o] * a.W2[o * 64 + tid];
@@ -320,25 +303,25 @@ neumf_step_kernel(NmArgs a) {
   const uint32_t thr = drop ? (uint32_t)((double)a.p_drop * 4294967296.0) : 0u;
   const float inv_keep = drop ? 1.f / (1.f - a.p_drop) : 1.f;
 
-  // dW1 accumulators.  Four wavefronts: tiles (unit half wave % 2, input quarters 2 (wave / 2), + 1) of dz1^T x.
-  // Eight: both unit halves of input quarter wave % 4 over the pairs 32 (wave / 4) .. + 31 of every tile, of
-  // gate^T (dl x); the two pair halves meet, and t2[unit] / keep comes in, when the partial is written.
+  // gate^T (dl x) accumulated over this workgroup's tiles: both unit halves of input quarter wave % 4 over the
+  // pairs 32 (wave / 4) .. + 31 of every tile; the two pair halves meet, and t2[unit] / keep comes in, when the
+  // partial is written
   f32x16 dW1a[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dW1a[0][r] = 0.f; dW1a[1][r] = 0.f; }
   float va = 0.f, db1a = 0.f;       // column (tid % 64) of v and db1 over the pairs PW wave .. PW wave + PW - 1 of every tile
   float vga[4] = {0.f, 0.f, 0.f, 0.f};   // columns qc .. qc + 3 of vg over this thread's pairs
-  float sdl = 0.f;                  // sum of dl over the pair tid / TP of every tile (threads with tid % TP == 0)
+  float sdl = 0.f;                  // first wavefront: sum of dl over the pair `lane` of every tile
   double lsum = 0.0;
   __syncthreads();
   const float t2c = T2[tid & 63];
   const float4 tg4 = make_float4(TG[qc], TG[qc + 1], TG[qc + 2], TG[qc + 3]);
   const float c0 = C0[0];
-  // eight wavefronts: the B operand of dx = dl (gate (t2 / keep . W1)) is the same for every tile -- three bf16
-  // planes of 64 units x 32 inputs per wavefront (pair half wave % 2, input quarter wave / 2): the first two in
-  // LDS (written by the wavefronts of pair half 0), the third in registers
-  bf16x8 wlo[WAVES == 8 ? 4 : 1];
-  if constexpr (WAVES == 8) {
+  // The B operand of dx = dl (gate (t2 / keep . W1)) is the same for every tile: three bf16 planes of 64 units x 32
+  // inputs per wavefront (pair half wave % 2, input quarter wave / 2), the first two in LDS (written by the
+  // wavefronts of pair half 0), the third in registers.
+  bf16x8 wlo[4];
+  {
     const int j = (wave >> 1) * 32 + l31;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -346,7 +329,7 @@ neumf_step_kernel(NmArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const int u = 16 * ks + 8 * hh + kk;
-        w[kk] = (T2[u] * inv_keep) * W1T[j * NM_LD + u];
+        w[kk] = (T2[u] * inv_keep) * a.W1[u * 128 + j];
       }
       bf16x8 whi, wmid;
       nm_split8(w, whi, wmid, wlo[ks]);
@@ -369,9 +352,12 @@ neumf_step_kernel(NmArgs a) {
     const int ns = (int)((a.B - s0 < S) ? a.B - s0 : S);
     const int PT = ns * N;
     const int64_t p0 = s0 * N;                  // first pair of the tile (pairs of a tile are contiguous)
-    nm_load_idx(a, tile + gridDim.x, tiles, S, N, qp, ix);   // the next tile's indices: used after the logits
     // ---- 1. the fetched rows: tower input into LDS, tg . zg of every pair
     nm_mask_rows(rows_ok, rum, rim, rug, rig);
+#ifdef NM_PHASE_TIMES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NM_STAMP(8);
+#endif
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int p = qp + QS * k;
@@ -379,65 +365,102 @@ neumf_step_kernel(NmArgs a) {
       xr[0] = rum[k].x; xr[1] = rum[k].y; xr[2] = rum[k].z; xr[3] = rum[k].w;
       xr[64] = rim[k].x; xr[65] = rim[k].y; xr[66] = rim[k].z; xr[67] = rim[k].w;
       float zd = (rug[k].x * rig[k].x) * tg4.x + (rug[k].y * rig[k].y) * tg4.y + (rug[k].z * rig[k].z) * tg4.z + (rug[k].w * rig[k].w) * tg4.w;
-      zd = rx_group_sum(zd, 16);
+      zd = nm_sum16(zd);
       if ((tid & 15) == 0) ZD[p] = zd;
+    }
+    // (issued only now: a wait for the fetched rows above also waits for every load issued before it)
+    {
+      int qpv = qp;
+      asm volatile("" : "+v"(qpv));      // (index addresses are formed here, per tile: 64-bit pieces of them kept across the loop cost registers)
+      nm_load_idx(a, tile + gridDim.x, tiles, S, N, qpv, ix);   // the next tile's indices: used after the logits
+    }
+    // the label of pair `lane` (used by the first wavefront), on its way until the logit is known: loaded by every
+    // wavefront from a clamped address and left as it is -- a branch around the load, or a conversion behind it,
+    // would make the tile wait for it here
+    typename std::conditional<F64, double, float>::type yraw;
+    {
+      int pl = lane < PT ? lane : PT - 1;
+      asm volatile("" : "+v"(pl));     // (the address is formed here, per tile)
+      yraw = reinterpret_cast<const typename std::conditional<F64, double, float>::type*>(a.labels)[p0 + pl];
     }
     __syncthreads();
     NM_STAMP(1);
-    // ---- 2. h1 = dropout(relu(x W1^T + b1)): wave -> 32 x 32 tile (rt, ct) of [64 pairs, 64 units]; with eight
-    //         wavefronts, half kh of the 128 inputs each: the upper halves leave their sums in h1's place
+    // ---- 2. h1 = dropout(relu(x W1^T + b1)): wave -> 32 x 32 tile (rt, ct) of [64 pairs, 64 units] over half kh of
+    //         the 128 inputs; the upper halves leave their sums in h1's place, the lower halves finish.  x is cut
+    //         into planes as it is read; of the nine plane products the six of weight >= 2^-16 are formed, smallest
+    //         first (what is left out is below the rounding of one fp32 product).
     {
       const int w4 = wave & 3, kh = wave >> 2;
       const int rt = w4 >> 1, ct = w4 & 1;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* ap = X + (rt * 32 + l31) * NM_LDX + hh;
-      const float* bp = W1T + hh * NM_LD + ct * 32 + l31;
+      const float* xrow = X + (rt * 32 + l31) * NM_LDX + kh * 64 + 8 * hh;
+      const uint16_t* wrow = WP16 + (ct * 32 + l31) * NM_LW + kh * 64 + 8 * hh;
       const int col = ct * 32 + l31;
-      if (WAVES == 4) {
-        nm_mm<64, 1, NM_LD>(acc, ap, bp);
-      } else {
-        nm_mm<32, 1, NM_LD, 4>(acc, ap + kh * 64, bp + kh * 64 * NM_LD);
-        if (kh == 1) {
+      float xn[8];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) H1[(rt * 32 + NM_ROW(r, hh)) * NM_LD + col] = acc[r];
+      for (int kk = 0; kk < 8; ++kk) xn[kk] = xrow[kk];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wrow + 16 * ks);
+        const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wrow + PL + 16 * ks);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wrow + 2 * PL + 16 * ks);
+        bf16x8 xh, xm, xl;
+        nm_split8(xn, xh, xm, xl);
+        if (ks + 1 < 4) {          // the next step's inputs are read under this step's products
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) xn[kk] = xrow[16 * (ks + 1) + kk];
         }
-        __syncthreads();
+        acc = NM_MFMA(xl, wh, acc);
+        acc = NM_MFMA(xh, wl, acc);
+        acc = NM_MFMA(xm, wm, acc);
+        acc = NM_MFMA(xm, wh, acc);
+        acc = NM_MFMA(xh, wm, acc);
+        acc = NM_MFMA(xh, wh, acc);
       }
-      const float bv = B1[col];
-      if (WAVES == 4 || kh == 0) {
-      uint16_t gate[16];
+      // the two halves of the sum meet through h1's place: wavefront kh finishes accumulator registers 8 kh .. 8 kh + 7
+      // (rows 16 kh + 4 hh + {0 .. 3, 8 .. 11} of its tile) and hands the partner its sums of the other eight
+      if (kh == 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + NM_ROW(r, hh);
-        if (WAVES == 8) acc[r] += H1[row * NM_LD + col];
-        float v = acc[r] + bv;
-        v = v > 0.f ? v : 0.f;
-        if (drop) {
-          int rowv = row;
-          asm volatile("" : "+v"(rowv));    // (formed here: sixteen 64-bit counters kept across the tile loop would cost 32 registers)
-          const uint32_t draw = (uint32_t)(nm_mix(seed, (uint64_t)(p0 + rowv) * 64ull + (uint64_t)col) >> 32);
-          v = draw >= thr ? v * inv_keep : 0.f;
-        }
-        v = row < PT ? v : 0.f;
-        H1[row * NM_LD + col] = v;
-        if constexpr (WAVES == 8) {
-          gate[r] = v > 0.f ? (uint16_t)0x3F80 : (uint16_t)0;
+        for (int r = 8; r < 16; ++r) H1[(rt * 32 + NM_ROW(r, hh)) * NM_LD + col] = acc[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) H1[(rt * 32 + NM_ROW(r, hh)) * NM_LD + col] = acc[r];
+      }
+      __syncthreads();
+      const float bv = B1[col];
+      auto finish = [&](auto half) {
+        constexpr int KH = decltype(half)::value;
+        uint16_t gate[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = rt * 32 + NM_ROW(8 * KH + r, hh);
+          const float other = H1[row * NM_LD + col];
+          float v = (KH ? other + acc[8 + r] : acc[r] + other) + bv;      // inputs 0 .. 63, then 64 .. 127, whichever wavefront adds
+          v = v > 0.f ? v : 0.f;
+          if (drop) {
+            int rowv = row;
+            asm volatile("" : "+v"(rowv));    // (formed here: 64-bit counters kept across the tile loop would cost registers all the way)
+            const uint32_t draw = (uint32_t)(nm_mix(seed, (uint64_t)(p0 + rowv) * 64ull + (uint64_t)col) >> 32);
+            v = draw >= thr ? v * inv_keep : 0.f;
+          }
+          v = row < PT ? v : 0.f;
+          H1[row * NM_LD + col] = v;
+          gate[r] = v > 0.f ? (uint16_t)0x3F80 : (uint16_t)0;       // bf16 1.0 / 0.0
           G16[row * NM_LG + col] = gate[r];
         }
-      }
-      if constexpr (WAVES == 8) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)     // rows 8 q + 4 hh .. + 3 of the tile sit in registers 4 q .. 4 q + 3
-          *reinterpret_cast<uint2*>(GT16 + col * NM_LG + rt * 32 + 8 * q + 4 * hh) =
+        for (int q = 0; q < 2; ++q)     // rows 8 (2 KH + q) + 4 hh .. + 3 of the tile sit in registers 4 q .. 4 q + 3 of this half
+          *reinterpret_cast<uint2*>(GT16 + col * NM_LG + rt * 32 + 8 * (2 * KH + q) + 4 * hh) =
               make_uint2((uint32_t)gate[4 * q] | ((uint32_t)gate[4 * q + 1] << 16), (uint32_t)gate[4 * q + 2] | ((uint32_t)gate[4 * q + 3] << 16));
-      }
-      }
+      };
+      if (kh == 0) finish(std::integral_constant<int, 0>{});
+      else finish(std::integral_constant<int, 1>{});
     }
     __syncthreads();
     NM_STAMP(2);
-    // ---- 3. logit = c0 + tg . zg + t2 . h1 (TP threads per pair), BCE term (fp64), dL/dlogit
+    // ---- 3. logit = c0 + tg . zg + t2 . h1 (TP threads per pair, left in ZD), BCE term (fp64), dL/dlogit
     // The next tile's row offsets are taken here, pinned in registers: the indices arrived two phases ago, and
     // a wait placed behind the label loads and gradient stores below would wait for those as well.
     rows_ok = nm_row_offsets(a, ix, ou, oi, bad);
@@ -451,41 +474,41 @@ neumf_step_kernel(NmArgs a) {
       float x = 0.f;
 #pragma unroll
       for (int j = 0; j < 64 / TP; ++j) x += hp[j] * T2[part + j];
-      x = rx_group_sum(x, TP);
-      if (tid % TP == 0) {
-        float dl = 0.f;
-        if (p < PT) {
-          x += c0 + ZD[p];
-          if (a.logits) a.logits[p0 + p] = x;
-          const double xd = (double)x;
-          const double y = F64 ? reinterpret_cast<const double*>(a.labels)[p0 + p] : (double)reinterpret_cast<const float*>(a.labels)[p0 + p];
-          const NmBce t = nm_bce_term(xd, y);
-          lsum += t.term;
-          dl = (float)((t.sig - y) * a.inv_m);
-        }
-        DL[p] = dl;
-        sdl += dl;
+      static_assert(TP == 8, "lanes per pair");
+      x = nm_sum8(x);
+      if (tid % TP == 0) ZD[p] = x + (c0 + ZD[p]);
+    }
+    __syncthreads();
+    // the fp64 part on ONE wavefront with every lane at work (pair = lane): spread over the eight, each would
+    // issue the whole sequence for eight active lanes
+    if (wave == 0) {
+      int p = lane;
+      asm volatile("" : "+v"(p));
+      float dl = 0.f;
+      if (p < PT) {
+        const float x = ZD[p];
+        if (a.logits) a.logits[p0 + p] = x;
+        const double xd = (double)x, y = (double)yraw;
+        const NmBce t = nm_bce_term(xd, y);
+        lsum += t.term;
+        dl = (float)((t.sig - y) * a.inv_m);
       }
+      DL[p] = dl;
+      sdl += dl;
     }
     __syncthreads();
     NM_STAMP(3);
-    // ---- 4. v += dl h1, dz1 = dl t2 through the dropout scale and the ReLU (in place), db1 += dz1;
-    //         vg += dl zg, item GMF gradients out, the pair's share of the user's GMF gradient into LDS
+    // ---- 4. v += dl h1, db1 += gate dl (t2 / keep comes in at the end); vg += dl zg, item GMF gradients out
     {
       const int c = tid & 63;
 #pragma unroll
       for (int p = wave * PW; p < wave * PW + PW; ++p) {
         const float h = H1[p * NM_LD + c], dl = DL[p];
         va += dl * h;
-        if constexpr (WAVES == 8) {
-          db1a += h > 0.f ? dl : 0.f;      // (t2 / keep comes in at the end)
-        } else {
-          const float dz = h > 0.f ? (dl * t2c) * inv_keep : 0.f;
-          db1a += dz;
-          H1[p * NM_LD + c] = dz;
-        }
+        db1a += h > 0.f ? dl : 0.f;
       }
     }
+    float4 gu[KI];      // the pair's share of the user's GMF gradient: into LDS once every wavefront is done with h1
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int p = qp + QS * k;
@@ -494,36 +517,40 @@ neumf_step_kernel(NmArgs a) {
       vga[2] += dl * (rug[k].z * rig[k].z); vga[3] += dl * (rug[k].w * rig[k].w);
       const float4 dz = make_float4(dl * tg4.x, dl * tg4.y, dl * tg4.z, dl * tg4.w);
       if (p < PT) *reinterpret_cast<float4*>(a.di_g + (p0 + p) * NM_D + qc) = make_float4(dz.x * rug[k].x, dz.y * rug[k].y, dz.z * rug[k].z, dz.w * rug[k].w);
-      float* gr = GU + p * NM_LD + qc;
-      gr[0] = dz.x * rig[k].x; gr[1] = dz.y * rig[k].y; gr[2] = dz.z * rig[k].z; gr[3] = dz.w * rig[k].w;
+      gu[k] = make_float4(dz.x * rig[k].x, dz.y * rig[k].y, dz.z * rig[k].z, dz.w * rig[k].w);
     }
     // the next tile's rows travel while the gradient products below run
     nm_load_rows(a, ou, oi, qc, rum, rim, rug, rig);
     __syncthreads();
     NM_STAMP(4);
-    // ---- 5. dW1 += dz1^T x; dx = dz1 W1 (two 32 x 32 tiles of each per wave with four wavefronts, one with eight)
-    if constexpr (WAVES == 8) {
-      // The gate is 0 / 1, so dz1 = gate (dl t2 / keep) factors: dW1 = (t2 / keep) . gate^T (dl x) and
-      // dx = dl . gate (t2 / keep . W1), with the fp32 factor cut into three bf16 planes (nm_split8).
-      {
-        const int cq = wave & 3, kh = wave >> 2;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int k0 = kh * 32 + ks * 16 + 8 * hh;       // this lane's eight pairs
-          float xv[8];
+    for (int k = 0; k < KI; ++k) {
+      float* gr = GU + (qp + QS * k) * NM_LD + qc;
+      gr[0] = gu[k].x; gr[1] = gu[k].y; gr[2] = gu[k].z; gr[3] = gu[k].w;
+    }
+    // ---- 5. The gate is 0 / 1, so dz1 = gate (dl t2 / keep) factors: dW1 = (t2 / keep) . gate^T (dl x) and
+    //         dx = dl . gate (t2 / keep . W1).  With the fp32 factor cut into three bf16 planes, a product with the
+    //         0 / 1 operand on v_mfma_f32_32x32x16_bf16 accumulates exactly the fp32 terms.
+    {
+      const int cq = wave & 3, kh = wave >> 2;
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) xv[kk] = X[(k0 + kk) * NM_LDX + cq * 32 + l31] * DL[k0 + kk];
-          bf16x8 bh, bm, bl;
-          nm_split8(xv, bh, bm, bl);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k0 = kh * 32 + ks * 16 + 8 * hh;       // this lane's eight pairs
+        float xv[8];
 #pragma unroll
-          for (int ht = 0; ht < 2; ++ht) {
-            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(GT16 + (ht * 32 + l31) * NM_LG + k0);
-            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bh, dW1a[ht], 0, 0, 0);
-            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bm, dW1a[ht], 0, 0, 0);
-            dW1a[ht] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, bl, dW1a[ht], 0, 0, 0);
-          }
+        for (int kk = 0; kk < 8; ++kk) xv[kk] = X[(k0 + kk) * NM_LDX + cq * 32 + l31] * DL[k0 + kk];
+        bf16x8 bh, bm, bl;
+        nm_split8(xv, bh, bm, bl);
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+          const bf16x8 ga = *reinterpret_cast<const bf16x8*>(GT16 + (ht * 32 + l31) * NM_LG + k0);
+          dW1a[ht] = NM_MFMA(ga, bh, dW1a[ht]);
+          dW1a[ht] = NM_MFMA(ga, bm, dW1a[ht]);
+          dW1a[ht] = NM_MFMA(ga, bl, dW1a[ht]);
         }
       }
+    }
+    {
       f32x16 acc1;
       const int rt = wave & 1, cq = wave >> 1;
 #pragma unroll
@@ -533,9 +560,9 @@ neumf_step_kernel(NmArgs a) {
         const bf16x8 ga = *reinterpret_cast<const bf16x8*>(G16 + (rt * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
         const bf16x8 wh = *reinterpret_cast<const bf16x8*>(WH16 + (cq * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
         const bf16x8 wm = *reinterpret_cast<const bf16x8*>(WM16 + (cq * 32 + l31) * NM_LG + 16 * ks + 8 * hh);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wh, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wm, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, wlo[ks], acc1, 0, 0, 0);
+        acc1 = NM_MFMA(ga, wlo[ks], acc1);
+        acc1 = NM_MFMA(ga, wm, acc1);
+        acc1 = NM_MFMA(ga, wh, acc1);
       }
       NM_STAMP(5);
       __syncthreads();    // every read of x is done: it now takes dx
@@ -543,26 +570,6 @@ neumf_step_kernel(NmArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = rt * 32 + NM_ROW(r, hh);
         X[row * NM_LDX + cq * 32 + l31] = acc1[r] * DL[row];
-      }
-    } else {
-      f32x16 acc1, acc2;
-      const int ht = wave & 1, cp = wave >> 1;
-      const float* ap = H1 + hh * NM_LD + ht * 32 + l31;                 // A[i = unit][k = pair]
-      const float* bp = X + hh * NM_LDX + cp * 64 + l31;                 // B[k = pair][j = input]
-      nm_mm2<NM_P / 2, NM_LD, NM_LDX, 32>(dW1a[0], dW1a[1], ap, bp);
-      const int rt = wave & 1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
-      const float* a1 = H1 + (rt * 32 + l31) * NM_LD + hh;               // A[i = pair][k = unit]
-      const float* b1p = W1T + (cp * 64 + l31) * NM_LD + hh;             // B[k = unit][j = input] = W1[unit][input]
-      nm_mm2<32, 1, 1, 32 * NM_LD>(acc1, acc2, a1, b1p);
-      NM_STAMP(5);
-      __syncthreads();    // every read of x is done: it now takes dx
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + NM_ROW(r, hh);
-        X[row * NM_LDX + cp * 64 + l31] = acc1[r];
-        X[row * NM_LDX + cp * 64 + 32 + l31] = acc2[r];
       }
     }
     __syncthreads();
@@ -593,15 +600,15 @@ neumf_step_kernel(NmArgs a) {
   }
 #ifdef NM_PHASE_TIMES
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-    printf("block %d phases (10 ns ticks): stage %lld  h1 %lld  logit %lld  dz %lld  mfma %lld  dx %lld  out %lld  | tile %lld\n", (int)blockIdx.x,
-           stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5],
+    printf("block %d phases (10 ns ticks): wait %lld  stage %lld  h1 %lld  logit %lld  dz %lld  mfma %lld  dx %lld  out %lld  | tile %lld\n", (int)blockIdx.x,
+           stamp[8] - stamp[0], stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4], stamp[6] - stamp[5],
            stamp[7] - stamp[6], stamp[7] - stamp[0]);
 #endif
 
   if (bad && a.err_flag) atomicOr(a.err_flag, RX_ERR_INDEX);
   // ---- this workgroup's partial: [dW1 | db1 | v | vg | sum dl]; the thread-level pieces meet in LDS, fixed order
   float* wp = a.raw + (size_t)blockIdx.x * NM_RAW;
-  if constexpr (WAVES == 8) {
+  {
     // the two pair halves of gate^T (dl x) meet in LDS (x is done with); the unit's t2 / keep comes in here
     const int cq = wave & 3, kh = wave >> 2;
     float* half = X + cq * 2048;
@@ -623,21 +630,13 @@ neumf_step_kernel(NmArgs a) {
     }
     __syncthreads();
     db1a *= t2c * inv_keep;
-  } else {
-    const int ht = wave & 1, cp = wave >> 1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int h = ht * 32 + NM_ROW(r, hh);
-      wp[h * 128 + cp * 64 + l31] = dW1a[0][r];
-      wp[h * 128 + cp * 64 + 32 + l31] = dW1a[1][r];
-    }
   }
   float* red = X;        // [db1: WAVES x 64 | v: WAVES x 64 at 512 | vg: QS x 64 at 1024 | sum dl: 64 at 3072]
   red[wave * 64 + lane] = db1a;
   red[512 + wave * 64 + lane] = va;
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[1024 + qp * 64 + qc + e] = vga[e];
-  if (tid % TP == 0) red[3072 + tid / TP] = sdl;
+  if (wave == 0) red[3072 + lane] = sdl;
   lsum = rx_wave_sum_f64(lsum);
   if (lane == 0) lsum_w[wave] = lsum;
   __syncthreads();
@@ -810,24 +809,15 @@ extern "C" int rx_neumf_step(const rx_neumf_args* r, void* ws, size_t ws_bytes, 
   a.loss_part = (double*)((char*)ws + rx_align_up((size_t)grid * NM_RAW * sizeof(float), 256));
   a.logits = r->logits; a.err_flag = err_flag;
   const size_t lds = NM_LDS_FLOATS * sizeof(float);
-  // RX_NEUMF_WAVES=4 runs the step with four wavefronts per workgroup instead of eight (A/B timing)
-  static const bool four = [] { const char* e = getenv("RX_NEUMF_WAVES"); return e && e[0] == '4'; }();
   static bool attr_set[64] = {};
   if (device >= 64 || !attr_set[device]) {   // LDS beyond 64 KiB per workgroup has to be asked for, per device
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RX_HIP(hipFuncSetAttribute((const void*)neumf_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (device < 64) attr_set[device] = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (four) {
-    if (r->labels_f64) hipLaunchKernelGGL((neumf_step_kernel<true, 4>), dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((neumf_step_kernel<false, 4>), dim3(grid), dim3(256), lds, st, a);
-  } else {
-    if (r->labels_f64) hipLaunchKernelGGL((neumf_step_kernel<true, 8>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((neumf_step_kernel<false, 8>), dim3(grid), dim3(512), lds, st, a);
-  }
+  if (r->labels_f64) hipLaunchKernelGGL(neumf_step_kernel<true>, dim3(grid), dim3(NM_THREADS), lds, st, a);
+  else hipLaunchKernelGGL(neumf_step_kernel<false>, dim3(grid), dim3(NM_THREADS), lds, st, a);
   RX_LAUNCH_CHECK();
   NmFin f{};
   f.raw = a.raw; f.n_parts = grid; f.wgrad = r->wgrad;
