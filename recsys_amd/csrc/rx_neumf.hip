@@ -17,23 +17,32 @@
 //   dW2 = wf[D/2:] (x) v,   db2 = wf[D/2:] sum(dl),   v  = sum_pairs dl h1
 //   dWg = wf[:D/2] (x) vg,  dbg = wf[:D/2] sum(dl),   vg = sum_pairs dl zg
 //   dwf = [Wg vg + bg sum(dl) | W2 v + b2 sum(dl)],   dbf = sum(dl)
-// which leaves three matrix products per pair tile -- the first tower layer forward, and its two gradients
-// (dW1 += dz1^T x, dx = dz1 W1) -- on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  The
-// only sums across pairs are those weight-gradient terms, the gradient of a user's rows over that user's N
+// which leaves three matrix products per pair tile: the first tower layer forward, and its two gradients
+// dW1 += dz1^T x and dx = dz1 W1.  fp32 matrix instructions (v_mfma_f32_32x32x2_f32) run at a sixteenth of the bf16
+// rate, and these three products were two thirds of the tile's time on them, so they run on
+// v_mfma_f32_32x32x16_bf16 with every fp32 operand cut into three bf16 planes that add up to it exactly (nm_split8):
+//   * dz1 = gate . (dl t2 / keep) with gate = [h1 > 0] in {0, 1}: dW1 = (t2 / keep) . gate^T (dl x) and
+//     dx = dl . gate (t2 / keep . W1).  One operand is 0 / 1, the other three planes: every product is exact, the
+//     sum is the fp32 accumulation of the fp32 terms.
+//   * h1 = x W1^T: of the nine plane products the six of weight >= 2^-16 are formed; what is left out is below the
+//     rounding of a single fp32 product.  (A unit whose pre-activation is zero to rounding may fall on the other
+//     side of the ReLU than under another summation order, as with any reordering of the sum.)
+// The only sums across pairs are the weight-gradient terms, the gradient of a user's rows over that user's N
 // items, and the loss.  A workgroup takes tiles of whole samples (64 / N samples, at most 64 pairs), keeps the
-// tile's activations in LDS, keeps dW1 in accumulator registers across its tiles, fetches the rows of its next
-// tile while the gradient products of the current one run, and leaves
+// tile's activations in LDS, keeps gate^T (dl x) in accumulator registers across its tiles, fetches the rows of
+// its next tile while the gradient products of the current one run, and leaves
 //   du_g, du_m [B, D]      gradient of the user's GMF / MLP row, summed over the sample's N pairs (pair order)
 //   di_g, di_m [B N, D]    gradient of every pair's item rows
 //   raw [grid][NM_RAW]     per-workgroup [dW1 | db1 | v | vg | sum(dl)], added in workgroup order by the finish
 //                          kernel, which also expands v, vg, sum(dl) into the gradients of W2, b2, Wg, bg, wf, bf
 //   loss partials          fp64, one per workgroup
 // The embedding gradients then take the usual deterministic path (sort + segmented reduce, fused row update).
-// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 153 KB of LDS per workgroup.
+// Written for D = 64 (tables of 64 floats, tower 128 -> 64 -> 32, GMF 64 -> 32): 155 KB of LDS per workgroup, eight
+// wavefronts, one workgroup per CU.
 //
-// LDS operands are read in the two patterns an MFMA lane needs -- (index = lane % 32, k = lane / 32) and
-// (k = lane / 32, index = lane % 32) -- from the same arrays; every array has an ODD row pitch, so both
-// patterns spread a wavefront's reads over all banks and W1 is kept once (as [in][out]).
+// LDS: the fp32 arrays (x, h1) have an ODD row pitch, so a wavefront's reads of 32 rows at one column, and of 32
+// columns of one row, both spread over all banks; the bf16 arrays (W1 planes, the gate in both orientations, the
+// planes of t2 / keep . W1) are read 16 bytes per lane and have row pitches of 36 and 68 words for the same reason.
 #include "rx_common.h"
 
 #include <type_traits>

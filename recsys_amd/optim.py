@@ -32,6 +32,7 @@ _NO_SPECULATION = os.environ.get("RX_NO_SPECULATIVE_SGD") == "1"   # A/B: clippe
 # second pass they save.
 _SPECULATE_SORTED = os.environ.get("RX_SPECULATIVE_SGD_SORTED") == "1"
 _NO_FUSED_TAIL = os.environ.get("RX_NO_FUSED_TAIL") == "1"      # clip factor, row updates and dense update as three launches (A/B)
+_FUSED_TAIL_MAX_ROWS, _FUSED_TAIL_MAX_PARTS = 1 << 18, 4096
 
 _MODES = {"sgd": _lib.RX_SEG_SGD, "adagrad": _lib.RX_SEG_ADAGRAD, "rowwise_adagrad": _lib.RX_SEG_ROWWISE_ADAGRAD}
 
@@ -371,6 +372,12 @@ class FusedOptimizer:
                 return False
             seen.add(id(param))
         if self.dense_kind == "adam":
+            return False
+        # every block of the fused launch adds up all partial sums before it touches a row: a gain for the small
+        # lists of the MF / NCF families (launch-bound tails), a loss once the lists are long -- 0.65 against 0.55 ms
+        # per step on 1.7 M occurrences of 512-byte rows
+        n_parts = (int(parts.numel()) if parts is not None else 0) + (int(parts64.numel()) if parts64 is not None else 0)
+        if sum(int(item[2].shape[0]) for item in self._pending) > _FUSED_TAIL_MAX_ROWS or n_parts > _FUSED_TAIL_MAX_PARTS:
             return False
         live = [(p, p.grad) for p in self.dense if p.grad is not None]
         if len(live) > _lib.RX_MULTI_MAX or any(not (p.data.is_contiguous() and g.is_contiguous() and p.is_cuda) for p, g in live):
