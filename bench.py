@@ -706,7 +706,7 @@ def main():
 
     from recsys_amd import ops
     ops.set_index_check("deferred")
-    clip = None if args.no_clip else 1.0
+    clip = None if args.no_clip else float(os.environ.get("RX_BENCH_CLIP_NORM", 1.0))   # (the reference clips at 1.0: recsys/utils.py:101)
 
     def run(name, steps, warmup, timed_op=None, use_graph=True, repeats=1, check=False):
         """Builds the workload, runs `warmup` untimed steps, then times `repeats` regions of EXACTLY `steps`

@@ -359,7 +359,18 @@ int rx_sort_dedup_fm(const rx_fm_args* a, int32_t* d_sorted_pos, int32_t* d_sort
 enum { RX_SEG_DENSE = 0, RX_SEG_COMPACT = 1, RX_SEG_SGD = 2, RX_SEG_ADAGRAD = 3,
        RX_SEG_ROWWISE_ADAGRAD = 4,
        RX_SEG_SGD_SPEC = 5,      /* rx_fg_reduce / rx_fg_row_update(_clip) only, see rx_fg_reduce_args.undo */
-       RX_SEG_SGD_SPEC_REDO = 6  /* rx_fg_row_update(_clip) only: redo the rows from their records whatever the factor */ };
+       RX_SEG_SGD_SPEC_REDO = 6, /* rx_fg_row_update(_clip) only: redo the rows from their records whatever the factor */
+       /* The one-pass clipped SGD step with records of half the size, for wide rows (rx_segreduce, rx_segreduce_fm):
+        * `state` [n][dim] / `state2` [n] keep only the row / entry of before the step.  When the factor turns out
+        * below 1 the step is redone from scratch by three calls that cost a launch each and nothing more while
+        * the factor is exactly 1:
+        *   rx_row_update(RX_SEG_RESTORE_IF_CLIPPED, d_compact = records)   rows and entries back in place
+        *   rx_segreduce_fm / rx_segreduce(RX_SEG_COMPACT_IF_CLIPPED, d_scale = the factor)   compact gradients again
+        *   rx_row_update(RX_SEG_SGD_IF_CLIPPED)                            the clipped step
+        * RX_SEG_RESTORE puts the rows back whatever the factor (gradients dropped, or a forward pass before the
+        * step).  The result equals RX_SEG_COMPACT + RX_SEG_SGD bit for bit either way. */
+       RX_SEG_SGD_SPEC_OLD = 7, RX_SEG_COMPACT_IF_CLIPPED = 8, RX_SEG_SGD_IF_CLIPPED = 9, RX_SEG_RESTORE = 10,
+       RX_SEG_RESTORE_IF_CLIPPED = 11 };
 int64_t rx_segreduce_grid(int64_t n, int32_t dim);
 size_t rx_segreduce_workspace_bytes(int64_t n, int32_t dim);
 int rx_segreduce(const float* d_occ, int64_t occ_ld, int64_t n, int32_t dim,

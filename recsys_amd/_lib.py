@@ -200,6 +200,7 @@ PROTOTYPES = {
 }
 
 RX_SEG_DENSE, RX_SEG_COMPACT, RX_SEG_SGD, RX_SEG_ADAGRAD, RX_SEG_ROWWISE_ADAGRAD, RX_SEG_SGD_SPEC, RX_SEG_SGD_SPEC_REDO = range(7)
+RX_SEG_SGD_SPEC_OLD, RX_SEG_COMPACT_IF_CLIPPED, RX_SEG_SGD_IF_CLIPPED, RX_SEG_RESTORE, RX_SEG_RESTORE_IF_CLIPPED = range(7, 12)
 RX_ERR_INDEX = 1
 RX_ERR_CAPACITY = 2
 RX_ABI_VERSION = 1

@@ -58,6 +58,12 @@ struct SegArgs {
   // and the number of 256-thread blocks the list needs (the launch itself is a small grid that strides).
   int force;
   unsigned upd_blocks;
+  // RX_SEG_SGD_SPEC_OLD: the records hold only what was there before the step -- `state` [n][dim] the row,
+  // `state2` [n] the companion entry (half the bytes; a step whose clip bites is then redone from scratch: rows put
+  // back, gradients formed again).  In rx_row_update the records are copied back (RX_SEG_RESTORE*).
+  int undo_old_only;
+  // *_IF_CLIPPED modes: the whole launch returns at once when this device scalar (the clip factor) is exactly 1
+  const float* gate;
 };
 
 // Optimizer arithmetic for one scalar (companion table entry).  MODE is a template parameter:
@@ -73,7 +79,8 @@ __device__ __forceinline__ void apply_scalar(const SegArgs& a, float g, int64_t 
     a.target2[row] = a.target2[row] - a.lr * (g * scale);
   } else if constexpr (MODE == RX_SEG_SGD_SPEC) {
     const float old = a.target2[row];
-    reinterpret_cast<float2*>(a.state2)[u] = make_float2(g, old);
+    if (a.undo_old_only) a.state2[u] = old;
+    else reinterpret_cast<float2*>(a.state2)[u] = make_float2(g, old);
     a.target2[row] = old - a.lr * g;
   } else {  // Adagrad; row-wise Adagrad of a width-1 row is the same rule
     g *= scale;
@@ -103,13 +110,22 @@ __device__ __forceinline__ void apply_row(const SegArgs& a, Acc<VEC, CH>& g, Acc
   if constexpr (MODE == RX_SEG_SGD_SPEC) {
     // the step with a clip factor of 1 (exact: the bits of the clipped step whenever the norm stays inside the
     // bound), and the record from which rx_row_update redoes the row when it does not
-    float* ud = a.state + u * (int64_t)(2 * dim);
+    if (a.undo_old_only) {
+      float* ud = a.state + u * (int64_t)dim;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const int c = (lg + k * group) * VEC;
-      if (c < dim) {
-        rx_store<VEC>(ud + c, g.p[k]);
-        rx_store<VEC>(ud + dim + c, x.p[k]);
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        if (c < dim) rx_store<VEC>(ud + c, x.p[k]);
+      }
+    } else {
+      float* ud = a.state + u * (int64_t)(2 * dim);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        if (c < dim) {
+          rx_store<VEC>(ud + c, g.p[k]);
+          rx_store<VEC>(ud + dim + c, x.p[k]);
+        }
       }
     }
     ACC_FOREACH(k, i) x.p[k].v[i] = x.p[k].v[i] - a.lr * g.p[k].v[i];
@@ -485,6 +501,7 @@ __device__ __forceinline__ void segreduce_chunk_body(const SegArgs& a, const uns
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_kernel(SegArgs a) {
+  if (a.gate && a.gate[0] == 1.f) return;
   segreduce_chunk_body<VEC, CH, MODE, FM, false>(a, blockIdx.x);
 }
 
@@ -516,6 +533,7 @@ segreduce_chunk_multi_kernel(SegMulti m) {
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_chunk_deep_kernel(SegArgs a) {
+  if (a.gate && a.gate[0] == 1.f) return;
   segreduce_chunk_body<VEC, CH, MODE, true, true>(a, blockIdx.x);
 }
 
@@ -682,6 +700,7 @@ __device__ __forceinline__ void segreduce_combine_body(const SegArgs& a, const i
 template <int VEC, int CH, int MODE, bool FM>
 __global__ void __launch_bounds__(RX_BLOCK)
 segreduce_combine_kernel(SegArgs a, int64_t n_pieces) {
+  if (a.gate && a.gate[0] == 1.f) return;
   segreduce_combine_body<VEC, CH, MODE, FM>(a, n_pieces, blockIdx.x);
 }
 
@@ -790,6 +809,14 @@ static int seg_place(SegArgs& a, bool fm, const char* who, void* ws, size_t ws_b
 
 // Shared driver of rx_segreduce and rx_segreduce_fm.
 static int segreduce_run(SegArgs a, bool fm, const char* who, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (a.mode == RX_SEG_SGD_SPEC_OLD) {
+    a.mode = RX_SEG_SGD_SPEC;
+    a.undo_old_only = 1;
+  } else if (a.mode == RX_SEG_COMPACT_IF_CLIPPED) {
+    RX_REQUIRE(a.scale, "%s: RX_SEG_COMPACT_IF_CLIPPED needs the clip factor", who);
+    a.mode = RX_SEG_COMPACT;
+    a.gate = a.scale;
+  }
   RxRowShape sh;
   if (seg_place(a, fm, who, ws, ws_bytes, &sh)) return 1;
   const int64_t n = a.n;
@@ -923,9 +950,19 @@ __device__ __forceinline__ void row_update_body(const SegArgs& a, const unsigned
   if constexpr (MODE == RX_SEG_SGD_SPEC) {
     const int64_t row = a.uniq_rows[u];
     if (row < 0 || row >= a.n_rows) return;
+    float* w = a.target + row * (int64_t)dim;
+    if (a.undo_old_only) {      // records of what was there before the step: put it back
+      const float* ud = a.occ + u * (int64_t)dim;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = (lg + k * group) * VEC;
+        if (c < dim) rx_store<VEC>(w + c, rx_load<VEC>(ud + c));
+      }
+      if (a.target2 && lg == 0) a.target2[row] = a.occ2[u];
+      return;
+    }
     // redo the row from its record: old - lr * (factor * G), what RX_SEG_COMPACT + RX_SEG_SGD leave
     const float* ud = a.occ + u * (int64_t)(2 * dim);
-    float* w = a.target + row * (int64_t)dim;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int c = (lg + k * group) * VEC;
@@ -987,6 +1024,7 @@ row_update_kernel(SegArgs a) {
     if (scale == 1.f && !a.force) return;
     for (unsigned b = blockIdx.x; b < a.upd_blocks; b += gridDim.x) row_update_body<VEC, CH, MODE>(a, b, scale);
   } else {
+    if (a.gate && a.gate[0] == 1.f) return;
     row_update_body<VEC, CH, MODE>(a, blockIdx.x, a.scale ? a.scale[0] : 1.f);
   }
 }
@@ -1005,10 +1043,14 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
                              void* stream) {
   RX_ENTER(device);
   RX_REQUIRE(n_max >= 0 && dim >= 1 && dim <= RX_MAX_DIM, "rx_row_update: bad shape");
-  const bool force = mode == RX_SEG_SGD_SPEC_REDO;
-  if (force) mode = RX_SEG_SGD_SPEC;
+  const bool force = mode == RX_SEG_SGD_SPEC_REDO || mode == RX_SEG_RESTORE;
+  const bool restore = mode == RX_SEG_RESTORE || mode == RX_SEG_RESTORE_IF_CLIPPED;
+  const bool gated = mode == RX_SEG_SGD_IF_CLIPPED;
+  RX_REQUIRE(!(mode == RX_SEG_RESTORE_IF_CLIPPED || gated) || d_scale, "rx_row_update: the *_IF_CLIPPED modes need the clip factor");
+  if (gated) mode = RX_SEG_SGD;
+  if (force || restore) mode = RX_SEG_SGD_SPEC;
   if (mode == RX_SEG_SGD_SPEC) {      // d_compact / d_compact2 are the undo records; no optimizer state
-    RX_REQUIRE(d_scale, "rx_row_update: the speculative step needs the clip factor");
+    RX_REQUIRE(d_scale || (restore && force), "rx_row_update: the speculative step needs the clip factor");
     d_state = const_cast<float*>(d_compact);
   }
   if (mode_check(mode, d_state, "rx_row_update", false)) return 1;
@@ -1025,6 +1067,8 @@ extern "C" int rx_row_update(const float* d_compact, int32_t dim, const int64_t*
   a.group = sh.group;
   unsigned grid = (unsigned)rx_cdiv(rx_cdiv(n_max, upd_rows_of(sh.chunks, mode)) * sh.group, RX_BLOCK);
   a.force = force ? 1 : 0;
+  a.undo_old_only = restore ? 1 : 0;
+  a.gate = gated ? d_scale : nullptr;
   a.upd_blocks = grid;
   if (mode == RX_SEG_SGD_SPEC && grid > 2048u) grid = 2048u;
   SEG_DISPATCH_F(mode, false, sh, row_update_kernel, dim3(grid), 0, (hipStream_t)stream, a);

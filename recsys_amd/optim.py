@@ -26,10 +26,11 @@ _SEPARATE_CLIP_LAUNCH = os.environ.get("RX_SEPARATE_CLIP") == "1"   # A/B timing
 _ONE_LAUNCH_PER_TABLE = os.environ.get("RX_NO_MULTI_TABLE") == "1"   # A/B timing of the multi-table launches
 
 _NO_SPECULATION = os.environ.get("RX_NO_SPECULATIVE_SGD") == "1"   # A/B: clipped SGD over field groups always in two phases
-# The same one-pass step on the general sorted path (rx_segreduce_fm): correct and tested, but OFF unless asked for.
-# Measured on fm_wide_d128 (125 M rows x 128, B = 65536): 0.748 ms per step against 0.629 in two phases -- a 512-byte
-# row's undo record is eight new 128-byte lines per distinct row, and first-touch line writes cost more than the
-# second pass they save.
+# The same one-pass step on the general sorted path (rx_segreduce_fm, records of the old rows only): correct and
+# tested, but OFF unless asked for.  Measured on fm_wide_d128 (125 M rows x 128, B = 65536): 0.54 ms per step against
+# 0.565 in two phases while the clip is idle -- first-touch writes of the records cost nearly what the second pass
+# saves -- and 1.0 ms when it bites (rows put back, two-phase step from T and g again), which it does on every
+# step of that workload at clip_norm = 1.
 _SPECULATE_SORTED = os.environ.get("RX_SPECULATIVE_SGD_SORTED") == "1"
 _NO_FUSED_TAIL = os.environ.get("RX_NO_FUSED_TAIL") == "1"      # clip factor, row updates and dense update as three launches (A/B)
 _FUSED_TAIL_MAX_ROWS, _FUSED_TAIL_MAX_PARTS = 1 << 18, 4096
@@ -122,12 +123,15 @@ def _rule_apply_fm(self, feat, bias_table, si, tsum, g, n_fields_ex, deep=None, 
     elif (self.kind == "sgd" and _SPECULATE_SORTED and not _NO_SPECULATION and self.owner.speculative and table.is_cuda and table.is_contiguous()
           and (rule2 is None or (rule2.kind == "sgd" and rule2.lr == self.lr))):
         # the same one-pass clipped SGD step on the general sorted path (rows wider than the field groups take,
-        # N > 1, B > 65536): undo records go where the reduce's `state` arguments point
-        undo = torch.empty(max(si.n, 1), 2 * dim, dtype=torch.float32, device=table.device)
-        undo2 = torch.empty(max(si.n, 1), 2, dtype=torch.float32, device=table.device) if bias_table is not None else None
-        sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_SGD_SPEC, table, state=undo, target2=table2, state2=undo2,
+        # N > 1, B > 65536).  The records keep only the rows of before the step (RX_SEG_SGD_SPEC_OLD: a 512-byte
+        # row's record of gradient + row is eight new lines per distinct row, and cost more than the second pass
+        # saved): when the clip bites, step() puts the rows back and takes the two-phase step from T and g again.
+        undo = torch.empty(max(si.n, 1), dim, dtype=torch.float32, device=table.device)
+        undo2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=table.device) if bias_table is not None else None
+        sq = ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_SGD_SPEC_OLD, table, state=undo, target2=table2, state2=undo2,
                               lr=self.lr, want_sq=True, sq_out=self.owner._sq_slice(si.n, dim, table.device), deep=deep)
-        self.owner._pending.append((self, feat, undo, si, sq, (rule2, bias_table, undo2) if bias_table is not None else None, "spec"))
+        self.owner._pending.append((self, feat, undo, si, sq, (rule2, bias_table, undo2) if bias_table is not None else None, "spec_old"))
+        self.owner._again[id(feat)] = (tsum, g, n_fields_ex, deep)
         self.owner._has_spec = True
         return
     compact = torch.empty(max(si.n, 1), dim, dtype=torch.float32, device=table.device)
@@ -206,6 +210,7 @@ class FusedOptimizer:
         self.speculative = bool(speculative) if speculative is not None else not self.dense
         self._pending = []
         self._has_spec = False                        # a pending entry whose rows the reduce already moved (speculative clipped SGD)
+        self._again = {}                              # id(table) -> (T, g, fields, tower gradient) of a "spec_old" entry: what its redo starts from
         self._zero = None
         self._one = None
         self._deferred = []                            # reduces queued by the backward while a clip is set
@@ -255,6 +260,11 @@ class FusedOptimizer:
             return
         for k, e in enumerate(self._pending):
             rule, param, undo, si, sq, comp, flag = e
+            if flag == "spec_old":
+                rule2, param2, undo2 = comp if comp is not None else (None, None, None)
+                ops.row_update(undo, si, _lib.RX_SEG_RESTORE, param.data, compact2=undo2, table2=param2.data if param2 is not None else None)
+                self._pending[k] = (rule, param, undo, si, sq, comp, "redo_old")
+                continue
             if flag != "spec":
                 continue
             if self._zero is None or self._zero.device != param.device:
@@ -271,6 +281,7 @@ class FusedOptimizer:
             p.grad = None
         self._restore_speculative()        # gradients dropped without a step: the rows go back
         self._pending.clear()
+        self._again.clear()
         self._deferred.clear()
         self._sq_used = 0
 
@@ -322,6 +333,23 @@ class FusedOptimizer:
                                   eps=rule.eps, scale=scale if (scale is not None or not spec) else self._one, compact2=compact2,
                                   table2=param2.data if param2 is not None else None,
                                   state2=rule2._state_for(param2) if rule2 is not None else None)
+            elif spec in ("spec_old", "redo_old"):
+                if spec == "spec_old" and scale is None:
+                    continue        # clip switched off after the backward pass: the rows already hold the plain step
+                # the two-phase step from T and g again -- every launch of it returns at once while the factor is 1
+                # ("spec_old": the rows hold the step already), or runs in full ("redo_old": the rows were put back)
+                rule2, param2, undo2 = comp if comp is not None else (None, None, None)
+                tsum, g, n_fields_ex, deep = self._again[id(param)]
+                gated = spec == "spec_old"
+                t2 = param2.data if param2 is not None else None
+                if gated:
+                    ops.row_update(compact, si, _lib.RX_SEG_RESTORE_IF_CLIPPED, param.data, scale=scale, compact2=undo2, table2=t2)
+                grads = torch.empty(max(si.n, 1), compact.shape[1], dtype=torch.float32, device=param.device)
+                grads2 = torch.empty(max(si.n, 1), dtype=torch.float32, device=param.device) if param2 is not None else None
+                ops.segreduce_fm(tsum, g, n_fields_ex, si, _lib.RX_SEG_COMPACT_IF_CLIPPED if gated else _lib.RX_SEG_COMPACT, grads,
+                                 table=param.data, target2=grads2, scale=scale if gated else None, deep=deep)
+                ops.row_update(grads, si, _lib.RX_SEG_SGD_IF_CLIPPED if gated else _lib.RX_SEG_SGD, param.data, lr=rule.lr, scale=scale,
+                               compact2=grads2, table2=t2)
             elif spec:
                 if spec == "spec" and scale is None:
                     continue        # clip switched off after the backward pass: the rows already hold the plain step
@@ -393,6 +421,7 @@ class FusedOptimizer:
         scale, self.last_total_norm = ops.step_tail(items, r0.mode, r0.lr, r0.eps, [p.data for p, _ in live], [g for _, g in live], states,
                                                     dmode, self.lr, self.eps, parts, parts64, float(self.clip_norm))
         self._pending.clear()
+        self._again.clear()
         self._has_spec = False
         self._sq_used = 0
         return True
@@ -527,6 +556,7 @@ class FusedOptimizer:
                     state2=rule2._state_for(param2) if rule2 is not None else None,
                     clip_parts=parts[0], max_norm=float(self.clip_norm))
                 self._pending.clear()
+                self._again.clear()
             elif (parts or parts64 is not None) and acc is None and self._fused_tail(parts[-1] if parts else None, parts64):
                 return
             elif parts or parts64 is not None:
@@ -538,6 +568,7 @@ class FusedOptimizer:
                                                              float(self.clip_norm))
         self._update_pending_rows(scale)
         self._pending.clear()
+        self._again.clear()
         self._has_spec = False
         self._sq_used = 0
         self._dense_step_all(scale)
