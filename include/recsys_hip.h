@@ -129,6 +129,10 @@ typedef struct {
   const int64_t* occs;                            /* [B] or NULL */
   const int64_t* temps;                           /* [B] or NULL */
   int64_t B; int32_t N; int32_t dim;
+  /* rx_mf_score_bwd only, all 0 otherwise: the final sum that a rx_mf_score_fwd_bce call with d_loss = NULL left
+   * out.  loss_out[0] = sum(loss_parts[0 .. n_loss_parts)) / loss_count, added in the order of that call's own
+   * finishing launch (bit for bit the same loss), by the first block of the backward launch. */
+  const double* loss_parts; int32_t n_loss_parts; int32_t pad_; int64_t loss_count; double* loss_out;
 } rx_mf_args;
 
 int rx_mf_score_fwd(const rx_mf_args* a, float* d_logits, int32_t* err_flag, int device,
@@ -137,8 +141,11 @@ int rx_mf_score_fwd(const rx_mf_args* a, float* d_logits, int32_t* err_flag, int
 /* rx_mf_score_fwd followed by the loss of the MF family and GMF (vanilla_mf.py:35-39, gmf.py:41-45:
  * F.binary_cross_entropy_with_logits, mean over B * N, fp64) in one launch plus the one-block sum of the
  * block partials: d_loss [1] fp64, d_dlogits [B, N] = (sigmoid(x) - y) / (B N) (what the backward starts
- * from), d_logits [B, N] (may be NULL).  ws: rx_mf_score_fwd_bce_workspace_bytes bytes. */
+ * from), d_logits [B, N] (may be NULL).  ws: rx_mf_score_fwd_bce_workspace_bytes bytes.
+ * d_loss may be NULL: the block partials then stay in ws (rx_mf_score_fwd_bce_partials(B, dim) of them) and the
+ * backward launch adds them up (rx_mf_args.loss_parts = ws, loss_count = B * N): one launch less per train step. */
 size_t rx_mf_score_fwd_bce_workspace_bytes(int64_t B, int32_t dim);
+int32_t rx_mf_score_fwd_bce_partials(int64_t B, int32_t dim);
 int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, int labels_f64, float* d_logits,
                         float* d_dlogits, double* d_loss, void* ws, size_t ws_bytes, int32_t* err_flag,
                         int device, void* stream);

@@ -27,7 +27,8 @@ class MFArgs(C.Structure):
                 ("occ_table", vp), ("n_occ", i64), ("utemp_table", vp), ("temp_table", vp),
                 ("n_temp", i64), ("user_bias", vp), ("item_bias", vp), ("bias", vp),
                 ("lin_w", vp), ("lin_b", vp), ("users", vp), ("items", vp), ("occs", vp),
-                ("temps", vp), ("B", i64), ("N", i32), ("dim", i32)]
+                ("temps", vp), ("B", i64), ("N", i32), ("dim", i32),
+                ("loss_parts", vp), ("n_loss_parts", i32), ("pad_", i32), ("loss_count", i64), ("loss_out", vp)]
 
 
 class FMArgs(C.Structure):
@@ -105,6 +106,7 @@ PROTOTYPES = {
     "rx_gather_concat_bwd": (C.c_int, [vp, i64, i64, i32, i32, i32, vp, C.c_int, vp]),
     "rx_mf_score_fwd": (C.c_int, [C.POINTER(MFArgs), vp, vp, C.c_int, vp]),
     "rx_mf_score_fwd_bce_workspace_bytes": (sz, [i64, i32]),
+    "rx_mf_score_fwd_bce_partials": (i32, [i64, i32]),
     "rx_mf_score_fwd_bce": (C.c_int, [C.POINTER(MFArgs), vp, C.c_int, vp, vp, vp, vp, sz, vp, C.c_int, vp]),
     "rx_mf_bwd_grid": (i64, [i64, i32]),
     "rx_mf_score_bwd": (C.c_int, [C.POINTER(MFArgs), vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]),

@@ -171,7 +171,8 @@ def _mf_backward(ctx, g):
         """Gradients of everything an MF-family score reads, from dL/dlogit ``g`` [B, N]."""
         U, V, users, items = ctx.args
         kw = ctx.kw
-        user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, **kw)
+        user_occ, item_occ, utemp_occ, temp_occ, gsum, linw_grad = ops.mf_score_bwd(g, U, V, users, items, loss_final=getattr(ctx, "loss_final", None), **kw)
+        ctx.loss_final = None
         su = sorted_index(users, U.shape[0])
         si = sorted_index(items, V.shape[0])
         gU, gV = tables_backward((U, V), (su, si), (user_occ, item_occ))
@@ -206,7 +207,12 @@ class MFLoss(Function):
         ctx.kw = kw
         ctx.args = (U, V, users, items)
         ctx.lin_w = lin_w
-        loss, ctx.dlogits, _ = ops.mf_score_fwd_bce(U, V, users, items, labels.contiguous(), **kw)
+        # inside a train step (DEFER_LOSS_FINAL, set by the step drivers: a backward pass is certain to follow) the
+        # launch that adds the loss partials is left to the backward launch
+        defer = DEFER_LOSS_FINAL[0] and labels.dtype == torch.float64 and users.shape[0] > 0 and any(ctx.needs_input_grad[4:14])
+        out = ops.mf_score_fwd_bce(U, V, users, items, labels.contiguous(), defer_final=defer, **kw)
+        loss, ctx.dlogits = out[0], out[1]
+        ctx.loss_final = out[3] if defer else None
         return loss if labels.dtype == torch.float64 else loss.to(torch.float32)
 
     @staticmethod
@@ -453,7 +459,7 @@ class FMLoss(Function):
         bias_flat = None if bias_table is None else bias_table.reshape(-1)
         # inside a train step (DEFER_LOSS_FINAL, set by the step drivers: a backward pass is certain to follow) the
         # launch that adds the loss partials is left out and the backward's reduce writes the loss instead
-        defer = DEFER_LOSS_FINAL[0] and torch.is_grad_enabled() and ctx.needs_input_grad[4] and labels.dtype == torch.float64
+        defer = DEFER_LOSS_FINAL[0] and ctx.needs_input_grad[4] and labels.dtype == torch.float64     # (grad mode is off inside forward(): needs_input_grad is the test)
         out = ops.fm2_fwd_bce(feat, bias_flat, ex_idx, ex_base, item_idx, item_base, labels.contiguous(), defer_final=defer)
         loss, gt = out[0], out[1]
         ctx.loss_final = out[3] if defer else None

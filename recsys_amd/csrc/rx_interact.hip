@@ -195,7 +195,7 @@ extern "C" int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, in
   RX_ENTER(device);
   if (mf_check(a, "rx_mf_score_fwd_bce")) return 1;
   RX_REQUIRE(a->B >= 1, "rx_mf_score_fwd_bce: empty batch");
-  RX_REQUIRE(d_labels && d_dlogits && d_loss && ws, "rx_mf_score_fwd_bce: null argument");
+  RX_REQUIRE(d_labels && d_dlogits && ws, "rx_mf_score_fwd_bce: null argument");
   RX_REQUIRE(ws_bytes >= rx_mf_score_fwd_bce_workspace_bytes(a->B, a->dim) && ((uintptr_t)ws & 15) == 0, "rx_mf_score_fwd_bce: workspace too small or unaligned");
   RxRowShape sh;
   if (rx_fused_shape(a->dim, &sh, "rx_mf_score_fwd_bce")) return 1;
@@ -215,9 +215,17 @@ extern "C" int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, in
   else MF_BCE(1, 4);
 #undef MF_BCE
   RX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B * (int64_t)a->N, d_loss);
-  RX_LAUNCH_CHECK();
+  if (d_loss) {   // NULL: the block partials stay in ws and rx_mf_score_bwd adds them up (rx_mf_args.loss_parts)
+    hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)grid, a->B * (int64_t)a->N, d_loss);
+    RX_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" int32_t rx_mf_score_fwd_bce_partials(int64_t B, int32_t dim) {
+  if (B < 1 || dim < 1 || dim > RX_MAX_DIM) return 0;
+  RxRowShape sh = rx_row_shape(dim);
+  return (int32_t)rx_cdiv(B * sh.group, RX_BLOCK);
 }
 
 extern "C" int64_t rx_mf_bwd_grid(int64_t B, int32_t dim) {
@@ -291,6 +299,13 @@ mf_bwd_kernel(rx_mf_args a, const float* __restrict__ g, float* __restrict__ use
       row_store<VEC, CH>(temp_occ + b * dim, te, lg, group, dim);
     }
   }
+  if (a.loss_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    // the deferred end of the forward's loss: exactly bce_final_kernel (lane l takes l, l + 64, ...; fixed xor tree)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.n_loss_parts; i += 64) s += a.loss_parts[i];
+    s = rx_wave_sum_f64(s);
+    if (threadIdx.x == 0) a.loss_out[0] = s / (double)a.loss_count;
+  }
   if (linw_part) {
     // block-level sum of dw over the block's samples in group order (fixed => reproducible)
     const int gpb = blockDim.x / group;
@@ -313,6 +328,8 @@ extern "C" int rx_mf_score_bwd(const rx_mf_args* a, const float* d_g, float* d_u
   RX_REQUIRE(d_g && d_user_occ && d_item_occ, "rx_mf_score_bwd: null gradient buffer");
   RX_REQUIRE(!a->utemp_table || (d_utemp_occ && d_temp_occ), "rx_mf_score_bwd: temporal gradient buffers missing");
   RX_REQUIRE(!a->lin_w || d_linw_part, "rx_mf_score_bwd: lin_w given but no d_linw_part");
+  RX_REQUIRE(!a->loss_out || (a->loss_parts && a->n_loss_parts >= 1 && a->loss_count >= 1 && a->B >= 1),
+             "rx_mf_score_bwd: loss_out needs the forward's partial sums, their count and the number of logits");
   if (a->B == 0) return 0;
   RxRowShape sh;
   if (rx_fused_shape(a->dim, &sh, "rx_mf_score_bwd")) return 1;

@@ -236,9 +236,12 @@ def mf_score_fwd(U, V, users, items, **kw) -> Tensor:
     return logits
 
 
-def mf_score_fwd_bce(U, V, users, items, labels: Tensor, want_logits: bool = False, **kw):
+def mf_score_fwd_bce(U, V, users, items, labels: Tensor, want_logits: bool = False, defer_final: bool = False, **kw):
     """rx_mf_score_fwd_bce: logits, mean BCE loss (fp64) and dL/dlogit of the MF family / GMF from one forward
-    launch.  Returns (loss fp64 scalar, dlogits [B, N] fp32, logits [B, N] or None)."""
+    launch.  Returns (loss fp64 scalar, dlogits [B, N] fp32, logits [B, N] or None).  ``defer_final``: the
+    one-wavefront launch that adds the block partials is left out; the returned loss is written by the
+    ``mf_score_bwd`` call of the backward pass instead, to which the caller hands the fourth return value
+    (``mf_score_bwd(..., loss_final=)``)."""
     a, B, N = _mf_args(U, V, users, items, **kw)
     if labels.dtype not in (torch.float64, torch.float32):
         raise TypeError(f"label: expected float64 or float32, got {labels.dtype}")
@@ -252,16 +255,26 @@ def mf_score_fwd_bce(U, V, users, items, labels: Tensor, want_logits: bool = Fal
     dlogits = torch.empty(B, N, dtype=torch.float32, device=dev)
     logits = torch.empty(B, N, dtype=torch.float32, device=dev) if want_logits else None
     loss = torch.empty((), dtype=torch.float64, device=dev)
-    ws = _ws(int(lib.rx_mf_score_fwd_bce_workspace_bytes(B, U.shape[1])), dev)
-    check(lib.rx_mf_score_fwd_bce(C.byref(a), _p(labels), int(labels.dtype == torch.float64), _p(logits), _p(dlogits), _p(loss),
-                                  _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(U), _stream(U)), "rx_mf_score_fwd_bce")
+    need = int(lib.rx_mf_score_fwd_bce_workspace_bytes(B, U.shape[1]))
+    # deferred: the partials have to outlive this call, so they get a buffer of their own (a few KB)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer_final else _ws(need, dev)
+    check(lib.rx_mf_score_fwd_bce(C.byref(a), _p(labels), int(labels.dtype == torch.float64), _p(logits), _p(dlogits),
+                                  _p(None if defer_final else loss), _p(ws), ws.numel(), _p(_err_flag(dev)), _dev(U), _stream(U)),
+          "rx_mf_score_fwd_bce")
     _after_index_op(dev)
+    if defer_final:
+        return loss, dlogits, logits, (ws, int(lib.rx_mf_score_fwd_bce_partials(B, U.shape[1])), B * N, loss)
     return loss, dlogits, logits
 
 
-def mf_score_bwd(g: Tensor, U, V, users, items, **kw):
-    """Returns (user_occ [B,D], item_occ [B*N,D], utemp_occ, temp_occ, gsum [B], linw_grad [D])."""
+def mf_score_bwd(g: Tensor, U, V, users, items, loss_final=None, **kw):
+    """Returns (user_occ [B,D], item_occ [B*N,D], utemp_occ, temp_occ, gsum [B], linw_grad [D]).
+    ``loss_final``: (partials, their count, number of logits, loss tensor) of mf_score_fwd_bce(defer_final=True);
+    the launch then also writes that loss."""
     a, B, N = _mf_args(U, V, users, items, **kw)
+    if loss_final is not None:
+        parts, n_parts, count, loss_out = loss_final
+        a.loss_parts, a.n_loss_parts, a.loss_count, a.loss_out = parts.data_ptr(), n_parts, count, loss_out.data_ptr()
     _req(g, torch.float32, "grad_logits")
     if g.numel() != B * N:
         raise ValueError("grad_logits: wrong number of elements")

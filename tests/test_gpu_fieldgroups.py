@@ -470,7 +470,7 @@ def test_forward_between_backward_and_step_sees_the_rows_of_before_the_step(line
 
 
 @pytest.mark.parametrize("kind,clip", [("sgd", 1.0), ("sgd", None), ("adagrad", 0.02)])
-def test_loss_written_by_the_reduce_equals_the_forward_launch_bitwise(kind, clip):
+def test_loss_written_by_the_reduce_equals_the_forward_launch_bitwise(kind, clip, monkeypatch):
     """Inside a train step (utils.train_step, graph.GraphedTrainStep) the FM forward leaves its loss partials
     and the backward's reduce adds them up (one launch less between forward and reduce).  Same loss bits and
     same weights as a step whose forward finishes the loss itself; a plain model.loss() outside a step is
@@ -479,9 +479,13 @@ def test_loss_written_by_the_reduce_equals_the_forward_launch_bitwise(kind, clip
     from recsys_amd.models import fields
     from recsys_amd.optim import FusedOptimizer
     from recsys_amd.utils import train_step
+    from recsys_amd import ops
     dims = [7, 1000, 13, 5000, 3, 211]
     batches = [synthetic.criteo_batch(dims, 1100, seed=s, device="cuda") for s in (1, 2)]
     out = []
+    taken = []          # did the forward leave the final sum out?
+    orig = ops.fm2_fwd_bce
+    monkeypatch.setattr(ops, "fm2_fwd_bce", lambda *a, **k: (taken.append(bool(k.get("defer_final"))), orig(*a, **k))[1])
     for deferred in (False, True):
         torch.manual_seed(0)
         with torch.device("cuda"):
@@ -501,6 +505,7 @@ def test_loss_written_by_the_reduce_equals_the_forward_launch_bitwise(kind, clip
                 assert torch.equal(first, loss.detach())
                 losses.append(first)
         out.append((losses, [p.detach().clone() for p in m.parameters()]))
+    assert taken == [False, False, True, True]
     (la, wa), (lb, wb) = out
     assert all(torch.equal(x, y) for x, y in zip(la, lb)), (la, lb)
     assert all(torch.equal(x, y) for x, y in zip(wa, wb))

@@ -479,3 +479,38 @@ def test_step_tail_in_one_launch_equals_the_three_launches_bitwise(fixture, kind
     assert c0 == 0 and c1 == (0 if fixture.startswith("BiasMF") else 3)
     for a, b in zip(w1 + n1 + s1, w0 + n0 + s0):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("fixture", ["VanillaMF_d16", "BiasMF_d16", "GMF_d16", "SideFeaturesMF_d16", "TemporalMF_d16"])
+def test_mf_loss_written_by_the_backward_launch_equals_the_forward_launch_bitwise(fixture, monkeypatch):
+    """Inside a train step (utils.train_step, the graph recorders) rx_mf_score_fwd_bce leaves its loss partials and
+    rx_mf_score_bwd adds them up (one launch less per step).  Same loss bits and same weights as steps whose forward
+    finishes the loss itself; a plain model.loss() outside a step is complete as soon as it returns."""
+    from recsys_amd import optim, ops
+    from recsys_amd.utils import train_step
+    if fixture not in MODEL_FIXTURES:
+        pytest.skip(f"no golden capture named {fixture}")
+    rec = load_golden(fixture)
+    batch = to_torch(group(rec, "batch"), "cuda")
+    out = []
+    for deferred in (True, False):
+        m = _build(rec, fixture.split("_")[0]).train()
+        o = optim.FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        seen = []
+        orig = ops.mf_score_bwd
+        monkeypatch.setattr(ops, "mf_score_bwd", lambda *a, **k: (seen.append(k.get("loss_final") is not None), orig(*a, **k))[1])
+        losses = []
+        for _ in range(3):
+            if deferred:
+                losses.append(train_step(m, o, batch, 1.0).clone())
+            else:
+                o.zero_grad(); loss = m.loss(batch); loss.backward(); o.step()
+                losses.append(loss.detach().clone())
+        monkeypatch.setattr(ops, "mf_score_bwd", orig)
+        assert seen == [deferred] * 3
+        out.append((losses, [p.detach().clone() for p in m.parameters()]))
+        plain = m.loss(batch)               # outside a step: written by the forward's own finishing launch
+        assert torch.isfinite(plain).item()
+    (la, wa), (lb, wb) = out
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    assert all(torch.equal(x, y) for x, y in zip(wa, wb))
