@@ -150,12 +150,13 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     w = dict(model=model, opt=opt, batches=batches, B=B, desc=desc, graphed=None, dims=dims if "fields" in desc else None)
     if use_graph:
         from recsys_amd.graph import GraphedTrainStep
-        gs = GraphedTrainStep(model, opt, pipeline=True, cycle=os.environ.get("RX_BENCH_NO_CYCLE") != "1", cycle_len=10)
+        gs = GraphedTrainStep(model, opt, pipeline=True, cycle=os.environ.get("RX_BENCH_NO_CYCLE") != "1", cycle_len=10,
+                              ahead=int(os.environ.get("RX_BENCH_PREP_AHEAD", 2)))
         gs.add_batches(batches)
         w["graphed"] = gs
         desc["resident_batches"] = n_batches
         desc["launch"] = (f"HIP graph replays over {n_batches} resident batches: one graph per 10 consecutive steps where "
-                          "the step count allows, one graph per step otherwise; the indices of batch i+1 are grouped on a "
+                          f"the step count allows, one graph per step otherwise; the indices of batch i+{gs.ahead} are grouped on a "
                           "side stream while batch i trains (one index preparation per step, off the critical path)")
     else:
         desc["launch"] = "eager"

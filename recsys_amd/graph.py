@@ -138,8 +138,14 @@ def refuse_live_autograd_graphs(model) -> None:
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, warmup: int = 3, pipeline: bool = False, cycle: bool = False,
-                 cycle_len: int = 0):
+                 cycle_len: int = 0, ahead: int = 1):
+        """``ahead`` (with ``pipeline``): the step on slot i is recorded beside the index preparation of slot
+        i + ahead.  With 1 a step starts when the preparation that ran beside the previous step has finished, so
+        the longer of the two chains sets the pace and the shorter one idles at every join; with 2 a step's
+        preparation finished a whole step earlier and the chains only meet when one falls a full step behind.
+        A refreshed slot (``copy_batch``) must be in place before the step ``ahead`` slots earlier is launched."""
         self.model, self.opt, self.warmup = model, optimizer, warmup
+        self.ahead = max(1, int(ahead))
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.batches: List[Dict[str, torch.Tensor]] = []
         self.losses: List[torch.Tensor] = []
@@ -188,6 +194,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         K = len(prepared)
+        A = self.ahead = min(self.ahead, K - 1)
         shared = self._shared_branch(dev)
         for i, b in enumerate(prepared):
             g = _new_graph()
@@ -199,14 +206,14 @@ class GraphedTrainStep:
                     fork = _prep_stream(dev)
                     fork.wait_stream(main)
                     with torch.cuda.stream(fork):
-                        self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
+                        self.model.prepare(prepared[(i + A) % K], out=prepared[(i + A) % K])
                     loss = self._eager(b)
                 else:       # behind the model's own branch work, on its stream (see _shared_branch)
                     fork = shared
                     fork.wait_stream(main)
                     loss = self._eager(b)
                     with torch.cuda.stream(fork):
-                        self.model.prepare(prepared[(i + 1) % K], out=prepared[(i + 1) % K])
+                        self.model.prepare(prepared[(i + A) % K], out=prepared[(i + A) % K])
                 main.wait_stream(fork)
             _check_width(g, "GraphedTrainStep.add_batches")
             if self._pool is None:
@@ -243,7 +250,7 @@ class GraphedTrainStep:
                 main = torch.cuda.current_stream(dev)
                 fork = shared if shared is not None else _prep_stream(dev)
                 fork.wait_stream(main)
-                ready = None          # preparation of the slot the next step consumes
+                ready = {}            # slot -> event behind its preparation inside this graph
                 done = {}             # slot -> event recorded after this graph's step on it
 
                 def prepare_next(nxt):
@@ -260,16 +267,16 @@ class GraphedTrainStep:
                     return ev
 
                 for i in slots:
-                    if ready is not None:
-                        main.wait_event(ready)
-                    nxt = (i + 1) % K
+                    if i in ready:
+                        main.wait_event(ready.pop(i))
+                    nxt = (i + self.ahead) % K
                     if shared is None:
-                        ready = prepare_next(nxt)
+                        ready[nxt] = prepare_next(nxt)
                     losses.append(self._eager(prepared[i]).detach())
                     done[i] = torch.cuda.Event()
                     done[i].record(main)
                     if shared is not None:      # behind this step's branch work on the branch's stream
-                        ready = prepare_next(nxt)
+                        ready[nxt] = prepare_next(nxt)
                 main.wait_stream(fork)
             _check_width(g, "GraphedTrainStep (multi-step segment)")
             self.segments[first] = (g, len(slots), losses)

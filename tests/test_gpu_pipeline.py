@@ -338,8 +338,9 @@ def test_round_graph_matches_eager_bitwise(name):
         assert torch.equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("ahead", [1, 2])
 @pytest.mark.parametrize("name", ["FieldFM_line_rows", "FieldFM", "VanillaMF"])
-def test_segment_graphs_match_eager_bitwise(name):
+def test_segment_graphs_match_eager_bitwise(name, ahead):
     """The launch structure bench.py times: ``cycle_len`` < number of resident batches, i.e. one graph per
     SEGMENT of consecutive slots (here 3 + 3 + 2 over 8 batches) with the index preparation of the next
     slot running ahead on the side stream across segment boundaries, mixed with single-step replays.
@@ -367,7 +368,7 @@ def test_segment_graphs_match_eager_bitwise(name):
         ops.set_index_check("deferred")
         try:
             if graphed:
-                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True, cycle=True, cycle_len=3)
+                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True, cycle=True, cycle_len=3, ahead=ahead)
                 gs.add_batches(batches)
                 assert sorted(gs.segments) == [0, 3, 6] and [gs.segment_at(s) for s in (0, 3, 6)] == [3, 3, 2]
                 assert gs.segment_at(1) == 0
@@ -379,6 +380,71 @@ def test_segment_graphs_match_eager_bitwise(name):
             else:
                 for i in [0, 0] + list(range(K)) * 3:
                     opt.zero_grad(); loss = m.loss(batches[i]); loss.backward(); opt.step()
+            ops.raise_if_index_error()
+        finally:
+            ops.set_index_check("sync")
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(loss.item())))
+    (sa, la), (sb, lb) = results
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("ahead", [1, 2])
+@pytest.mark.parametrize("name", ["FieldFM", "VanillaMF"])
+def test_refreshed_slots_are_prepared_ahead_bitwise(name, ahead):
+    """A stream of 24 DIFFERENT batches through 8 resident slots: the step on slot i is recorded beside the index
+    preparation of slot i + ahead, so a slot's new contents (copy_batch) have to be in place before the step
+    ``ahead`` slots earlier is launched -- and then the preparation must be the one of the new contents.  Segments
+    of three steps and single-step graphs mixed; weights and last loss equal eager steps over the stream, bit
+    for bit (a stale preparation would reduce the gradients of the wrong rows)."""
+    from recsys_amd import ops, synthetic
+    from recsys_amd.graph import GraphedTrainStep
+    from recsys_amd.models.fields import FieldFM
+    from recsys_amd.models.matrix_factorization import VanillaMF
+    from recsys_amd.optim import FusedOptimizer
+    d = synthetic.ML1M
+    dims = [7, 1000, 13, 5000, 3, 211]
+    K, T = 8, 24
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(6)
+        with torch.device("cuda"):
+            if name == "FieldFM":
+                m = FieldFM(dims, 16)
+                stream = [synthetic.criteo_batch(dims, 300, seed=140 + i, device="cuda") for i in range(T)]
+            else:
+                m = VanillaMF(d["n_users"], d["n_items"], 16)
+                stream = [synthetic.ml1m_batch(256, seed=120 + i, device="cuda") for i in range(T)]
+        m.train()
+        opt = FusedOptimizer(m, kind="sgd", lr=0.05, clip_norm=1.0)
+        ops.set_index_check("deferred")
+        try:
+            if graphed:
+                slots = [{k: v.clone() for k, v in b.items()} for b in stream[:K]]
+                init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+                gs = GraphedTrainStep(m, opt, warmup=2, pipeline=True, cycle=True, cycle_len=3, ahead=ahead)
+                gs.add_batches(slots)
+                with torch.no_grad():       # the warm-up steps moved the weights: start both runs from the same ones
+                    for k, v in m.state_dict().items():
+                        v.copy_(init[k])
+                j = 0
+                plan = [3, 3, 1, 1] + [3, 1, 1, 1, 2] + [1, 1, 1, 3, 2]      # launches per round: 8 steps each
+                for L in plan:
+                    for t in range(j + ahead, j + L + ahead):       # what the launches below prepare
+                        if K <= t < T:
+                            gs.copy_batch(t % K, stream[t])
+                    if L == 1:
+                        gs(j % K)
+                    else:
+                        assert gs.segment_at(j % K) == L
+                        gs.run_cycle(j % K)
+                    j += L
+                assert j == T
+                loss = gs.losses[(T - 1) % K] if plan[-1] == 1 else gs.segments[6][2][-1]
+            else:
+                for b in stream:
+                    opt.zero_grad(); loss = m.loss(b); loss.backward(); opt.step()
             ops.raise_if_index_error()
         finally:
             ops.set_index_check("sync")
