@@ -151,7 +151,10 @@ def build_workload(name: str, device, rank: int, world: int, clip, use_graph: bo
     if use_graph:
         from recsys_amd.graph import GraphedTrainStep
         gs = GraphedTrainStep(model, opt, pipeline=True, cycle=os.environ.get("RX_BENCH_NO_CYCLE") != "1", cycle_len=10,
-                              ahead=int(os.environ.get("RX_BENCH_PREP_AHEAD", 2)))
+                              # preparation depth, measured per workload (A/B on one box): two slots ahead where the side
+                              # chain is as long as the step (fm_criteo 0.1265 -> 0.1237 ms, neumf_ml1m 0.095 -> 0.080), one
+                              # where it is short (mf_ml1m 0.0525 against 0.0556 with two, deepfm_criteo_bf16 1.349 / 1.357)
+                              ahead=int(os.environ.get("RX_BENCH_PREP_AHEAD", 2 if name in ("fm_criteo", "neumf_ml1m") else 1)))
         gs.add_batches(batches)
         w["graphed"] = gs
         desc["resident_batches"] = n_batches
