@@ -122,28 +122,43 @@ mf_fwd_kernel(rx_mf_args a, float* __restrict__ logits, int group, int32_t* err_
 // Forward + loss of the MF family / GMF in one launch: the lane that holds a logit also forms its BCE term
 // and dL/dlogit = (sigmoid(x) - y) / (B N) in fp64 (the arithmetic of bce_kernel); every block stores the
 // fp64 sum of its terms, bce_final_kernel adds the block sums in a fixed order.
+// One pair's BCE term (returned) and dL/dlogit, fp64: the arithmetic of bce_kernel.
+template <bool F64>
+__device__ __forceinline__ double mf_bce_pair(const void* __restrict__ labels, int64_t at, float xf, double inv_m, float* __restrict__ dlogits,
+                                              float* __restrict__ logits) {
+  const double x = (double)xf;
+  const double y = F64 ? reinterpret_cast<const double*>(labels)[at] : (double)reinterpret_cast<const float*>(labels)[at];
+  const double e = exp(-fabs(x));
+  const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+  dlogits[at] = (float)((sig - y) * inv_m);
+  if (logits) logits[at] = xf;
+  return fmax(x, 0.0) - x * y + log1p(e);
+}
+
 template <int VEC, int CH, bool F64>
 __global__ void __launch_bounds__(RX_BLOCK)
 mf_fwd_bce_kernel(rx_mf_args a, const void* __restrict__ labels, float* __restrict__ logits, float* __restrict__ dlogits,
-                  double* __restrict__ partial, int group, int32_t* err_flag) {
+                  double* __restrict__ partial, int group, int staged, int32_t* err_flag) {
   __shared__ double wsum[RX_BLOCK / 64];
+  extern __shared__ float mf_xs[];      // staged: [lane groups of the block][N] logits
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t b = gid / group;
   const int lg = (int)(gid % group);
+  const int N = a.N;
+  const double inv_m = 1.0 / ((double)a.B * (double)N);
   double term = 0.0;
-  if (b < a.B) {
-    const int N = a.N;
-    const double inv_m = 1.0 / ((double)a.B * (double)N);
-    mf_forward_sample<VEC, CH>(a, b, lg, group, lg == 0 ? err_flag : nullptr, [&](int n, float xf) {
-      const int64_t at = b * N + n;
-      const double x = (double)xf;
-      const double y = F64 ? reinterpret_cast<const double*>(labels)[at] : (double)reinterpret_cast<const float*>(labels)[at];
-      const double e = exp(-fabs(x));
-      term += fmax(x, 0.0) - x * y + log1p(e);
-      const double sig = x >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
-      dlogits[at] = (float)((sig - y) * inv_m);
-      if (logits) logits[at] = xf;
-    });
+  if (staged) {
+    // The sample's N logits go through LDS and its lane group shares the fp64 part, lane l taking pairs l,
+    // l + group, ...: left to the one lane that holds the logits, the fp64 sequence ran N times per sample
+    // with a quarter of the lanes (rows of 16 floats) at work.
+    float* xs = mf_xs + (threadIdx.x / group) * N;
+    if (b < a.B) mf_forward_sample<VEC, CH>(a, b, lg, group, lg == 0 ? err_flag : nullptr, [&](int n, float xf) { xs[n] = xf; });
+    __syncthreads();
+    if (b < a.B)
+      for (int n = lg; n < N; n += group) term += mf_bce_pair<F64>(labels, b * N + n, xs[n], inv_m, dlogits, logits);
+  } else if (b < a.B) {
+    mf_forward_sample<VEC, CH>(a, b, lg, group, lg == 0 ? err_flag : nullptr,
+                               [&](int n, float xf) { term += mf_bce_pair<F64>(labels, b * N + n, xf, inv_m, dlogits, logits); });
   }
   term = rx_wave_sum_f64(term);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = term;
@@ -202,10 +217,14 @@ extern "C" int rx_mf_score_fwd_bce(const rx_mf_args* a, const void* d_labels, in
   const unsigned grid = (unsigned)rx_cdiv(a->B * sh.group, RX_BLOCK);
   double* partial = (double*)ws;
   hipStream_t st = (hipStream_t)stream;
+  // room for every lane group's N logits in LDS (see the kernel): beyond 32 KiB the lane that holds them does the loss
+  const size_t want = (size_t)(RX_BLOCK / sh.group) * (size_t)a->N * sizeof(float);
+  const int staged = want <= 32 * 1024;
+  const size_t xs_bytes = staged ? want : 0;
 #define MF_BCE(V, C)                                                                                                                                \
   do {                                                                                                                                              \
-    if (labels_f64) hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, true>), dim3(grid), dim3(RX_BLOCK), 0, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, err_flag); \
-    else hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, false>), dim3(grid), dim3(RX_BLOCK), 0, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, err_flag);           \
+    if (labels_f64) hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, true>), dim3(grid), dim3(RX_BLOCK), xs_bytes, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, staged, err_flag); \
+    else hipLaunchKernelGGL((mf_fwd_bce_kernel<V, C, false>), dim3(grid), dim3(RX_BLOCK), xs_bytes, st, *a, d_labels, d_logits, d_dlogits, partial, sh.group, staged, err_flag);           \
   } while (0)
   if (sh.vec == 4 && sh.chunks == 1) MF_BCE(4, 1);
   else if (sh.vec == 4 && sh.chunks == 2) MF_BCE(4, 2);
