@@ -372,10 +372,10 @@ def test_segment_graphs_match_eager_bitwise(name, ahead):
                 gs.add_batches(batches)
                 assert sorted(gs.segments) == [0, 3, 6] and [gs.segment_at(s) for s in (0, 3, 6)] == [3, 3, 2]
                 assert gs.segment_at(1) == 0
-                gs(0); gs(1); gs(2)                                   # round 1: single steps, then segments
+                gs(0); gs(1); gs(2)                                   # first pass over the slots: single steps, then segments
                 gs.run_cycle(3); gs.run_cycle(6)
-                gs.run_cycle(0); gs(3); gs(4); gs(5); gs.run_cycle(6)  # round 2: mixed
-                gs.run_cycle(0); gs.run_cycle(3); gs(6); gs(7)         # round 3
+                gs.run_cycle(0); gs(3); gs(4); gs(5); gs.run_cycle(6)  # second pass: mixed
+                gs.run_cycle(0); gs.run_cycle(3); gs(6); gs(7)         # third pass
                 loss = gs.losses[7]
             else:
                 for i in [0, 0] + list(range(K)) * 3:
